@@ -1,0 +1,209 @@
+/*
+ * glrm_hip.h -- C ABI of libglrm_hip.so, the MI355X (gfx950) engine behind
+ * LowRankModels.jl's `fit!(glrm::GLRM, params::ProxGradParams)`.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.
+ * A Julia `ccall`, a Python `ctypes` or a C caller binds exactly these symbols.
+ * The same entry points exist with a `glrm_cpu_` prefix in oracle/ (the CPU
+ * restatement used ONLY as the parity checker and CPU baseline).
+ *
+ * Reference interfaces replaced (paths relative to the LowRankModels.jl tree):
+ *   glrm_params    <- ProxGradParams                src/algorithms/proxgrad.jl:4-31
+ *   glrm_problem   <- GLRM struct + Omega lists     src/glrm.jl:12-22, src/modify_glrm.jl:5-18
+ *   glrm_loss      <- Loss subtypes (scalar)        src/losses.jl:138-352
+ *   glrm_reg       <- Regularizer subtypes          src/regularizers.jl:52-114,295-318
+ *   glrm_hip_fit   <- fit!(::GLRM,::ProxGradParams) src/algorithms/proxgrad.jl:34-220
+ *   glrm_hip_objective <- objective(glrm,X,Y;...)   src/evaluate_fit.jl:57-81
+ *   objective/seconds arrays <- ConvergenceHistory  src/convergence.jl:3-27
+ *
+ * Conventions
+ *   - X is k x m, Y is k x n, both COLUMN-major with leading dimension k, i.e.
+ *     X[:,e] and Y[:,f] are k contiguous doubles (same as the Julia arrays,
+ *     src/algorithms/proxgrad.jl:90-91).
+ *   - All indices are 0-based across this ABI (the Julia shim shifts by one).
+ *   - Omega is handed over twice and the two views are NEVER derived from each
+ *     other: CSR-by-row = observed_features, CSC-by-column = observed_examples,
+ *     both in the reference's list order with duplicates kept
+ *     (src/modify_glrm.jl:8-12).
+ *   - Every function returns 0 on success or a negative glrm_status; the message
+ *     is available from glrm_hip_last_error() (thread-local).  Nothing throws or
+ *     aborts across the boundary.
+ *   - A handle is not thread-safe (one call at a time per handle).
+ */
+#ifndef GLRM_HIP_H
+#define GLRM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GLRM_HIP_ABI_VERSION 1
+
+typedef enum glrm_status {
+  GLRM_OK = 0,
+  GLRM_ERR_INVALID = -1,     /* bad argument / inconsistent sizes (reference: error(...) src/glrm.jl:39-43) */
+  GLRM_ERR_UNSUPPORTED = -2, /* loss / regularizer kind or rank not implemented by the engine */
+  GLRM_ERR_HIP = -3,         /* HIP runtime error */
+  GLRM_ERR_COMM = -4,        /* reserved (collectives live in the host layer) */
+  GLRM_ERR_OOM = -5,         /* device or host allocation failed */
+  GLRM_ERR_NONFINITE = -6    /* NaN observation (src/glrm.jl:63-71) or bad Bool label (src/losses.jl:104) */
+} glrm_status;
+
+/* Scalar losses, src/losses.jl. */
+typedef enum glrm_loss_kind {
+  GLRM_LOSS_QUAD = 0,           /* QuadLoss          :138-148  scale            */
+  GLRM_LOSS_L1 = 1,             /* L1Loss            :152-162  scale            */
+  GLRM_LOSS_HUBER = 2,          /* HuberLoss         :166-179  scale, p0=crossover */
+  GLRM_LOSS_QUANTILE = 3,       /* QuantileLoss      :186-203  scale, p0=quantile  */
+  GLRM_LOSS_PERIODIC = 4,       /* PeriodicLoss      :209-224  scale, p0=T         */
+  GLRM_LOSS_POISSON = 5,        /* PoissonLoss       :231-243  scale            */
+  GLRM_LOSS_ORDINAL_HINGE = 6,  /* OrdinalHingeLoss  :247-294  scale, p0=min, p1=max */
+  GLRM_LOSS_LOGISTIC = 7,       /* LogisticLoss      :298-311  scale; a in {1.0 (true), 0.0 (false)} */
+  GLRM_LOSS_WEIGHTED_HINGE = 8, /* WeightedHingeLoss :317-352  scale, p0=case_weight_ratio; a in {1.0,0.0} */
+  GLRM_LOSS_KIND_COUNT = 9
+} glrm_loss_kind;
+
+/* Regularizers named by the north star, src/regularizers.jl. */
+typedef enum glrm_reg_kind {
+  GLRM_REG_ZERO = 0,            /* ZeroReg                 :91-97   */
+  GLRM_REG_QUAD = 1,            /* QuadReg(scale)          :52-58   */
+  GLRM_REG_ONE = 2,             /* OneReg(scale)           :79-88   */
+  GLRM_REG_NONNEG = 3,          /* NonNegConstraint        :101-114 */
+  GLRM_REG_UNIT_ONE_SPARSE = 4, /* UnitOneSparseConstraint :295-318 */
+  GLRM_REG_KIND_COUNT = 5
+} glrm_reg_kind;
+
+typedef struct glrm_loss {
+  int32_t kind;     /* glrm_loss_kind */
+  int32_t reserved; /* must be 0 */
+  double scale;
+  double p0;
+  double p1;
+} glrm_loss; /* 32 bytes */
+
+typedef struct glrm_reg {
+  int32_t kind;     /* glrm_reg_kind */
+  int32_t reserved; /* must be 0 */
+  double scale;
+} glrm_reg; /* 16 bytes */
+
+#define GLRM_PROBLEM_DEVICE_ARRAYS 1 /* flags bit 0: rowptr..colvals are DEVICE pointers (copied, not adopted) */
+
+/*
+ * One shard of a GLRM.  A single-GPU problem is the shard
+ * [row_begin,row_end) = [0,m), [col_begin,col_end) = [0,n).
+ * The shard owns the X half-step of its rows and the Y half-step of its
+ * columns; X (k x m) and Y (k x n) are replicated on every shard
+ * (row/column independence: src/algorithms/proxgrad_multithread.jl:118,163).
+ */
+typedef struct glrm_problem {
+  int64_t m, n;               /* global matrix size */
+  int32_t k;                  /* rank */
+  int32_t flags;              /* GLRM_PROBLEM_* */
+  int64_t row_begin, row_end; /* rows whose x_e this shard updates */
+  int64_t col_begin, col_end; /* columns whose y_f this shard updates */
+  /* CSR over the local rows: observed_features[e] for e in [row_begin,row_end) */
+  const int64_t* rowptr;      /* (row_end-row_begin)+1 entries, rowptr[0]==0 */
+  const int32_t* colidx;      /* global column ids, list order, duplicates kept */
+  const double* rowvals;      /* A[e,f] for each listed (e,f) */
+  /* CSC over the local columns: observed_examples[f] for f in [col_begin,col_end) */
+  const int64_t* colptr;      /* (col_end-col_begin)+1 entries, colptr[0]==0 */
+  const int32_t* rowidx;      /* global row ids */
+  const double* colvals;
+  const glrm_loss* losses;    /* n_losses entries (host memory) */
+  int64_t n_losses;           /* 1 (every column alike) or n */
+  const glrm_reg* rx;         /* n_rx entries (host memory) */
+  int64_t n_rx;               /* 1 (every row alike) or row_end-row_begin */
+  const glrm_reg* ry;
+  int64_t n_ry;               /* 1 or col_end-col_begin */
+} glrm_problem;
+
+/* ProxGradParams, src/algorithms/proxgrad.jl:4-12 (inner_iter already merged, :22-23). */
+typedef struct glrm_params {
+  double stepsize;
+  int64_t max_iter;
+  int64_t inner_iter_X;
+  int64_t inner_iter_Y;
+  double abs_tol;
+  double rel_tol;
+  double min_stepsize;
+} glrm_params;
+
+typedef struct glrm_options {
+  int32_t device_id; /* HIP device ordinal; -1 = current device */
+  int32_t profile;   /* 1 = bracket every sweep launch with HIP events (glrm_hip_kernel_stats) */
+  int32_t waves_row; /* waves cooperating on one row   (0 = choose from mean |Omega_e|; 1, 4 or 16) */
+  int32_t waves_col; /* waves cooperating on one column (0 = choose from mean |Omega^f|) */
+  void* stream;      /* hipStream_t to launch on; NULL = the handle creates its own */
+} glrm_options;
+
+typedef struct glrm_handle glrm_handle;
+
+/* ---- whole-fit API (what the Julia `fit!` shim calls) -------------------------------- */
+
+int glrm_hip_version(void);
+const char* glrm_hip_last_error(void);
+
+/* Copies the shard's Omega views, values and descriptors to the device. */
+int glrm_hip_create(glrm_handle** out, const glrm_problem* p, const glrm_options* o);
+void glrm_hip_destroy(glrm_handle* h); /* NULL is a no-op */
+
+/*
+ * fit!(glrm, ProxGradParams) for a single-shard handle (src/algorithms/proxgrad.jl:34-220).
+ * X (k x m) and Y (k x n) are read on entry (warm start) and overwritten on exit.
+ * objective[0] is the full initial objective (loss + rx + ry, :76); objective[i>=1] is
+ * sum(obj_by_col) after outer iteration i (:205, excludes rx).  seconds[] is cumulative
+ * wall-clock like ch.times (src/convergence.jl:22-26).  cap must be >= max_iter+1.
+ */
+int glrm_hip_fit(glrm_handle* h, const glrm_params* prm, double* X, double* Y,
+                 double* objective, double* seconds, int64_t cap, int64_t* n_recorded);
+
+/* objective(glrm, X, Y; include_regularization) over observed_examples (src/evaluate_fit.jl:57-81). */
+int glrm_hip_objective(glrm_handle* h, const double* X, const double* Y, int include_reg, double* out);
+
+/* ---- step-level API (multi-GPU hosts: one process per GPU, collectives in the host) ---- */
+/*
+ * Device-resident factors use leading dimension ld = glrm_hip_factor_ld(h) >= k
+ * (zero padded).  A distributed host allocates dX (ld*m), dY (ld*n), dObjCol (n) and
+ * dObjRow (m) doubles on the handle's device, binds them, and between the calls below
+ * all-gathers the slices the shard wrote:
+ *   step_x     -> dX[ld*row_begin : ld*row_end]
+ *   step_y     -> dY[ld*col_begin : ld*col_end], dObjCol[col_begin:col_end]
+ *   col_losses -> dObjCol[col_begin:col_end]       (loss only, no ry)
+ *   row_penalties -> dObjRow[row_begin:row_end]    (rx_e(x_e))
+ *   col_penalties -> dObjCol[col_begin:col_end]    (ry_f(y_f))
+ * All launches are asynchronous on the handle's stream.
+ */
+int glrm_hip_factor_ld(glrm_handle* h);
+int glrm_hip_bind_buffers(glrm_handle* h, void* dX, void* dY, void* dObjCol, void* dObjRow);
+int glrm_hip_set_factors(glrm_handle* h, const double* X, const double* Y); /* host k x m, k x n -> device */
+int glrm_hip_get_factors(glrm_handle* h, double* X, double* Y);             /* device -> host (synchronises) */
+int glrm_hip_reset_stepsizes(glrm_handle* h, double stepsize);              /* alpharow, alphacol (:69-70,:112-115) */
+int glrm_hip_step_x(glrm_handle* h, double min_stepsize);                   /* one inner X sweep (:118-156) */
+int glrm_hip_step_y(glrm_handle* h, double min_stepsize);                   /* one inner Y sweep (:162-201) */
+int glrm_hip_col_losses(glrm_handle* h);
+int glrm_hip_row_penalties(glrm_handle* h);
+int glrm_hip_col_penalties(glrm_handle* h);
+/* Fixed-order sum of n device doubles (independent of the number of shards); synchronises. */
+int glrm_hip_sum(glrm_handle* h, const void* dvec, int64_t n, double* out);
+int glrm_hip_synchronize(glrm_handle* h);
+
+/* ---- introspection ------------------------------------------------------------------- */
+
+typedef struct glrm_kernel_stats {
+  int64_t launches_x, launches_y;
+  double ms_x, ms_y;           /* summed HIP-event durations of the row / column sweeps (profile=1) */
+  int64_t trials_x, trials_y;  /* line-search trials taken (sum over segments and sweeps) */
+  int64_t accepts_x, accepts_y;
+  int64_t nnz_rows, nnz_cols;  /* |Omega| of the local CSR / CSC */
+  int32_t waves_row, waves_col, ld, reserved;
+} glrm_kernel_stats;
+
+int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GLRM_HIP_H */

@@ -1,0 +1,19 @@
+"""lowrankmodels.jl_amd -- MI355X-native engine for LowRankModels.jl's proximal-gradient ``fit!``.
+
+Host-side mirror of the reference interface for that one path (GLRM / losses / regularizers /
+ProxGradParams / fit! / ConvergenceHistory) over the C ABI of ``libglrm_hip.so``
+(include/glrm_hip.h).  See DESIGN.md for scope and INTEGRATION.md for the Julia binding.
+"""
+from . import _capi
+from ._capi import GLRMError
+from .convergence import ConvergenceHistory, update_ch
+from .fit import ShardedFit, fit, fit_b, objective, partition
+from .glrm import GLRM, copy_estimate, parameter_estimate, scale_regularizer_, sort_observations
+from .losses import (HingeLoss, HuberLoss, L1Loss, LogisticLoss, Loss, OrdinalHingeLoss, PeriodicLoss,
+                     PoissonLoss, QuadLoss, QuantileLoss, WeightedHingeLoss, embedding_dim, evaluate, grad)
+from .params import AbstractParams, HipProxGradParams, Params, ProxGradParams
+from .regularizers import (NonNegConstraint, OneReg, QuadReg, Regularizer, UnitOneSparseConstraint, ZeroReg, prox)
+
+fit_inplace = fit_b  # Julia's `fit!`
+
+__all__ = [n for n in dir() if not n.startswith("_")]

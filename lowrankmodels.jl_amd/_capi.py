@@ -1,0 +1,256 @@
+"""ctypes binding of the C ABI declared in include/glrm_hip.h.
+
+The product binds ``libglrm_hip.so`` with the ``glrm_hip_`` prefix (:func:`hip_api`).  The
+same binder is reused by tests/ to bind the CPU oracle (``glrm_cpu_`` prefix) -- the product
+never does that, and :func:`hip_api` raises if the HIP library is missing (no CPU fallback).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+ABI_VERSION = 1
+
+GLRM_OK = 0
+ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_COMM, ERR_OOM, ERR_NONFINITE = -1, -2, -3, -4, -5, -6
+PROBLEM_DEVICE_ARRAYS = 1
+
+
+class GLRMError(RuntimeError):
+    """A negative glrm_status from the engine (the reference throws Julia exceptions instead)."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[glrm status {code}] {message}")
+        self.code = code
+        self.message = message
+
+
+class CLoss(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("scale", C.c_double), ("p0", C.c_double), ("p1", C.c_double)]
+
+
+class CReg(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("scale", C.c_double)]
+
+
+LOSS_DTYPE = np.dtype([("kind", "<i4"), ("reserved", "<i4"), ("scale", "<f8"), ("p0", "<f8"), ("p1", "<f8")])
+REG_DTYPE = np.dtype([("kind", "<i4"), ("reserved", "<i4"), ("scale", "<f8")])
+assert LOSS_DTYPE.itemsize == C.sizeof(CLoss) == 32 and REG_DTYPE.itemsize == C.sizeof(CReg) == 16
+
+
+class CProblem(C.Structure):
+    _fields_ = [
+        ("m", C.c_int64), ("n", C.c_int64), ("k", C.c_int32), ("flags", C.c_int32),
+        ("row_begin", C.c_int64), ("row_end", C.c_int64), ("col_begin", C.c_int64), ("col_end", C.c_int64),
+        ("rowptr", C.c_void_p), ("colidx", C.c_void_p), ("rowvals", C.c_void_p),
+        ("colptr", C.c_void_p), ("rowidx", C.c_void_p), ("colvals", C.c_void_p),
+        ("losses", C.c_void_p), ("n_losses", C.c_int64),
+        ("rx", C.c_void_p), ("n_rx", C.c_int64),
+        ("ry", C.c_void_p), ("n_ry", C.c_int64),
+    ]
+
+
+class CParams(C.Structure):
+    _fields_ = [
+        ("stepsize", C.c_double), ("max_iter", C.c_int64), ("inner_iter_X", C.c_int64), ("inner_iter_Y", C.c_int64),
+        ("abs_tol", C.c_double), ("rel_tol", C.c_double), ("min_stepsize", C.c_double),
+    ]
+
+
+class COptions(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("profile", C.c_int32), ("waves_row", C.c_int32), ("waves_col", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+class CKernelStats(C.Structure):
+    _fields_ = [
+        ("launches_x", C.c_int64), ("launches_y", C.c_int64), ("ms_x", C.c_double), ("ms_y", C.c_double),
+        ("trials_x", C.c_int64), ("trials_y", C.c_int64), ("accepts_x", C.c_int64), ("accepts_y", C.c_int64),
+        ("nnz_rows", C.c_int64), ("nnz_cols", C.c_int64),
+        ("waves_row", C.c_int32), ("waves_col", C.c_int32), ("ld", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+    def asdict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved"}
+
+
+#: every symbol include/glrm_hip.h declares (suffix after the prefix); the CPU test-suite checks
+#: that the built library exports all of them.
+ABI_SYMBOLS = (
+    "version", "last_error", "create", "destroy", "fit", "objective", "factor_ld", "bind_buffers",
+    "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "col_losses", "row_penalties",
+    "col_penalties", "sum", "synchronize", "kernel_stats",
+)
+
+
+def _ptr(a):
+    """numpy array -> address; int -> address; None -> NULL."""
+    if a is None:
+        return None
+    if isinstance(a, (int, np.integer)):
+        return int(a)
+    return a.ctypes.data
+
+
+class Api:
+    """One loaded library + symbol prefix.  Thin, stateless, no numerics."""
+
+    def __init__(self, lib: C.CDLL, prefix: str, device_type: str):
+        self.lib, self.prefix, self.device_type = lib, prefix, device_type
+        H = C.c_void_p
+        sig = {
+            "version": (C.c_int, []),
+            "last_error": (C.c_char_p, []),
+            "create": (C.c_int, [C.POINTER(H), C.POINTER(CProblem), C.POINTER(COptions)]),
+            "destroy": (None, [H]),
+            "fit": (C.c_int, [H, C.POINTER(CParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                              C.POINTER(C.c_int64)]),
+            "objective": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
+            "factor_ld": (C.c_int, [H]),
+            "bind_buffers": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+            "set_factors": (C.c_int, [H, C.c_void_p, C.c_void_p]),
+            "get_factors": (C.c_int, [H, C.c_void_p, C.c_void_p]),
+            "reset_stepsizes": (C.c_int, [H, C.c_double]),
+            "step_x": (C.c_int, [H, C.c_double]),
+            "step_y": (C.c_int, [H, C.c_double]),
+            "col_losses": (C.c_int, [H]),
+            "row_penalties": (C.c_int, [H]),
+            "col_penalties": (C.c_int, [H]),
+            "sum": (C.c_int, [H, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
+            "synchronize": (C.c_int, [H]),
+            "kernel_stats": (C.c_int, [H, C.POINTER(CKernelStats), C.c_int]),
+        }
+        self._f = {}
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, prefix + name)
+            fn.restype, fn.argtypes = res, args
+            self._f[name] = fn
+        v = self._f["version"]()
+        if v != ABI_VERSION:
+            raise RuntimeError(f"{prefix}version() = {v}, this host layer speaks ABI {ABI_VERSION}")
+
+    # -- error plumbing ---------------------------------------------------------------
+    def last_error(self) -> str:
+        m = self._f["last_error"]()
+        return m.decode("utf-8", "replace") if m else ""
+
+    def _ck(self, rc: int):
+        if rc != GLRM_OK:
+            raise GLRMError(rc, self.last_error())
+
+    # -- lifecycle --------------------------------------------------------------------
+    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=0):
+        p = CProblem()
+        p.m, p.n, p.k, p.flags = prob.m, prob.n, prob.k, prob.flags
+        p.row_begin, p.row_end, p.col_begin, p.col_end = prob.row_begin, prob.row_end, prob.col_begin, prob.col_end
+        p.rowptr, p.colidx, p.rowvals = _ptr(prob.rowptr), _ptr(prob.colidx), _ptr(prob.rowvals)
+        p.colptr, p.rowidx, p.colvals = _ptr(prob.colptr), _ptr(prob.rowidx), _ptr(prob.colvals)
+        p.losses, p.n_losses = _ptr(prob.losses), len(prob.losses)
+        p.rx, p.n_rx = _ptr(prob.rx), len(prob.rx)
+        p.ry, p.n_ry = _ptr(prob.ry), len(prob.ry)
+        o = COptions(device_id, profile, waves_row, waves_col, stream or None)
+        h = C.c_void_p()
+        self._ck(self._f["create"](C.byref(h), C.byref(p), C.byref(o)))
+        return h
+
+    def destroy(self, h):
+        if h is not None and h.value:
+            self._f["destroy"](h)
+            h.value = None
+
+    # -- whole-fit --------------------------------------------------------------------
+    def fit(self, h, params, X, Y):
+        cap = int(params.max_iter) + 1
+        obj = np.zeros(cap)
+        sec = np.zeros(cap)
+        nrec = C.c_int64(0)
+        cp = CParams(params.stepsize, params.max_iter, params.inner_iter_X, params.inner_iter_Y, params.abs_tol,
+                     params.rel_tol, params.min_stepsize)
+        self._ck(self._f["fit"](h, C.byref(cp), _ptr(X), _ptr(Y), _ptr(obj), _ptr(sec), cap, C.byref(nrec)))
+        return obj[: nrec.value].copy(), sec[: nrec.value].copy()
+
+    def objective(self, h, X, Y, include_reg=True) -> float:
+        out = C.c_double(0.0)
+        self._ck(self._f["objective"](h, _ptr(X), _ptr(Y), 1 if include_reg else 0, C.byref(out)))
+        return out.value
+
+    # -- step-level -------------------------------------------------------------------
+    def factor_ld(self, h) -> int:
+        ld = self._f["factor_ld"](h)
+        if ld <= 0:
+            raise GLRMError(ld, self.last_error())
+        return ld
+
+    def bind_buffers(self, h, dX, dY, dObjCol, dObjRow):
+        self._ck(self._f["bind_buffers"](h, _ptr(dX), _ptr(dY), _ptr(dObjCol), _ptr(dObjRow)))
+
+    def set_factors(self, h, X, Y):
+        self._ck(self._f["set_factors"](h, _ptr(X), _ptr(Y)))
+
+    def get_factors(self, h, X, Y):
+        self._ck(self._f["get_factors"](h, _ptr(X), _ptr(Y)))
+
+    def reset_stepsizes(self, h, stepsize):
+        self._ck(self._f["reset_stepsizes"](h, float(stepsize)))
+
+    def step_x(self, h, min_stepsize):
+        self._ck(self._f["step_x"](h, float(min_stepsize)))
+
+    def step_y(self, h, min_stepsize):
+        self._ck(self._f["step_y"](h, float(min_stepsize)))
+
+    def col_losses(self, h):
+        self._ck(self._f["col_losses"](h))
+
+    def row_penalties(self, h):
+        self._ck(self._f["row_penalties"](h))
+
+    def col_penalties(self, h):
+        self._ck(self._f["col_penalties"](h))
+
+    def sum(self, h, vec, n) -> float:
+        out = C.c_double(0.0)
+        self._ck(self._f["sum"](h, _ptr(vec), int(n), C.byref(out)))
+        return out.value
+
+    def synchronize(self, h):
+        self._ck(self._f["synchronize"](h))
+
+    def kernel_stats(self, h, reset=False) -> dict:
+        st = CKernelStats()
+        self._ck(self._f["kernel_stats"](h, C.byref(st), 1 if reset else 0))
+        return st.asdict()
+
+
+class ProblemArrays:
+    """Plain container for one shard in the ABI's layout (0-based, CSR + CSC, descriptors)."""
+
+    def __init__(self, m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, losses, rx, ry,
+                 row_begin=0, row_end=None, col_begin=0, col_end=None, flags=0):
+        self.m, self.n, self.k, self.flags = int(m), int(n), int(k), int(flags)
+        self.row_begin, self.row_end = int(row_begin), int(m if row_end is None else row_end)
+        self.col_begin, self.col_end = int(col_begin), int(n if col_end is None else col_end)
+        self.rowptr, self.colidx, self.rowvals = rowptr, colidx, rowvals
+        self.colptr, self.rowidx, self.colvals = colptr, rowidx, colvals
+        self.losses, self.rx, self.ry = losses, rx, ry  # numpy structured arrays (LOSS_DTYPE / REG_DTYPE)
+
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_PKG_DIR, "libglrm_hip.so")
+_hip_api = None
+
+
+def hip_api() -> Api:
+    """The MI355X engine.  Fails loudly when the HIP library has not been built -- there is no
+    CPU fallback in the product path."""
+    global _hip_api
+    if _hip_api is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise RuntimeError(
+                f"{HIP_LIB_PATH} is missing: build it with `python __graft_entry__.py` (hipcc, gfx950). "
+                "lowrankmodels.jl_amd has no CPU fallback."
+            )
+        _hip_api = Api(C.CDLL(HIP_LIB_PATH, mode=C.RTLD_GLOBAL), "glrm_hip_", "cuda")
+    return _hip_api

@@ -1,0 +1,240 @@
+"""fit! / fit (reference: src/fit.jl:8-31, src/algorithms/proxgrad.jl:34-220) on the MI355X engine.
+
+Single GPU: one ``glrm_hip_fit`` call -- the whole alternating loop runs in the C library.
+Several GPUs: one process per GPU (``torch.distributed``, backend nccl = RCCL over xGMI); this
+module runs the outer loop of Appendix A, calls the step-level C entry points on the rank's
+row/column shard and all-gathers the factor the half-step just updated.
+There is no CPU fallback: without libglrm_hip.so the call raises.
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+
+from . import _capi
+from .convergence import ConvergenceHistory, update_ch
+from .params import AbstractParams, HipProxGradParams, ProxGradParams
+
+
+def _engine_opts(params):
+    g = lambda k, d: getattr(params, k, d)
+    return dict(device_id=g("device_id", -1), profile=1 if g("profile", False) else 0,
+                waves_row=g("waves_row", 0), waves_col=g("waves_col", 0))
+
+
+def _should_stop(i, prev, obj, scaled_abs_tol, rel_tol):
+    """src/algorithms/proxgrad.jl:210-213 (a negative decrease also stops; obj == 0 divides like Julia)."""
+    dec = prev - obj
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rel = np.float64(dec) / np.float64(obj)
+    return i > 10 and (dec < scaled_abs_tol or rel < rel_tol)
+
+
+def partition(ptr, parts):
+    """Contiguous blocks of segments for ``parts`` shards, balanced by nnz;
+    equal-count blocks are preferred when they are within 2 % of the nnz balance (enables the
+    in-place all-gather)."""
+    nseg, nnz = len(ptr) - 1, int(ptr[-1])
+    eq = [nseg * i // parts for i in range(parts + 1)]
+    if nseg % parts == 0 and nnz > 0:
+        worst = max(int(ptr[eq[i + 1]] - ptr[eq[i]]) for i in range(parts))
+        if worst <= 1.02 * nnz / parts + 1:
+            return eq
+    if nnz == 0:
+        return eq
+    b = [int(np.searchsorted(ptr, nnz * i / parts, side="left")) for i in range(parts + 1)]
+    b[0], b[-1] = 0, nseg
+    for i in range(1, parts + 1):
+        b[i] = max(b[i], b[i - 1])
+    return b
+
+
+def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, **kwargs):
+    """``fit!(glrm, params; ch, verbose)`` -> ``(glrm.X, glrm.Y, ch)``; glrm.X / glrm.Y are updated in
+    place (warm start: a second call continues, README.md:337-346).  ``params`` may also be passed
+    as the keyword the reference's dispatcher looks for (src/fit.jl:8-12).
+
+    ``engine`` is a test hook (an ``_capi.Api``); the product default is the HIP library.
+    """
+    if params is None:
+        params = HipProxGradParams()
+    if not isinstance(params, AbstractParams):
+        raise TypeError("params must be an AbstractParams (ProxGradParams / HipProxGradParams)")
+    if ch is None:
+        ch = ConvergenceHistory("ProxGradGLRM")
+    api = engine if engine is not None else _capi.hip_api()
+    world = 1
+    if group is not None or os.environ.get("WORLD_SIZE", "1") != "1":
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            world = dist.get_world_size(group)
+    if world > 1:
+        return _fit_distributed(glrm, params, ch, verbose, api, group)
+
+    if np.linalg.norm(glrm.Y) == 0:
+        raise ValueError("Y is all zeros (the reference cannot start from Y == 0, src/algorithms/proxgrad.jl:45-48)")
+    key = (id(api), _engine_opts(params)["device_id"], glrm._descriptor_key())
+    if glrm._handle_cache is not None and glrm._handle_cache[2] != key:
+        glrm.close()
+    if glrm._handle_cache is None:
+        h = api.create(glrm.problem_arrays(), **_engine_opts(params))
+        glrm._handle_cache = (api, h, key)
+    h = glrm._handle_cache[1]
+    if verbose:
+        print("Fitting GLRM")
+    X = np.asfortranarray(glrm.X, dtype=np.float64)
+    Y = np.asfortranarray(glrm.Y, dtype=np.float64)
+    obj, sec = api.fit(h, params, X, Y)
+    if X is not glrm.X:
+        glrm.X[...] = X
+    if Y is not glrm.Y:
+        glrm.Y[...] = Y
+    scaled_abs_tol = params.abs_tol * float(glrm._rowptr[-1])
+    for i in range(len(obj)):
+        update_ch(ch, sec[i] - (sec[i - 1] if i else 0.0), float(obj[i]))
+        if verbose and i >= 1 and i % 10 == 0 and not _should_stop(i, obj[i - 1], obj[i], scaled_abs_tol, params.rel_tol):
+            print(f"Iteration {i}: objective value = {obj[i]}")
+    return glrm.X, glrm.Y, ch
+
+
+def fit(glrm, *args, **kwargs):
+    """Non-mutating ``fit`` (src/fit.jl:24-31): returns (X', Y, ch) and restores glrm.X / glrm.Y."""
+    X0, Y0 = glrm.X.copy(order="F"), glrm.Y.copy(order="F")
+    X, Y, ch = fit_b(glrm, *args, **kwargs)
+    Xo, Yo = X.copy(order="F"), Y.copy(order="F")
+    glrm.X[...] = X0
+    glrm.Y[...] = Y0
+    return Xo.T, Yo, ch
+
+
+def objective(glrm, X=None, Y=None, *, include_regularization=True, engine=None, **_):
+    """objective(glrm, X, Y; include_regularization) over observed_examples (src/evaluate_fit.jl:57-83)."""
+    api = engine if engine is not None else _capi.hip_api()
+    X = np.asfortranarray(glrm.X if X is None else X, dtype=np.float64)
+    Y = np.asfortranarray(glrm.Y if Y is None else Y, dtype=np.float64)
+    h = api.create(glrm.problem_arrays())
+    try:
+        return api.objective(h, X, Y, include_regularization)
+    finally:
+        api.destroy(h)
+
+
+# ----------------------------------------------------------------------------- multi-GPU host
+
+class ShardedFit:
+    """The outer loop of src/algorithms/proxgrad.jl:107-217 for one rank of a row/column-sharded fit.
+
+    The rank owns rows [rb,re) (X half-step) and columns [cb,ce) (Y half-step); X and Y are
+    replicated.  After the X half-step every rank all-gathers the X blocks, after the Y half-step
+    the Y blocks and the per-column objectives; the recorded objective is a fixed-order sum of the
+    gathered per-column values, so it does not depend on the number of ranks.
+    """
+
+    def __init__(self, api, prob, row_bounds, col_bounds, group=None, device=None, stream=0, opts=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.api, self.group = torch, dist, api, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.row_bounds, self.col_bounds = list(row_bounds), list(col_bounds)
+        self.m, self.n, self.k = prob.m, prob.n, prob.k
+        self.device = device if device is not None else torch.device("cpu")
+        o = dict(opts or {})
+        if self.device.type == "cuda":
+            o["device_id"] = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.h = api.create(prob, stream=stream, **o)
+        self.ld = api.factor_ld(self.h)
+        z = lambda cnt: torch.zeros(cnt, dtype=torch.float64, device=self.device)
+        self.dX, self.dY, self.dObjCol, self.dObjRow = z(self.m * self.ld), z(self.n * self.ld), z(self.n), z(self.m)
+        api.bind_buffers(self.h, self.dX.data_ptr(), self.dY.data_ptr(), self.dObjCol.data_ptr(), self.dObjRow.data_ptr())
+        mode = os.environ.get("GLRM_GATHER", "auto")
+        self._inplace_ok = mode != "broadcast" and (mode == "allgather" or dist.get_backend(group) == "nccl")
+
+    def close(self):
+        if self.h is not None:
+            self.api.destroy(self.h)
+            self.h = None
+
+    def _gather(self, buf, bounds, unit):
+        """Make ``buf`` (global length) identical on every rank: rank r contributed
+        buf[bounds[r]*unit : bounds[r+1]*unit].  Equal blocks -> one in-place all-gather (each GPU
+        pushes its 1/G slice to its peers); ragged blocks -> one broadcast per owner."""
+        dist, sizes = self.dist, [(bounds[r + 1] - bounds[r]) * unit for r in range(self.world)]
+        if self._inplace_ok and len(set(sizes)) == 1 and sizes[0] > 0:
+            own = buf[bounds[self.rank] * unit: bounds[self.rank + 1] * unit]
+            dist.all_gather_into_tensor(buf, own, group=self.group)
+            return
+        for r in range(self.world):
+            if sizes[r]:
+                src = dist.get_global_rank(self.group, r) if self.group is not None else r
+                dist.broadcast(buf[bounds[r] * unit: bounds[r + 1] * unit], src=src, group=self.group)
+
+    def initial_objective(self):
+        api, h = self.api, self.h
+        api.col_losses(h)
+        self._gather(self.dObjCol, self.col_bounds, 1)
+        loss = api.sum(h, self.dObjCol.data_ptr(), self.n)
+        api.row_penalties(h)
+        self._gather(self.dObjRow, self.row_bounds, 1)
+        px = api.sum(h, self.dObjRow.data_ptr(), self.m)
+        api.col_penalties(h)
+        self._gather(self.dObjCol, self.col_bounds, 1)
+        py = api.sum(h, self.dObjCol.data_ptr(), self.n)
+        return loss + (px + py)  # err += calc_penalty(...), src/evaluate_fit.jl:19-21
+
+    def iteration(self, params):
+        """One outer iteration (src/algorithms/proxgrad.jl:107-205); returns sum(obj_by_col)."""
+        api, h = self.api, self.h
+        if params.inner_iter_X > 1 or params.inner_iter_Y > 1:
+            api.reset_stepsizes(h, params.stepsize)
+        for _ in range(params.inner_iter_X):
+            api.step_x(h, params.min_stepsize)
+        self._gather(self.dX, self.row_bounds, self.ld)  # inner X sweeps only touch own rows: gather once
+        for _ in range(params.inner_iter_Y):
+            api.step_y(h, params.min_stepsize)
+        self._gather(self.dY, self.col_bounds, self.ld)
+        self._gather(self.dObjCol, self.col_bounds, 1)
+        return api.sum(h, self.dObjCol.data_ptr(), self.n)
+
+
+def _fit_distributed(glrm, params, ch, verbose, api, group):
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    rbs, cbs = partition(glrm._rowptr, world), partition(glrm._colptr, world)
+    prob = glrm.problem_arrays(rows=(rbs[rank], rbs[rank + 1]), cols=(cbs[rank], cbs[rank + 1]))
+    if api.device_type == "cuda":
+        device = torch.device("cuda", torch.cuda.current_device())
+        stream = torch.cuda.current_stream().cuda_stream
+    else:
+        device, stream = torch.device("cpu"), 0
+    opts = _engine_opts(params)
+    sf = ShardedFit(api, prob, rbs, cbs, group=group, device=device, stream=stream, opts=opts)
+    try:
+        if np.linalg.norm(glrm.Y) == 0:
+            raise ValueError("Y is all zeros (the reference cannot start from Y == 0)")
+        X = np.asfortranarray(glrm.X, dtype=np.float64)
+        Y = np.asfortranarray(glrm.Y, dtype=np.float64)
+        api.set_factors(sf.h, X, Y)
+        api.reset_stepsizes(sf.h, params.stepsize)
+        scaled_abs_tol = params.abs_tol * float(glrm._rowptr[-1])
+        if verbose and rank == 0:
+            print("Fitting GLRM")
+        update_ch(ch, 0, sf.initial_objective())
+        t = time.time()
+        for i in range(1, params.max_iter + 1):
+            obj = sf.iteration(params)
+            t = time.time() - t
+            update_ch(ch, t, obj)
+            t = time.time()
+            if _should_stop(i, ch.objective[-2], obj, scaled_abs_tol, params.rel_tol):
+                break
+            if verbose and rank == 0 and i % 10 == 0:
+                print(f"Iteration {i}: objective value = {ch.objective[-1]}")
+        api.get_factors(sf.h, X, Y)
+        glrm.X[...] = X
+        glrm.Y[...] = Y
+    finally:
+        sf.close()
+    return glrm.X, glrm.Y, ch

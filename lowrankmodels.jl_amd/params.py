@@ -1,0 +1,40 @@
+"""Solver parameters (reference: src/algorithms/proxgrad.jl:4-31, src/fit.jl:4-5)."""
+
+
+class AbstractParams:
+    pass
+
+
+class ProxGradParams(AbstractParams):
+    """ProxGradParams(stepsize=1.0; max_iter=100, inner_iter_X=1, inner_iter_Y=1, inner_iter=1,
+    abs_tol=1e-5, rel_tol=1e-4, min_stepsize=0.01*stepsize) -- same defaults and the same
+    max-merge of ``inner_iter`` into both inner counts (src/algorithms/proxgrad.jl:13-31)."""
+
+    def __init__(self, stepsize=1.0, *, max_iter=100, inner_iter_X=1, inner_iter_Y=1, inner_iter=1,
+                 abs_tol=0.00001, rel_tol=0.0001, min_stepsize=None):
+        self.stepsize = float(stepsize)
+        self.max_iter = int(max_iter)
+        self.inner_iter_X = max(int(inner_iter_X), int(inner_iter))
+        self.inner_iter_Y = max(int(inner_iter_Y), int(inner_iter))
+        self.abs_tol = float(abs_tol)
+        self.rel_tol = float(rel_tol)
+        self.min_stepsize = float(0.01 * self.stepsize if min_stepsize is None else min_stepsize)
+
+    def __repr__(self):
+        f = ("stepsize", "max_iter", "inner_iter_X", "inner_iter_Y", "abs_tol", "rel_tol", "min_stepsize")
+        return f"{type(self).__name__}(" + ", ".join(f"{k}={getattr(self, k)}" for k in f) + ")"
+
+
+class HipProxGradParams(ProxGradParams):
+    """The drop-in params type: the ProxGradParams fields plus engine knobs.  In Julia this is
+    ``struct HipProxGradParams <: AbstractParams`` (julia/HipGLRM.jl); `fit!(glrm, params=p)`
+    dispatches on it exactly like on the built-in solvers (src/fit.jl:8-12)."""
+
+    def __init__(self, stepsize=1.0, *, device_id=-1, profile=False, waves_row=0, waves_col=0, **kw):
+        super().__init__(stepsize, **kw)
+        self.device_id, self.profile = int(device_id), bool(profile)
+        self.waves_row, self.waves_col = int(waves_row), int(waves_col)
+
+
+def Params(*args, **kwargs):  # src/fit.jl:5
+    return ProxGradParams(*args, **kwargs)

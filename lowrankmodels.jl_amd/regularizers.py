@@ -1,0 +1,132 @@
+"""Regularizers named by the north star (reference: src/regularizers.jl), host descriptors.
+
+``evaluate``/``prox`` restate the reference's array methods for API parity; inside the fit the
+prox step runs fused in the HIP sweep kernels.
+"""
+from __future__ import annotations
+
+import copy as _copy
+
+import numpy as np
+
+from ._capi import REG_DTYPE
+
+ZERO, QUAD, ONE, NONNEG, UNIT_ONE_SPARSE = range(5)
+
+
+class Regularizer:
+    kind = -1
+
+    def __init__(self, scale=1.0):
+        self.scale = float(scale)
+
+    def mul_(self, newscale):  # mul!(r, newscale), src/regularizers.jl:38
+        self.scale = float(newscale)
+        return self
+
+    def __rmul__(self, newscale):  # *(newscale, r): scale(r)*newscale on a fresh copy, :40
+        r = _copy.copy(self)
+        r.mul_(self.scale * newscale)
+        return r
+
+    def descriptor(self):
+        return (self.kind, 0, self.scale)
+
+    def __repr__(self):
+        return f"{type(self).__name__}({self.scale})"
+
+
+class QuadReg(Regularizer):  # :52-58
+    kind = QUAD
+
+    def __init__(self, scale=1):
+        super().__init__(scale)
+
+    def evaluate(self, a):
+        return self.scale * float(np.sum(np.abs(np.asarray(a, dtype=float)) ** 2))
+
+    def prox(self, u, alpha):
+        return 1 / (1 + 2 * alpha * self.scale) * np.asarray(u, dtype=float)
+
+
+class OneReg(Regularizer):  # :79-88
+    kind = ONE
+
+    def __init__(self, scale=1):
+        super().__init__(scale)
+
+    def evaluate(self, a):
+        return self.scale * float(np.sum(np.abs(a)))
+
+    def prox(self, u, alpha):
+        u = np.asarray(u, dtype=float)
+        t = self.scale * alpha
+        return np.maximum(u - t, 0) + np.minimum(u + t, 0)
+
+
+class _Unscaled(Regularizer):
+    def __init__(self):
+        super().__init__(1.0)
+
+    def mul_(self, newscale):  # mul!(r::ZeroReg/NonNeg/UnitOneSparse, _) is a no-op (:97,:114,:318)
+        return self
+
+    def descriptor(self):
+        return (self.kind, 0, 1.0)
+
+    def __repr__(self):
+        return f"{type(self).__name__}()"
+
+
+class ZeroReg(_Unscaled):  # :91-97
+    kind = ZERO
+
+    def evaluate(self, a):
+        return 0
+
+    def prox(self, u, alpha):
+        return np.asarray(u, dtype=float)
+
+
+class NonNegConstraint(_Unscaled):  # :101-114
+    kind = NONNEG
+
+    def evaluate(self, a):
+        return float("inf") if np.any(np.asarray(a) < 0) else 0
+
+    def prox(self, u, alpha=1):
+        return np.maximum(np.asarray(u, dtype=float), 0)
+
+
+class UnitOneSparseConstraint(_Unscaled):  # :295-318
+    kind = UNIT_ONE_SPARSE
+
+    def evaluate(self, a):
+        oneflag = False
+        for ai in np.asarray(a).ravel():
+            if ai == 0:
+                continue
+            if ai == 1:
+                if oneflag:
+                    return float("inf")
+                oneflag = True
+            else:
+                return float("inf")
+        return 0
+
+    def prox(self, u, alpha=0):
+        u = np.asarray(u, dtype=float)
+        v = np.zeros_like(u)
+        v[int(np.argmax(u))] = 1
+        return v
+
+
+def prox(r, u, alpha):
+    return r.prox(u, alpha)
+
+
+def pack_regs(regs):
+    descs = [r.descriptor() for r in regs]
+    if len(set(descs)) == 1:
+        descs = descs[:1]
+    return np.array(descs, dtype=REG_DTYPE)

@@ -1,0 +1,826 @@
+/*
+ * glrm_oracle.c -- CPU restatement of LowRankModels.jl's proximal-gradient fit!.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle and the CPU baseline
+ * of the MI355X engine in lowrankmodels.jl_amd/csrc.  Nothing in the product path may
+ * import, link, call or fall back to it; only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg use it (as the checker / the timed CPU baseline).
+ *
+ * PARITY STATUS: "operator-pinned, trajectory unpinned".  The reference is pure Julia;
+ * no `julia` binary exists in the build container or on the GPU box, so the reference
+ * itself can be neither run nor compiled here.  The oracle is pinned against every
+ * closed-form known answer the reference's tests/notebook hold for this path
+ * (tests/test_oracle_kat.py), but the reference has no golden *trajectory* that is
+ * reproducible without Julia's RNG.
+ *
+ * Every function cites the reference file:line (relative to the LowRankModels.jl
+ * tree) it follows.  Arithmetic is Float64 throughout, indices 0-based here
+ * (the reference is 1-based).
+ *
+ * Summation orders follow the reference:
+ *   - gradient: axpy in list order                     src/algorithms/proxgrad.jl:127,170
+ *   - row objective: sequential += from 0.0            src/evaluate_fit.jl:28-32
+ *   - column objective: Julia pairwise reduce(+) (block 1024) for DiffLoss /
+ *     ClassificationLoss, sequential for the others    src/losses.jl:623-638
+ *   - recorded objective: sum(obj_by_col), pairwise    src/algorithms/proxgrad.jl:205
+ * Dot products and axpys use fma() (what an FMA-capable BLAS does); the order inside
+ * a BLAS dot is implementation-defined anyway.
+ */
+#define _GNU_SOURCE
+#include "../include/glrm_hip.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORACLE_MAX_K 1024
+
+static __thread char g_err[512];
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+const char* glrm_cpu_last_error(void) { return g_err; }
+int glrm_cpu_version(void) { return GLRM_HIP_ABI_VERSION; }
+
+static int g_threads = 1;
+/* Threads used for the row loop, then the column loop
+ * (Threads.@threads, src/algorithms/proxgrad_multithread.jl:118,163). */
+void glrm_cpu_set_threads(int t) { g_threads = t < 1 ? 1 : t; }
+int glrm_cpu_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+static double now_s(void) {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+/* ------------------------------------------------------------------ losses */
+
+/* evaluate(l, u, a) for the scalar losses, src/losses.jl (Appendix B of SURVEY.md). */
+double glrm_cpu_loss_evaluate(const glrm_loss* l, double u, double a) {
+  const double s = l->scale;
+  switch (l->kind) {
+    case GLRM_LOSS_QUAD: { /* src/losses.jl:144  l.scale*(u-a)^2 */
+      double d = u - a;
+      return s * (d * d);
+    }
+    case GLRM_LOSS_L1: /* :158  l.scale*abs(u-a) */
+      return s * fabs(u - a);
+    case GLRM_LOSS_HUBER: { /* :173-175 */
+      double c = l->p0, d = fabs(u - a);
+      return d > c ? (d - c + c * c) * s : ((u - a) * (u - a)) * s;
+    }
+    case GLRM_LOSS_QUANTILE: { /* :193-196 */
+      double q = l->p0, diff = a - u;
+      return diff > 0 ? s * q * diff : -s * (1 - q) * diff;
+    }
+    case GLRM_LOSS_PERIODIC: { /* :216  l.scale*(1-cos((a-u)*(2*pi)/l.T)) */
+      double T = l->p0;
+      return s * (1 - cos((a - u) * (2 * M_PI) / T));
+    }
+    case GLRM_LOSS_POISSON: /* :237-239 */
+      return s * (exp(u) - a * u + (a == 0 ? 0 : a * (log(a) - 1)));
+    case GLRM_LOSS_ORDINAL_HINGE: { /* :258-278, four branches transcribed literally */
+      double mn = l->p0, mx = l->p1, n, loss;
+      if (u > mx - 1) {
+        n = fmin(floor(u), mx - 1) - a;
+        loss = n * (n + 1) / 2 + (n + 1) * (u - mx + 1);
+      } else if (u > a) {
+        n = fmin(floor(u), mx) - a;
+        loss = n * (n + 1) / 2 + (n + 1) * (u - floor(u));
+      } else if (u > mn + 1) {
+        n = a - fmax(ceil(u), mn + 1);
+        loss = n * (n + 1) / 2 + (n + 1) * (ceil(u) - u);
+      } else {
+        n = a - fmax(ceil(u), mn + 1);
+        loss = n * (n + 1) / 2 + (n + 1) * (mn + 1 - u);
+      }
+      return s * loss;
+    }
+    case GLRM_LOSS_LOGISTIC: { /* :304  l.scale*log(1+exp(-(2a-1)*u)), a::Bool stored 1.0/0.0 */
+      double aa = 2 * a - 1;
+      return s * log(1 + exp(-aa * u));
+    }
+    case GLRM_LOSS_WEIGHTED_HINGE: { /* :326-332 */
+      double r = l->p0, aa = 2 * a - 1;
+      double loss = s * fmax(1 - aa * u, 0);
+      if (r != 1.0 && a == 1.0) loss *= r;
+      return loss;
+    }
+    default:
+      return NAN;
+  }
+}
+
+/* grad(l, u, a), src/losses.jl. */
+double glrm_cpu_loss_grad(const glrm_loss* l, double u, double a) {
+  const double s = l->scale;
+  switch (l->kind) {
+    case GLRM_LOSS_QUAD: /* :146  2*(u-a)*l.scale */
+      return 2 * (u - a) * s;
+    case GLRM_LOSS_L1: { /* :160  sign(u-a)*l.scale */
+      double d = u - a;
+      return (d > 0 ? 1.0 : (d < 0 ? -1.0 : d)) * s;
+    }
+    case GLRM_LOSS_HUBER: { /* :177  (note: (u-a)*scale, not 2(u-a)*scale) */
+      double c = l->p0, d = u - a;
+      return fabs(d) > c ? (d > 0 ? 1.0 : (d < 0 ? -1.0 : d)) * s : d * s;
+    }
+    case GLRM_LOSS_QUANTILE: { /* :198-201 */
+      double q = l->p0, diff = a - u;
+      return diff > 0 ? -s * q : s * (1 - q);
+    }
+    case GLRM_LOSS_PERIODIC: { /* :218 */
+      double T = l->p0;
+      return -s * ((2 * M_PI) / T) * sin((a - u) * (2 * M_PI) / T);
+    }
+    case GLRM_LOSS_POISSON: /* :241 */
+      return s * (exp(u) - a);
+    case GLRM_LOSS_ORDINAL_HINGE: { /* :280-292 */
+      double mn = l->p0, mx = l->p1, g;
+      if (u > a) {
+        g = fmin(ceil(u), mx) - a;
+      } else {
+        g = -(a - fmax(floor(u), mn));
+      }
+      return s * g;
+    }
+    case GLRM_LOSS_LOGISTIC: { /* :306  aa=2a-1; -aa*l.scale/(1+exp(aa*u)) */
+      double aa = 2 * a - 1;
+      return -aa * s / (1 + exp(aa * u));
+    }
+    case GLRM_LOSS_WEIGHTED_HINGE: { /* :334-341 */
+      double r = l->p0, an = 2 * a - 1;
+      double g = (an * u >= 1 ? 0 : -an * s);
+      if (r != 1.0 && a == 1.0) g *= r;
+      return g;
+    }
+    default:
+      return NAN;
+  }
+}
+
+/* DiffLoss / ClassificationLoss = SingleDimLoss: vector evaluate is map! + reduce(+)
+ * (src/losses.jl:633-638); Poisson and OrdinalHinge are plain `Loss` and use the
+ * sequential loop (:623-630). */
+static int loss_is_single_dim(int kind) {
+  return !(kind == GLRM_LOSS_POISSON || kind == GLRM_LOSS_ORDINAL_HINGE);
+}
+
+static int loss_is_classification(int kind) {
+  return kind == GLRM_LOSS_LOGISTIC || kind == GLRM_LOSS_WEIGHTED_HINGE;
+}
+
+/* Julia's mapreduce_impl for reduce(+, v): sequential below 1024 elements, else split
+ * at ifirst + (ilast-ifirst)>>1 (Base reduce.jl; indices inclusive). */
+static double julia_pairwise(const double* v, int64_t ifirst, int64_t ilast) {
+  if (ifirst == ilast) return v[ifirst];
+  if (ilast - ifirst < 1024) {
+    double s = v[ifirst] + v[ifirst + 1];
+    for (int64_t i = ifirst + 2; i <= ilast; ++i) s += v[i];
+    return s;
+  }
+  int64_t imid = ifirst + ((ilast - ifirst) >> 1);
+  double v1 = julia_pairwise(v, ifirst, imid);
+  double v2 = julia_pairwise(v, imid + 1, ilast);
+  return v1 + v2;
+}
+
+static double julia_sum(const double* v, int64_t n) {
+  if (n <= 0) return 0.0;
+  return julia_pairwise(v, 0, n - 1);
+}
+
+/* -------------------------------------------------------------- regularizers */
+
+/* evaluate(r, a), src/regularizers.jl:58,88,95,103-112,300-316. */
+double glrm_cpu_reg_evaluate(const glrm_reg* r, const double* x, int k) {
+  switch (r->kind) {
+    case GLRM_REG_ZERO:
+      return 0.0;
+    case GLRM_REG_QUAD: { /* r.scale*sum(abs2, a) */
+      double s = 0.0;
+      for (int c = 0; c < k; ++c) s += x[c] * x[c];
+      return r->scale * s;
+    }
+    case GLRM_REG_ONE: { /* r.scale*sum(abs,a) */
+      double s = 0.0;
+      for (int c = 0; c < k; ++c) s += fabs(x[c]);
+      return r->scale * s;
+    }
+    case GLRM_REG_NONNEG:
+      for (int c = 0; c < k; ++c)
+        if (x[c] < 0) return INFINITY;
+      return 0.0;
+    case GLRM_REG_UNIT_ONE_SPARSE: {
+      int oneflag = 0;
+      for (int c = 0; c < k; ++c) {
+        if (x[c] == 0) continue;
+        if (x[c] == 1) {
+          if (oneflag) return INFINITY;
+          oneflag = 1;
+        } else {
+          return INFINITY;
+        }
+      }
+      return 0.0;
+    }
+    default:
+      return NAN;
+  }
+}
+
+/* prox(r, u, alpha) written back in place: inside fit! prox! always receives a SubArray,
+ * so the generic prox!(r,u,alpha) = copy(prox(r,u,alpha)) is what runs
+ * (src/regularizers.jl:34; formulas :56,:83-86,:93,:103,:297). */
+void glrm_cpu_reg_prox(const glrm_reg* r, double* u, int k, double alpha) {
+  switch (r->kind) {
+    case GLRM_REG_ZERO:
+      return;
+    case GLRM_REG_QUAD: { /* 1/(1+2*alpha*r.scale)*u */
+      double f = 1 / (1 + 2 * alpha * r->scale);
+      for (int c = 0; c < k; ++c) u[c] = f * u[c];
+      return;
+    }
+    case GLRM_REG_ONE: { /* softthreshold(x; alpha=r.scale*alpha) = max(x-t,0)+min(x+t,0) */
+      double t = r->scale * alpha;
+      for (int c = 0; c < k; ++c) u[c] = fmax(u[c] - t, 0) + fmin(u[c] + t, 0);
+      return;
+    }
+    case GLRM_REG_NONNEG:
+      for (int c = 0; c < k; ++c) u[c] = u[c] > 0 ? u[c] : 0.0; /* broadcast(max,u,0) */
+      return;
+    case GLRM_REG_UNIT_ONE_SPARSE: { /* idx = argmax(u) (first maximal index); e_idx */
+      int idx = 0;
+      for (int c = 1; c < k; ++c)
+        if (u[c] > u[idx]) idx = c;
+      for (int c = 0; c < k; ++c) u[c] = 0.0;
+      u[idx] = 1.0;
+      return;
+    }
+    default:
+      return;
+  }
+}
+
+/* ------------------------------------------------------------------ handle */
+
+typedef struct glrm_cpu_handle {
+  int64_t m, n;
+  int32_t k;
+  int64_t row_begin, row_end, col_begin, col_end;
+  int64_t *rowptr, *colptr;
+  int32_t *colidx, *rowidx;
+  double *rowvals, *colvals;
+  glrm_loss* losses;
+  int64_t n_losses;
+  glrm_reg *rx, *ry;
+  int64_t n_rx, n_ry;
+  /* factors and per-segment state; X,Y,objcol,objrow may be caller-bound */
+  double *X, *Y, *objcol, *objrow;
+  double *ownX, *ownY, *ownobjcol, *ownobjrow;
+  double *alpharow, *alphacol;
+  int dense_faithful; /* 1 = reproduce the reference's Theta(mnk) cost model */
+  double* XY;         /* m x n, only in dense_faithful mode */
+  glrm_kernel_stats st;
+} glrm_cpu_handle;
+
+static const glrm_loss* loss_of(const glrm_cpu_handle* h, int64_t f) {
+  return h->n_losses == 1 ? &h->losses[0] : &h->losses[f];
+}
+static const glrm_reg* rx_of(const glrm_cpu_handle* h, int64_t e_local) {
+  return h->n_rx == 1 ? &h->rx[0] : &h->rx[e_local];
+}
+static const glrm_reg* ry_of(const glrm_cpu_handle* h, int64_t f_local) {
+  return h->n_ry == 1 ? &h->ry[0] : &h->ry[f_local];
+}
+
+static void* dup_mem(const void* src, size_t bytes) {
+  void* p = malloc(bytes ? bytes : 1);
+  if (p && bytes) memcpy(p, src, bytes);
+  return p;
+}
+
+void glrm_cpu_destroy(glrm_cpu_handle* h) {
+  if (!h) return;
+  free(h->rowptr); free(h->colptr); free(h->colidx); free(h->rowidx);
+  free(h->rowvals); free(h->colvals); free(h->losses); free(h->rx); free(h->ry);
+  free(h->ownX); free(h->ownY); free(h->ownobjcol); free(h->ownobjrow);
+  free(h->alpharow); free(h->alphacol); free(h->XY);
+  free(h);
+}
+
+static int check_desc(const glrm_problem* p) {
+  if (!p->losses || !(p->n_losses == 1 || p->n_losses == p->n))
+    return fail(GLRM_ERR_INVALID, "There must be as many losses as there are columns in the data matrix (n_losses=%lld, n=%lld)",
+                (long long)p->n_losses, (long long)p->n);
+  int64_t ml = p->row_end - p->row_begin, nl = p->col_end - p->col_begin;
+  if (!p->rx || !(p->n_rx == 1 || p->n_rx == ml))
+    return fail(GLRM_ERR_INVALID, "There must be either one X regularizer or as many X regularizers as there are rows in the data matrix");
+  if (!p->ry || !(p->n_ry == 1 || p->n_ry == nl))
+    return fail(GLRM_ERR_INVALID, "There must be either one Y regularizer or as many Y regularizers as there are columns in the data matrix");
+  for (int64_t i = 0; i < p->n_losses; ++i) {
+    if (p->losses[i].kind < 0 || p->losses[i].kind >= GLRM_LOSS_KIND_COUNT)
+      return fail(GLRM_ERR_UNSUPPORTED, "loss kind %d (column %lld) is not a supported scalar loss", p->losses[i].kind, (long long)i);
+    if (p->losses[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_loss.reserved must be 0");
+  }
+  for (int64_t i = 0; i < p->n_rx; ++i) {
+    if (p->rx[i].kind < 0 || p->rx[i].kind >= GLRM_REG_KIND_COUNT)
+      return fail(GLRM_ERR_UNSUPPORTED, "rx regularizer kind %d is not supported", p->rx[i].kind);
+    if (p->rx[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_reg.reserved must be 0");
+  }
+  for (int64_t i = 0; i < p->n_ry; ++i) {
+    if (p->ry[i].kind < 0 || p->ry[i].kind >= GLRM_REG_KIND_COUNT)
+      return fail(GLRM_ERR_UNSUPPORTED, "ry regularizer kind %d is not supported", p->ry[i].kind);
+    if (p->ry[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_reg.reserved must be 0");
+  }
+  return GLRM_OK;
+}
+
+/* Validation shared in spirit with the GLRM constructor, src/glrm.jl:38-43,63-71, and the
+ * Bool coercion of ClassificationLoss labels, src/losses.jl:104-106. */
+static int check_view(const char* name, int64_t nseg, const int64_t* ptr, const int32_t* idx,
+                      const double* vals, int64_t idx_bound, const glrm_problem* p, int by_idx,
+                      int64_t seg_offset) {
+  if (!ptr) return fail(GLRM_ERR_INVALID, "%s pointer array is NULL", name);
+  if (ptr[0] != 0) return fail(GLRM_ERR_INVALID, "%s[0] must be 0", name);
+  for (int64_t s = 0; s < nseg; ++s)
+    if (ptr[s + 1] < ptr[s]) return fail(GLRM_ERR_INVALID, "%s is not monotone at %lld", name, (long long)s);
+  int64_t nnz = ptr[nseg];
+  if (nnz > 0 && (!idx || !vals)) return fail(GLRM_ERR_INVALID, "%s index/value arrays are NULL", name);
+  for (int64_t s = 0; s < nseg; ++s) {
+    for (int64_t t = ptr[s]; t < ptr[s + 1]; ++t) {
+      if (idx[t] < 0 || idx[t] >= idx_bound)
+        return fail(GLRM_ERR_INVALID, "%s: index %d out of range [0,%lld)", name, idx[t], (long long)idx_bound);
+      if (isnan(vals[t])) {
+        int64_t e = by_idx ? seg_offset + s : idx[t], f = by_idx ? idx[t] : seg_offset + s;
+        return fail(GLRM_ERR_NONFINITE, "Observed value in entry (%lld, %lld) is NaN.", (long long)e, (long long)f);
+      }
+      int64_t f = by_idx ? idx[t] : seg_offset + s;
+      const glrm_loss* l = p->n_losses == 1 ? &p->losses[0] : &p->losses[f];
+      if (loss_is_classification(l->kind) && !(vals[t] == 1.0 || vals[t] == 0.0))
+        return fail(GLRM_ERR_NONFINITE, "entry in column %lld has label %g; a ClassificationLoss needs true(1)/false(0)",
+                    (long long)f, vals[t]);
+    }
+  }
+  return GLRM_OK;
+}
+
+int glrm_cpu_create(glrm_cpu_handle** out, const glrm_problem* p, const glrm_options* o) {
+  (void)o;
+  if (!out || !p) return fail(GLRM_ERR_INVALID, "NULL argument");
+  *out = NULL;
+  if (p->flags & GLRM_PROBLEM_DEVICE_ARRAYS) return fail(GLRM_ERR_INVALID, "the CPU oracle takes host arrays only");
+  if (p->m <= 0 || p->n <= 0 || p->k <= 0) return fail(GLRM_ERR_INVALID, "m, n, k must be positive");
+  if (p->k > ORACLE_MAX_K) return fail(GLRM_ERR_UNSUPPORTED, "k > %d", ORACLE_MAX_K);
+  if (p->m > INT32_MAX || p->n > INT32_MAX) return fail(GLRM_ERR_UNSUPPORTED, "m, n must fit int32 indices");
+  if (p->row_begin < 0 || p->row_end > p->m || p->row_begin > p->row_end || p->col_begin < 0 ||
+      p->col_end > p->n || p->col_begin > p->col_end)
+    return fail(GLRM_ERR_INVALID, "shard ranges out of bounds");
+  int rc = check_desc(p);
+  if (rc) return rc;
+  int64_t ml = p->row_end - p->row_begin, nl = p->col_end - p->col_begin;
+  rc = check_view("rowptr", ml, p->rowptr, p->colidx, p->rowvals, p->n, p, 1, p->row_begin);
+  if (rc) return rc;
+  rc = check_view("colptr", nl, p->colptr, p->rowidx, p->colvals, p->m, p, 0, p->col_begin);
+  if (rc) return rc;
+
+  glrm_cpu_handle* h = (glrm_cpu_handle*)calloc(1, sizeof *h);
+  if (!h) return fail(GLRM_ERR_OOM, "out of memory");
+  h->m = p->m; h->n = p->n; h->k = p->k;
+  h->row_begin = p->row_begin; h->row_end = p->row_end;
+  h->col_begin = p->col_begin; h->col_end = p->col_end;
+  int64_t nzr = p->rowptr[ml], nzc = p->colptr[nl];
+  h->rowptr = (int64_t*)dup_mem(p->rowptr, (size_t)(ml + 1) * 8);
+  h->colptr = (int64_t*)dup_mem(p->colptr, (size_t)(nl + 1) * 8);
+  h->colidx = (int32_t*)dup_mem(p->colidx, (size_t)nzr * 4);
+  h->rowidx = (int32_t*)dup_mem(p->rowidx, (size_t)nzc * 4);
+  h->rowvals = (double*)dup_mem(p->rowvals, (size_t)nzr * 8);
+  h->colvals = (double*)dup_mem(p->colvals, (size_t)nzc * 8);
+  h->n_losses = p->n_losses; h->n_rx = p->n_rx; h->n_ry = p->n_ry;
+  h->losses = (glrm_loss*)dup_mem(p->losses, (size_t)p->n_losses * sizeof(glrm_loss));
+  h->rx = (glrm_reg*)dup_mem(p->rx, (size_t)p->n_rx * sizeof(glrm_reg));
+  h->ry = (glrm_reg*)dup_mem(p->ry, (size_t)p->n_ry * sizeof(glrm_reg));
+  h->alpharow = (double*)malloc((size_t)(ml ? ml : 1) * 8);
+  h->alphacol = (double*)malloc((size_t)(nl ? nl : 1) * 8);
+  h->ownX = (double*)calloc((size_t)p->k * p->m, 8);
+  h->ownY = (double*)calloc((size_t)p->k * p->n, 8);
+  h->ownobjcol = (double*)calloc((size_t)p->n, 8);
+  h->ownobjrow = (double*)calloc((size_t)p->m, 8);
+  if (!h->rowptr || !h->colptr || !h->colidx || !h->rowidx || !h->rowvals || !h->colvals || !h->losses ||
+      !h->rx || !h->ry || !h->alpharow || !h->alphacol || !h->ownX || !h->ownY || !h->ownobjcol || !h->ownobjrow) {
+    glrm_cpu_destroy(h);
+    return fail(GLRM_ERR_OOM, "out of memory");
+  }
+  h->X = h->ownX; h->Y = h->ownY; h->objcol = h->ownobjcol; h->objrow = h->ownobjrow;
+  for (int64_t e = 0; e < ml; ++e) h->alpharow[e] = 1.0;
+  for (int64_t f = 0; f < nl; ++f) h->alphacol[f] = 1.0;
+  h->st.nnz_rows = nzr; h->st.nnz_cols = nzc; h->st.ld = p->k; h->st.waves_row = h->st.waves_col = 0;
+  *out = h;
+  return GLRM_OK;
+}
+
+/* 1 = allocate XY = X'Y (m x n) and evaluate full rows / columns of it in every objective
+ * call, exactly the reference's cost model (src/algorithms/proxgrad.jl:65-66,157,202;
+ * src/evaluate_fit.jl:29,45).  The numbers produced are identical to the sparse mode. */
+int glrm_cpu_set_dense_faithful(glrm_cpu_handle* h, int on) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (on && !(h->row_begin == 0 && h->row_end == h->m && h->col_begin == 0 && h->col_end == h->n))
+    return fail(GLRM_ERR_INVALID, "dense-faithful mode needs a single-shard handle");
+  h->dense_faithful = on ? 1 : 0;
+  if (on && !h->XY) {
+    h->XY = (double*)malloc((size_t)h->m * h->n * 8);
+    if (!h->XY) return fail(GLRM_ERR_OOM, "cannot allocate dense XY (%lld x %lld)", (long long)h->m, (long long)h->n);
+  }
+  return GLRM_OK;
+}
+
+/* -------------------------------------------------------------- primitives */
+
+static inline double dotk(const double* x, const double* y, int k) {
+  double s = 0.0;
+  for (int c = 0; c < k; ++c) s = fma(x[c], y[c], s);
+  return s;
+}
+
+/* gemm!('T','N',1.0,X,Y,0.0,XY), src/algorithms/proxgrad.jl:66,157,202 (dense-faithful only). */
+static void recompute_XY(glrm_cpu_handle* h) {
+  if (!h->dense_faithful) return;
+  const int k = h->k;
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+  for (int64_t e = 0; e < h->m; ++e)
+    for (int64_t f = 0; f < h->n; ++f) h->XY[e * h->n + f] = dotk(h->X + e * k, h->Y + f * k, k);
+}
+
+/* row_objective(glrm, i, x), src/evaluate_fit.jl:24-38.  `scratch` (n doubles) is only
+ * used in dense-faithful mode, where the full x'*Y is formed like the reference does (:29). */
+static double row_objective(const glrm_cpu_handle* h, int64_t el, const double* x, double* scratch) {
+  const int k = h->k;
+  double err = 0.0;
+  const int64_t b = h->rowptr[el], e = h->rowptr[el + 1];
+  if (h->dense_faithful) {
+    for (int64_t f = 0; f < h->n; ++f) scratch[f] = dotk(x, h->Y + f * k, k);
+    for (int64_t t = b; t < e; ++t) {
+      int64_t f = h->colidx[t];
+      err += glrm_cpu_loss_evaluate(loss_of(h, f), scratch[f], h->rowvals[t]);
+    }
+  } else {
+    for (int64_t t = b; t < e; ++t) {
+      int64_t f = h->colidx[t];
+      double u = dotk(x, h->Y + f * k, k);
+      err += glrm_cpu_loss_evaluate(loss_of(h, f), u, h->rowvals[t]);
+    }
+  }
+  err += glrm_cpu_reg_evaluate(rx_of(h, el), x, k);
+  return err;
+}
+
+/* The loss part of col_objective(glrm, j, y), src/evaluate_fit.jl:39-51:
+ * evaluate(losses[j], XY[obsex], A[obsex,j]) with the vector methods of src/losses.jl:623-638.
+ * `mapped` needs room for the column's observations (plus m doubles in dense-faithful mode). */
+static double col_loss(const glrm_cpu_handle* h, int64_t fl, const double* y, double* mapped) {
+  const int k = h->k;
+  const int64_t b = h->colptr[fl], e = h->colptr[fl + 1], len = e - b;
+  const glrm_loss* l = loss_of(h, h->col_begin + fl);
+  if (h->dense_faithful) { /* XY = X'*y over ALL m rows first (:45) */
+    double* full = mapped + len;
+    for (int64_t i = 0; i < h->m; ++i) full[i] = dotk(h->X + i * k, y, k);
+    for (int64_t t = 0; t < len; ++t) mapped[t] = glrm_cpu_loss_evaluate(l, full[h->rowidx[b + t]], h->colvals[b + t]);
+  } else {
+    for (int64_t t = 0; t < len; ++t) {
+      double u = dotk(h->X + (int64_t)h->rowidx[b + t] * k, y, k);
+      mapped[t] = glrm_cpu_loss_evaluate(l, u, h->colvals[b + t]);
+    }
+  }
+  if (loss_is_single_dim(l->kind)) return julia_sum(mapped, len); /* reduce(+, mapped) */
+  double out = 0; /* `out = 0; out += ...` */
+  for (int64_t t = 0; t < len; ++t) out += mapped[t];
+  return out;
+}
+
+static int64_t max_col_len(const glrm_cpu_handle* h) {
+  int64_t mx = 0, nl = h->col_end - h->col_begin;
+  for (int64_t f = 0; f < nl; ++f) {
+    int64_t len = h->colptr[f + 1] - h->colptr[f];
+    if (len > mx) mx = len;
+  }
+  return mx;
+}
+
+/* ------------------------------------------------------------- half-steps */
+
+/* One inner X sweep over the local rows, src/algorithms/proxgrad.jl:118-156
+ * (threaded exactly like proxgrad_multithread.jl:118: rows are independent). */
+int glrm_cpu_step_x(glrm_cpu_handle* h, double min_stepsize) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  const int k = h->k;
+  const int64_t ml = h->row_end - h->row_begin;
+  int64_t trials = 0, accepts = 0;
+#pragma omp parallel num_threads(g_threads) reduction(+ : trials, accepts)
+  {
+    double g[ORACLE_MAX_K], newx[ORACLE_MAX_K];
+    double* scratch = h->dense_faithful ? (double*)malloc((size_t)h->n * 8) : NULL;
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t el = 0; el < ml; ++el) {
+      double* x = h->X + (h->row_begin + el) * k;
+      const int64_t b = h->rowptr[el], e = h->rowptr[el + 1];
+      for (int c = 0; c < k; ++c) g[c] = 0.0; /* fill!(g, 0.) :119 */
+      for (int64_t t = b; t < e; ++t) {       /* :122-132 */
+        int64_t f = h->colidx[t];
+        const double* y = h->Y + f * k;
+        double u = h->dense_faithful ? h->XY[(h->row_begin + el) * h->n + f] : dotk(x, y, k);
+        double cg = glrm_cpu_loss_grad(loss_of(h, f), u, h->rowvals[t]);
+        for (int c = 0; c < k; ++c) g[c] = fma(cg, y[c], g[c]); /* axpy!(curgrad, vf[f], g) :127 */
+      }
+      const double l = (double)(e - b) + 1;           /* :134 */
+      double obj_old = row_objective(h, el, x, scratch); /* :135 */
+      const glrm_reg* r = rx_of(h, el);
+      double alpha = h->alpharow[el];
+      while (alpha > min_stepsize) { /* :136 */
+        double stepsize = alpha / l; /* :137 */
+        for (int c = 0; c < k; ++c) newx[c] = fma(-stepsize, g[c], x[c]); /* axpy!(-stepsize,g,newve[e]) :140 */
+        glrm_cpu_reg_prox(r, newx, k, stepsize);                            /* :142 */
+        ++trials;
+        if (row_objective(h, el, newx, scratch) < obj_old) { /* :143 */
+          memcpy(x, newx, (size_t)k * 8);
+          alpha *= 1.05;
+          ++accepts;
+          break;
+        } else { /* :147-153 */
+          alpha *= .7;
+          if (alpha < min_stepsize) {
+            alpha = min_stepsize * 1.1;
+            break;
+          }
+        }
+      }
+      h->alpharow[el] = alpha;
+    }
+    free(scratch);
+  }
+  h->st.launches_x += 1; h->st.trials_x += trials; h->st.accepts_x += accepts;
+  recompute_XY(h); /* :157 */
+  return GLRM_OK;
+}
+
+/* One inner Y sweep over the local columns, src/algorithms/proxgrad.jl:162-201. */
+int glrm_cpu_step_y(glrm_cpu_handle* h, double min_stepsize) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  const int k = h->k;
+  const int64_t nl = h->col_end - h->col_begin;
+  const int64_t mlen = max_col_len(h) + (h->dense_faithful ? h->m : 0);
+  int64_t trials = 0, accepts = 0;
+  int oom = 0;
+#pragma omp parallel num_threads(g_threads) reduction(+ : trials, accepts) reduction(| : oom)
+  {
+    double G[ORACLE_MAX_K], newy[ORACLE_MAX_K];
+    double* mapped = (double*)malloc((size_t)(mlen ? mlen : 1) * 8);
+    if (!mapped) oom = 1;
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t fl = 0; fl < nl; ++fl) {
+      if (!mapped) continue;
+      const int64_t fg = h->col_begin + fl;
+      double* y = h->Y + fg * k;
+      const int64_t b = h->colptr[fl], e = h->colptr[fl + 1];
+      const glrm_loss* lo = loss_of(h, fg);
+      for (int c = 0; c < k; ++c) G[c] = 0.0; /* fill!(G, 0.) :161 */
+      for (int64_t t = b; t < e; ++t) {       /* :165-175 */
+        int64_t i = h->rowidx[t];
+        const double* x = h->X + i * k;
+        double u = h->dense_faithful ? h->XY[i * h->n + fg] : dotk(x, y, k);
+        double cg = glrm_cpu_loss_grad(lo, u, h->colvals[t]);
+        for (int c = 0; c < k; ++c) G[c] = fma(cg, x[c], G[c]); /* axpy!(curgrad, ve[e], gf[f]) :170 */
+      }
+      const double l = (double)(e - b) + 1; /* :177 */
+      const glrm_reg* r = ry_of(h, fl);
+      double obj = 0.0; /* col_objective :178; err = 0.0; err += loss; err += reg (evaluate_fit.jl:44-53) */
+      obj += col_loss(h, fl, y, mapped);
+      obj += glrm_cpu_reg_evaluate(r, y, k);
+      double alpha = h->alphacol[fl];
+      while (alpha > min_stepsize) { /* :179 */
+        double stepsize = alpha / l;
+        for (int c = 0; c < k; ++c) newy[c] = fma(-stepsize, G[c], y[c]); /* :183 */
+        glrm_cpu_reg_prox(r, newy, k, stepsize);                            /* :185 */
+        double nobj = 0.0;
+        nobj += col_loss(h, fl, newy, mapped);
+        nobj += glrm_cpu_reg_evaluate(r, newy, k);
+        ++trials;
+        if (nobj < obj) { /* :187-191 */
+          memcpy(y, newy, (size_t)k * 8);
+          alpha *= 1.05;
+          obj = nobj;
+          ++accepts;
+          break;
+        } else { /* :192-199 */
+          alpha *= .7;
+          if (alpha < min_stepsize) {
+            alpha = min_stepsize * 1.1;
+            break;
+          }
+        }
+      }
+      h->alphacol[fl] = alpha;
+      h->objcol[fg] = obj; /* obj_by_col[f] */
+    }
+    free(mapped);
+  }
+  if (oom) return fail(GLRM_ERR_OOM, "out of memory");
+  h->st.launches_y += 1; h->st.trials_y += trials; h->st.accepts_y += accepts;
+  recompute_XY(h); /* :202 */
+  return GLRM_OK;
+}
+
+/* Per-column loss sums (no regularizer) -> objcol[col_begin:col_end]. */
+int glrm_cpu_col_losses(glrm_cpu_handle* h) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  const int64_t nl = h->col_end - h->col_begin;
+  const int64_t mlen = max_col_len(h) + (h->dense_faithful ? h->m : 0);
+  double* mapped = (double*)malloc((size_t)(mlen ? mlen : 1) * 8);
+  if (!mapped) return fail(GLRM_ERR_OOM, "out of memory");
+  for (int64_t fl = 0; fl < nl; ++fl) {
+    /* sequential += like objective(), src/evaluate_fit.jl:13-17 */
+    const int k = h->k;
+    const int64_t fg = h->col_begin + fl;
+    const glrm_loss* lo = loss_of(h, fg);
+    double err = 0.0;
+    for (int64_t t = h->colptr[fl]; t < h->colptr[fl + 1]; ++t) {
+      double u = dotk(h->X + (int64_t)h->rowidx[t] * k, h->Y + fg * k, k);
+      err += glrm_cpu_loss_evaluate(lo, u, h->colvals[t]);
+    }
+    h->objcol[fg] = err;
+  }
+  free(mapped);
+  return GLRM_OK;
+}
+
+int glrm_cpu_row_penalties(glrm_cpu_handle* h) { /* calc_penalty, src/evaluate_fit.jl:97-99 */
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  for (int64_t el = 0; el < h->row_end - h->row_begin; ++el)
+    h->objrow[h->row_begin + el] = glrm_cpu_reg_evaluate(rx_of(h, el), h->X + (h->row_begin + el) * h->k, h->k);
+  return GLRM_OK;
+}
+
+int glrm_cpu_col_penalties(glrm_cpu_handle* h) { /* calc_penalty, src/evaluate_fit.jl:100-102 */
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  for (int64_t fl = 0; fl < h->col_end - h->col_begin; ++fl)
+    h->objcol[h->col_begin + fl] = glrm_cpu_reg_evaluate(ry_of(h, fl), h->Y + (h->col_begin + fl) * h->k, h->k);
+  return GLRM_OK;
+}
+
+int glrm_cpu_sum(glrm_cpu_handle* h, const void* vec, int64_t n, double* out) { /* sum(::Vector{Float64}) */
+  (void)h;
+  if (!out || (n > 0 && !vec)) return fail(GLRM_ERR_INVALID, "NULL argument");
+  *out = julia_sum((const double*)vec, n);
+  return GLRM_OK;
+}
+
+int glrm_cpu_synchronize(glrm_cpu_handle* h) { (void)h; return GLRM_OK; }
+int glrm_cpu_factor_ld(glrm_cpu_handle* h) { return h ? h->k : GLRM_ERR_INVALID; }
+
+int glrm_cpu_bind_buffers(glrm_cpu_handle* h, void* X, void* Y, void* objcol, void* objrow) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  h->X = X ? (double*)X : h->ownX;
+  h->Y = Y ? (double*)Y : h->ownY;
+  h->objcol = objcol ? (double*)objcol : h->ownobjcol;
+  h->objrow = objrow ? (double*)objrow : h->ownobjrow;
+  return GLRM_OK;
+}
+
+int glrm_cpu_set_factors(glrm_cpu_handle* h, const double* X, const double* Y) {
+  if (!h || !X || !Y) return fail(GLRM_ERR_INVALID, "NULL argument");
+  memcpy(h->X, X, (size_t)h->k * h->m * 8);
+  memcpy(h->Y, Y, (size_t)h->k * h->n * 8);
+  recompute_XY(h);
+  return GLRM_OK;
+}
+
+int glrm_cpu_get_factors(glrm_cpu_handle* h, double* X, double* Y) {
+  if (!h || !X || !Y) return fail(GLRM_ERR_INVALID, "NULL argument");
+  memcpy(X, h->X, (size_t)h->k * h->m * 8);
+  memcpy(Y, h->Y, (size_t)h->k * h->n * 8);
+  return GLRM_OK;
+}
+
+int glrm_cpu_reset_stepsizes(glrm_cpu_handle* h, double stepsize) { /* :69-70, :112-115 */
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  for (int64_t e = 0; e < h->row_end - h->row_begin; ++e) h->alpharow[e] = stepsize;
+  for (int64_t f = 0; f < h->col_end - h->col_begin; ++f) h->alphacol[f] = stepsize;
+  return GLRM_OK;
+}
+
+int glrm_cpu_kernel_stats(glrm_cpu_handle* h, glrm_kernel_stats* out, int reset) {
+  if (!h || !out) return fail(GLRM_ERR_INVALID, "NULL argument");
+  *out = h->st;
+  if (reset) {
+    h->st.launches_x = h->st.launches_y = 0;
+    h->st.trials_x = h->st.trials_y = h->st.accepts_x = h->st.accepts_y = 0;
+    h->st.ms_x = h->st.ms_y = 0;
+  }
+  return GLRM_OK;
+}
+
+/* Per-segment step sizes, for tests that compare the line-search state. */
+int glrm_cpu_get_stepsizes(glrm_cpu_handle* h, double* alpharow, double* alphacol) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (alpharow) memcpy(alpharow, h->alpharow, (size_t)(h->row_end - h->row_begin) * 8);
+  if (alphacol) memcpy(alphacol, h->alphacol, (size_t)(h->col_end - h->col_begin) * 8);
+  return GLRM_OK;
+}
+
+/* ------------------------------------------------------------ whole-fit API */
+
+static int single_shard(const glrm_cpu_handle* h) {
+  return h->row_begin == 0 && h->row_end == h->m && h->col_begin == 0 && h->col_end == h->n;
+}
+
+/* objective(glrm, X, Y, XY; include_regularization), src/evaluate_fit.jl:4-23 with
+ * calc_penalty :91-104: ONE accumulator across all columns, columns outer, list order inner. */
+static double full_objective(const glrm_cpu_handle* h, const double* X, const double* Y, int include_reg) {
+  const int k = h->k;
+  double err = 0.0;
+  for (int64_t j = 0; j < h->n; ++j) {
+    const glrm_loss* lo = loss_of(h, j);
+    for (int64_t t = h->colptr[j]; t < h->colptr[j + 1]; ++t) {
+      double u = dotk(X + (int64_t)h->rowidx[t] * k, Y + j * k, k);
+      err += glrm_cpu_loss_evaluate(lo, u, h->colvals[t]);
+    }
+  }
+  if (include_reg) {
+    double penalty = 0.0;
+    for (int64_t i = 0; i < h->m; ++i) penalty += glrm_cpu_reg_evaluate(rx_of(h, i), X + i * k, k);
+    for (int64_t f = 0; f < h->n; ++f) penalty += glrm_cpu_reg_evaluate(ry_of(h, f), Y + f * k, k);
+    err += penalty;
+  }
+  return err;
+}
+
+int glrm_cpu_objective(glrm_cpu_handle* h, const double* X, const double* Y, int include_reg, double* out) {
+  if (!h || !X || !Y || !out) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (!single_shard(h)) return fail(GLRM_ERR_INVALID, "glrm_cpu_objective needs a single-shard handle");
+  *out = full_objective(h, X, Y, include_reg);
+  return GLRM_OK;
+}
+
+/* fit!(glrm::GLRM, params::ProxGradParams), src/algorithms/proxgrad.jl:34-220. */
+int glrm_cpu_fit(glrm_cpu_handle* h, const glrm_params* prm, double* X, double* Y, double* objective,
+                 double* seconds, int64_t cap, int64_t* n_recorded) {
+  if (!h || !prm || !X || !Y || !objective || !seconds || !n_recorded) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (!single_shard(h)) return fail(GLRM_ERR_INVALID, "glrm_cpu_fit needs a single-shard handle");
+  if (prm->max_iter < 0 || cap < prm->max_iter + 1) return fail(GLRM_ERR_INVALID, "objective/seconds capacity must be >= max_iter+1");
+  if (prm->inner_iter_X < 1 || prm->inner_iter_Y < 1) return fail(GLRM_ERR_INVALID, "inner iteration counts must be >= 1");
+  const int k = h->k;
+  double ynorm = 0.0; /* norm(Y)==0 guard, :45-48 (the reference would hit an UndefVarError) */
+  for (int64_t i = 0; i < (int64_t)k * h->n; ++i) ynorm += Y[i] * Y[i];
+  if (ynorm == 0.0) return fail(GLRM_ERR_INVALID, "Y is all zeros (the reference cannot start from Y == 0)");
+
+  glrm_cpu_bind_buffers(h, NULL, NULL, NULL, NULL);
+  glrm_cpu_set_factors(h, X, Y);                 /* X = glrm.X; Y = glrm.Y; XY = X'Y  :43,:65-66 */
+  glrm_cpu_reset_stepsizes(h, prm->stepsize);    /* :69-70 */
+  double scaled_abs_tol = prm->abs_tol * (double)h->rowptr[h->m]; /* :72 uses observed_features */
+  int64_t nrec = 0;
+  objective[nrec] = full_objective(h, h->X, h->Y, 1); /* update_ch!(ch, 0, objective(...)) :76 */
+  seconds[nrec] = 0.0;
+  ++nrec;
+  double t = now_s();
+  for (int64_t i = 1; i <= prm->max_iter; ++i) { /* :107 */
+    if (prm->inner_iter_X > 1 || prm->inner_iter_Y > 1) glrm_cpu_reset_stepsizes(h, prm->stepsize); /* :112-115 */
+    for (int64_t inner = 0; inner < prm->inner_iter_X; ++inner) { /* :117 */
+      int rc = glrm_cpu_step_x(h, prm->min_stepsize);
+      if (rc) return rc;
+    }
+    for (int64_t inner = 0; inner < prm->inner_iter_Y; ++inner) { /* :160 */
+      int rc = glrm_cpu_step_y(h, prm->min_stepsize);
+      if (rc) return rc;
+    }
+    double obj = julia_sum(h->objcol, h->n); /* :205 */
+    double dt = now_s() - t;                 /* :206 */
+    objective[nrec] = obj;                   /* update_ch! :207, src/convergence.jl:16-27 */
+    seconds[nrec] = seconds[nrec - 1] + dt;
+    ++nrec;
+    t = now_s();
+    double obj_decrease = objective[nrec - 2] - obj; /* :210 */
+    if (i > 10 && (obj_decrease < scaled_abs_tol || obj_decrease / obj < prm->rel_tol)) break; /* :211-213 */
+  }
+  memcpy(X, h->X, (size_t)k * h->m * 8);
+  memcpy(Y, h->Y, (size_t)k * h->n * 8);
+  *n_recorded = nrec;
+  return GLRM_OK;
+}

@@ -1,0 +1,127 @@
+"""Test-side access to the CPU oracle (oracle/libglrm_oracle.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module: the
+oracle is the parity checker, never part of the product path.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_LIB = os.path.join(ORACLE_DIR, "libglrm_oracle.so")
+
+
+def build_oracle(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("glrm_oracle.c", "synth.c")] + [
+        os.path.join(ROOT, "include", f) for f in ("glrm_hip.h", "glrm_synth.h")]
+    stale = (not os.path.exists(ORACLE_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_LIB) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", ORACLE_DIR, "-s"], check=True)
+    return ORACLE_LIB
+
+
+_api = None
+_lib = None
+
+
+def oracle_lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build_oracle())
+        _lib.glrm_cpu_loss_evaluate.restype = C.c_double
+        _lib.glrm_cpu_loss_evaluate.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        _lib.glrm_cpu_loss_grad.restype = C.c_double
+        _lib.glrm_cpu_loss_grad.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        _lib.glrm_cpu_reg_evaluate.restype = C.c_double
+        _lib.glrm_cpu_reg_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _lib.glrm_cpu_reg_prox.restype = None
+        _lib.glrm_cpu_reg_prox.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+        _lib.glrm_cpu_set_threads.argtypes = [C.c_int]
+        _lib.glrm_cpu_set_dense_faithful.argtypes = [C.c_void_p, C.c_int]
+        _lib.glrm_cpu_get_stepsizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    return _lib
+
+
+def oracle_api():
+    """The oracle behind the same Api binder the product uses for the HIP library."""
+    global _api
+    if _api is None:
+        from lowrankmodels.jl_amd import _capi
+        _api = _capi.Api(oracle_lib(), "glrm_cpu_", "cpu")
+    return _api
+
+
+def set_threads(n):
+    oracle_lib().glrm_cpu_set_threads(int(n))
+
+
+def _loss_struct(loss):
+    from lowrankmodels.jl_amd import _capi
+    k, r, s, p0, p1 = loss.descriptor()
+    return _capi.CLoss(k, r, s, p0, p1)
+
+
+def _reg_struct(reg):
+    from lowrankmodels.jl_amd import _capi
+    k, r, s = reg.descriptor()
+    return _capi.CReg(k, r, s)
+
+
+def loss_evaluate(loss, u, a):
+    st = _loss_struct(loss)
+    return oracle_lib().glrm_cpu_loss_evaluate(C.addressof(st), float(u), float(a))
+
+
+def loss_grad(loss, u, a):
+    st = _loss_struct(loss)
+    return oracle_lib().glrm_cpu_loss_grad(C.addressof(st), float(u), float(a))
+
+
+def reg_evaluate(reg, x):
+    st = _reg_struct(reg)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    return oracle_lib().glrm_cpu_reg_evaluate(C.addressof(st), x.ctypes.data, x.size)
+
+
+def reg_prox(reg, u, alpha):
+    st = _reg_struct(reg)
+    u = np.array(u, dtype=np.float64)
+    oracle_lib().glrm_cpu_reg_prox(C.addressof(st), u.ctypes.data, u.size, float(alpha))
+    return u
+
+
+# ------------------------------------------------------------------ synthetic workloads (CPU)
+
+class SynthSpec(C.Structure):
+    _fields_ = [("m", C.c_int64), ("n", C.c_int64), ("k", C.c_int32), ("q", C.c_int32), ("seed", C.c_uint64),
+                ("value_model", C.c_int32), ("loss_mix", C.c_int32), ("noise", C.c_double)]
+
+
+def synth_cpu(m, n, k, q, seed=20260926, value_model=0, loss_mix=0, noise=0.1, init_seed=1,
+              rows=None, cols=None):
+    """Generate (rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0) with oracle/synth.c."""
+    lib = oracle_lib()
+    s = SynthSpec(m, n, k, q, seed, value_model, loss_mix, noise)
+    rb, re = (0, m) if rows is None else rows
+    cb, ce = (0, n) if cols is None else cols
+    nzr = (re - rb) * q
+    rowptr = np.zeros(re - rb + 1, np.int64)
+    colidx = np.zeros(nzr, np.int32)
+    rowvals = np.zeros(nzr, np.float64)
+    assert lib.glrm_synth_cpu_rows(C.byref(s), C.c_int64(rb), C.c_int64(re), C.c_void_p(rowptr.ctypes.data),
+                                   C.c_void_p(colidx.ctypes.data), C.c_void_p(rowvals.ctypes.data)) == 0
+    colptr = np.zeros(ce - cb + 1, np.int64)
+    assert lib.glrm_synth_cpu_col_counts(C.byref(s), C.c_int64(cb), C.c_int64(ce), C.c_void_p(colptr.ctypes.data)) == 0
+    nzc = int(colptr[-1])
+    rowidx = np.zeros(nzc, np.int32)
+    colvals = np.zeros(nzc, np.float64)
+    assert lib.glrm_synth_cpu_cols(C.byref(s), C.c_int64(cb), C.c_int64(ce), C.c_void_p(colptr.ctypes.data),
+                                   C.c_void_p(rowidx.ctypes.data), C.c_void_p(colvals.ctypes.data)) == 0
+    X0 = np.zeros((k, m), order="F")
+    Y0 = np.zeros((k, n), order="F")
+    assert lib.glrm_synth_cpu_init(C.byref(s), C.c_uint64(init_seed), C.c_int(k), C.c_void_p(X0.ctypes.data),
+                                   C.c_void_p(Y0.ctypes.data)) == 0
+    return rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0
