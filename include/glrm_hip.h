@@ -134,7 +134,7 @@ typedef struct glrm_params {
 typedef struct glrm_options {
   int32_t device_id; /* HIP device ordinal; -1 = current device */
   int32_t profile;   /* 1 = bracket every sweep launch with HIP events (glrm_hip_kernel_stats) */
-  int32_t waves_row; /* waves cooperating on one row   (0 = choose from mean |Omega_e|; 1, 4 or 16) */
+  int32_t waves_row; /* waves cooperating on one row   (0 = choose from mean |Omega_e|; 1, 4 or 8) */
   int32_t waves_col; /* waves cooperating on one column (0 = choose from mean |Omega^f|) */
   void* stream;      /* hipStream_t to launch on; NULL = the handle creates its own */
 } glrm_options;

@@ -1,0 +1,47 @@
+"""In-tree build of the gfx950 shared libraries (explicit hipcc; hipcc cross-compiles without a GPU).
+
+    libglrm_hip.so    the engine + C ABI (include/glrm_hip.h)
+    libglrm_synth.so  device-side synthetic workload generator (bench / test tooling)
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
+
+TARGETS = {
+    "libglrm_hip.so": (["glrm_hip.hip"], ["glrm_device.hpp", "../../include/glrm_hip.h"]),
+    "libglrm_synth.so": (["glrm_synth.hip"], ["../../include/glrm_synth.h"]),
+}
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_all(force=False, verbose=True):
+    built = []
+    for name, (srcs, hdrs) in TARGETS.items():
+        out = os.path.join(PKG, name)
+        src_paths = [os.path.join(CSRC, s) for s in srcs]
+        deps = src_paths + [os.path.normpath(os.path.join(CSRC, h)) for h in hdrs]
+        if force or _stale(out, deps):
+            cmd = [HIPCC] + FLAGS + src_paths + ["-o", out]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
+            built.append(name)
+    return built
+
+
+if __name__ == "__main__":
+    build_all(force=True)

@@ -1,0 +1,918 @@
+// glrm_hip.hip -- libglrm_hip.so: the MI355X (gfx950 / CDNA4) engine behind
+// LowRankModels.jl's fit!(glrm, ProxGradParams) (src/algorithms/proxgrad.jl:34-220).
+//
+// One HIP kernel per factor half-step ("sweep"):
+//   X half-step = row sweep over CSR-by-row   (proxgrad.jl:118-156 + evaluate_fit.jl:24-38)
+//   Y half-step = column sweep over CSC-by-col (proxgrad.jl:162-201 + evaluate_fit.jl:39-55)
+// Both are the same kernel template: a *segment* (row or column) is owned by WAVES wavefronts;
+// every observation of the segment is handled by a group of G lanes that reads the opposing
+// factor's k-vector with one 16-byte load per lane (16*G contiguous bytes per group), reduces
+// the dot product with DPP adds, evaluates loss and gradient, and accumulates the gradient in
+// registers.  Gradient pass, backtracking line search (one more pass over the segment per trial)
+// and the prox step are fused in the kernel; the accept/reject decision is wave/block uniform.
+// Reduction order is fixed by the code => results are run-to-run deterministic and independent of
+// how rows/columns are sharded over GPUs.
+//
+// No CPU fallback lives here; the CPU restatement (oracle/) is a separate, test-only library.
+
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "glrm_device.hpp"
+
+using namespace glrm;
+
+// =============================================================================== kernels
+
+struct SweepArgs {
+  int64_t nseg;          // local segments
+  const int64_t* ptr;    // nseg+1 offsets into idx/vals
+  const int32_t* idx;    // index into the opposing factor (global id)
+  const double* vals;    // A values
+  double* own;           // factor being updated (global array, leading dimension KP)
+  int64_t own_offset;    // global id of local segment 0
+  const double* other;   // opposing factor (global array, leading dimension KP)
+  double* alpha;         // per local segment step size
+  double* obj;           // per GLOBAL segment objective (nullable)
+  const glrm_loss* losses;
+  int loss_by_segment;   // LOSS==1: 1 -> losses[own_offset+seg], 0 -> losses[0]
+  const glrm_reg* regs;
+  int reg_single;        // 1 -> regs[0], 0 -> regs[seg]
+  int k;
+  int eval_only;         // 1: obj[seg] = sum of losses (no regularizer), nothing else is written
+  double min_stepsize;
+  int32_t* trials;       // per local segment accumulators (nullable)
+  int32_t* accepts;
+};
+
+enum { LOSS_QUAD_UNIFORM = 0, LOSS_SEGMENT = 1, LOSS_PER_OBS = 2 };
+
+// One pass over the segment for one wave: J = sum of losses at u = <xv, other[idx]>, and (GRAD)
+// g = sum of dL * other[idx].  Returns wave-level totals replicated in every lane.
+template <int G, int R, int WAVES, int LOSS, bool GRAD>
+__device__ __forceinline__ double sweep_pass(const SweepArgs& a, const Vec<G, R>& xv, Vec<G, R>& g, int64_t beg,
+                                             int64_t len, int gg, int j, const LossDesc& segloss) {
+  constexpr int KP = G * R, NG = 64 / G, TG = NG * WAVES;
+  double J = 0.0;
+  if (GRAD) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) g.v[i] = make_double2(0.0, 0.0);
+  }
+  const double2* __restrict__ other2 = reinterpret_cast<const double2*>(a.other);
+  const int32_t* __restrict__ idx = a.idx + beg;
+  const double* __restrict__ vals = a.vals + beg;
+  // Software pipeline: the index/value of step t+1 are requested while step t computes, so the
+  // dependent chain per step is only the factor gather.  The trip count is wave-uniform; lanes past
+  // the end of the segment re-read its last entry and are masked by `valid`.
+  int c = 0;
+  double av_next = 0.0;
+  if (len > 0) {
+    const int64_t tt = gg < len ? gg : len - 1;
+    c = idx[tt];
+    av_next = vals[tt];
+  }
+  for (int64_t t0 = 0; t0 < len; t0 += TG) {
+    const bool valid = t0 + gg < len;
+    const double2* __restrict__ yp = other2 + (int64_t)c * (KP / 2) + j;
+    double2 y[R / 2];
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) y[i] = yp[i * G];
+    const double av = av_next;
+    const int ccur = c;
+    {
+      int64_t tn = t0 + TG + gg;
+      tn = tn < len ? tn : len - 1;
+      c = idx[tn];
+      av_next = vals[tn];
+    }
+    double dot = 0.0;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      dot = fma(xv.v[i].x, y[i].x, dot);
+      dot = fma(xv.v[i].y, y[i].y, dot);
+    }
+    dot = group_sum<G>(dot);
+    double L, dL;
+    if constexpr (LOSS == LOSS_QUAD_UNIFORM) {
+      const double d = dot - av;
+      L = segloss.scale * (d * d);
+      dL = 2 * d * segloss.scale;
+    } else if constexpr (LOSS == LOSS_SEGMENT) {
+      loss_both<GRAD>(segloss, dot, av, L, dL);
+    } else {
+      const LossDesc lo = load_loss(a.losses, ccur);
+      loss_both<GRAD>(lo, dot, av, L, dL);
+    }
+    if (!valid) {
+      L = 0.0;
+      dL = 0.0;
+    }
+    J += L;
+    if (GRAD) {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) {
+        g.v[i].x = fma(dL, y[i].x, g.v[i].x);
+        g.v[i].y = fma(dL, y[i].y, g.v[i].y);
+      }
+    }
+  }
+  J = across_groups_sum<G>(J);
+  if (GRAD) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      g.v[i].x = across_groups_sum<G>(g.v[i].x);
+      g.v[i].y = across_groups_sum<G>(g.v[i].y);
+    }
+  }
+  return J;
+}
+
+// Combine the per-wave totals of a multi-wave segment through LDS, in wave order, so that every
+// thread of the block ends with the same bits.
+template <int G, int R, int WAVES, bool GRAD>
+__device__ __forceinline__ double block_combine(double J, Vec<G, R>& g, double* red, int wave, int lane) {
+  constexpr int KP = G * R, STRIDE = KP + 2;
+  if constexpr (WAVES == 1) return J;
+  const int j = lane % G;
+  __syncthreads(); // previous readers of `red` are done
+  if (lane < G) {
+    if (GRAD) {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) *reinterpret_cast<double2*>(&red[wave * STRIDE + i * 2 * G + 2 * j]) = g.v[i];
+    }
+    if (lane == 0) red[wave * STRIDE + KP] = J;
+  }
+  __syncthreads();
+  double Js = 0.0;
+  if (GRAD) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) g.v[i] = make_double2(0.0, 0.0);
+  }
+  for (int w = 0; w < WAVES; ++w) {
+    Js += red[w * STRIDE + KP];
+    if (GRAD) {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) {
+        const double2 p = *reinterpret_cast<const double2*>(&red[w * STRIDE + i * 2 * G + 2 * j]);
+        g.v[i].x += p.x;
+        g.v[i].y += p.y;
+      }
+    }
+  }
+  return Js;
+}
+
+template <int G, int R, int WAVES, int LOSS>
+__global__ void __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64) sweep_kernel(const SweepArgs a) {
+  constexpr int KP = G * R, NG = 64 / G;
+  __shared__ __attribute__((aligned(16))) double red[WAVES == 1 ? 2 : WAVES * (KP + 2)];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform -> SGPR
+  const int64_t seg = WAVES == 1 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+  if (seg >= a.nseg) return; // wave-uniform (WAVES==1) or block-uniform
+  const int j = lane % G, gi = lane / G;
+  const int gg = (WAVES == 1 ? 0 : wave * NG) + gi;
+  const int64_t beg = a.ptr[seg], len = a.ptr[seg + 1] - beg;
+  const int64_t gseg = a.own_offset + seg;
+  double2* ownp = reinterpret_cast<double2*>(a.own + gseg * KP);
+
+  Vec<G, R> x, g;
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) x.v[i] = ownp[i * G + j];
+  const RegDesc rd = load_reg(a.regs, a.reg_single ? 0 : seg);
+  LossDesc segloss;
+  if constexpr (LOSS != LOSS_PER_OBS) segloss = load_loss(a.losses, a.loss_by_segment ? gseg : 0);
+  else segloss = LossDesc{0, 1.0, 0.0, 0.0};
+
+  // pass 1: gradient + objective at the current point (proxgrad.jl:122-135 / :165-178)
+  double Jold = sweep_pass<G, R, WAVES, LOSS, true>(a, x, g, beg, len, gg, j, segloss);
+  Jold = block_combine<G, R, WAVES, true>(Jold, g, red, wave, lane);
+  if (a.eval_only) {
+    if (threadIdx.x == (WAVES == 1 ? wave * 64 : 0) && a.obj) a.obj[gseg] = Jold;
+    return;
+  }
+  Jold += reg_eval<G, R>(rd, x, j, a.k);
+
+  // backtracking line search (proxgrad.jl:136-155 / :179-200); g is NOT recomputed between trials
+  double alpha = a.alpha[seg];
+  const double l = (double)len + 1.0;
+  int ntrials = 0;
+  bool accepted = false;
+  while (alpha > a.min_stepsize) {
+    const double s = alpha / l;
+    Vec<G, R> xn, dummy;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) { // axpy!(-stepsize, g, newx)
+      xn.v[i].x = fma(-s, g.v[i].x, x.v[i].x);
+      xn.v[i].y = fma(-s, g.v[i].y, x.v[i].y);
+    }
+    reg_prox<G, R>(rd, xn, s, j, a.k); // prox!(r, newx, stepsize)
+    double Jn = sweep_pass<G, R, WAVES, LOSS, false>(a, xn, dummy, beg, len, gg, j, segloss);
+    Jn = block_combine<G, R, WAVES, false>(Jn, dummy, red, wave, lane);
+    Jn += reg_eval<G, R>(rd, xn, j, a.k);
+    ++ntrials;
+    if (Jn < Jold) { // strict; false for NaN and for Inf < Inf
+      x = xn;
+      alpha *= 1.05;
+      Jold = Jn;
+      accepted = true;
+      break;
+    }
+    alpha *= .7;
+    if (alpha < a.min_stepsize) {
+      alpha = a.min_stepsize * 1.1;
+      break;
+    }
+  }
+
+  if (accepted && wave == (WAVES == 1 ? wave : 0) && gi == 0) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = x.v[i];
+  }
+  if (lane == 0 && (WAVES == 1 || wave == 0)) {
+    a.alpha[seg] = alpha;
+    if (a.obj) a.obj[gseg] = Jold;
+    if (a.trials) {
+      a.trials[seg] += ntrials;
+      a.accepts[seg] += accepted ? 1 : 0;
+    }
+  }
+}
+
+// evaluate(r, factor[:,seg]) for every local segment (calc_penalty, src/evaluate_fit.jl:91-104)
+__global__ void penalty_kernel(const double* fac, int ld, int k, int64_t offset, int64_t nseg, const glrm_reg* regs,
+                               int reg_single, double* out) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nseg) return;
+  const double* x = fac + (offset + s) * ld;
+  const glrm_reg r = regs[reg_single ? 0 : s];
+  double v = 0.0;
+  switch (r.kind) {
+    case GLRM_REG_QUAD: {
+      double acc = 0.0;
+      for (int c = 0; c < k; ++c) acc += x[c] * x[c];
+      v = r.scale * acc;
+      break;
+    }
+    case GLRM_REG_ONE: {
+      double acc = 0.0;
+      for (int c = 0; c < k; ++c) acc += fabs(x[c]);
+      v = r.scale * acc;
+      break;
+    }
+    case GLRM_REG_NONNEG:
+      for (int c = 0; c < k; ++c)
+        if (x[c] < 0) v = __builtin_inf();
+      break;
+    case GLRM_REG_UNIT_ONE_SPARSE: {
+      int ones = 0, other = 0;
+      for (int c = 0; c < k; ++c) {
+        if (x[c] == 0) continue;
+        if (x[c] == 1) ++ones; else ++other;
+      }
+      if (other > 0 || ones > 1) v = __builtin_inf();
+      break;
+    }
+    default:
+      break;
+  }
+  out[offset + s] = v;
+}
+
+// Fixed-shape two-stage sum: 256 blocks x 256 threads, strided partials, LDS tree, then one block.
+// The shape never depends on the shard layout, so the recorded objective is G-invariant.
+constexpr int SUM_BLOCKS = 256, SUM_THREADS = 256;
+
+__device__ __forceinline__ double block_tree_sum(double v, double* sh) {
+  sh[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = SUM_THREADS / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+    __syncthreads();
+  }
+  return sh[0];
+}
+
+__global__ void __launch_bounds__(SUM_THREADS) sum_stage1(const double* v, int64_t n, double* partials) {
+  __shared__ double sh[SUM_THREADS];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * SUM_THREADS + threadIdx.x; i < n; i += (int64_t)SUM_BLOCKS * SUM_THREADS) acc += v[i];
+  const double t = block_tree_sum(acc, sh);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ void __launch_bounds__(SUM_THREADS) sum_stage2(const double* partials, double* out) {
+  __shared__ double sh[SUM_THREADS];
+  const double t = block_tree_sum(partials[threadIdx.x], sh);
+  if (threadIdx.x == 0) *out = t;
+}
+
+__global__ void fill_kernel(double* p, int64_t n, double v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void isum_kernel(const int32_t* v, int64_t n, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) acc += (unsigned long long)v[i];
+  for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+// =============================================================================== host side
+
+static thread_local char g_err[768];
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCK(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail(e_ == hipErrorOutOfMemory ? GLRM_ERR_OOM : GLRM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                                         \
+  } while (0)
+
+struct glrm_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int64_t m = 0, n = 0;
+  int k = 0, kp = 0;
+  int64_t rb = 0, re = 0, cb = 0, ce = 0, ml = 0, nl = 0, nnz_r = 0, nnz_c = 0;
+  int64_t *rowptr = nullptr, *colptr = nullptr;
+  int32_t *colidx = nullptr, *rowidx = nullptr;
+  double *rowvals = nullptr, *colvals = nullptr;
+  glrm_loss* losses = nullptr;
+  int64_t n_losses = 0;
+  bool loss_quad_uniform = false;
+  glrm_reg *rx = nullptr, *ry = nullptr;
+  int64_t n_rx = 0, n_ry = 0;
+  double *alpharow = nullptr, *alphacol = nullptr;
+  double *X = nullptr, *Y = nullptr, *objcol = nullptr, *objrow = nullptr;             // in use (bound or owned)
+  double *oX = nullptr, *oY = nullptr, *oobjcol = nullptr, *oobjrow = nullptr;         // owned
+  double *partials = nullptr, *dscalar = nullptr;
+  unsigned long long* dcount = nullptr;
+  int32_t *trials_r = nullptr, *accepts_r = nullptr, *trials_c = nullptr, *accepts_c = nullptr;
+  int waves_row = 1, waves_col = 4;
+  int profile = 0;
+  struct Ev { hipEvent_t a, b; int which; };
+  std::vector<Ev> pending, pool;
+  int64_t launches_x = 0, launches_y = 0;
+  double ms_x = 0, ms_y = 0;
+};
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) ok = false;
+    if (ok && prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+  }
+  ~DeviceGuard() {
+    int cur;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+
+extern "C" int glrm_hip_version(void) { return GLRM_HIP_ABI_VERSION; }
+extern "C" const char* glrm_hip_last_error(void) { return g_err; }
+
+static int pick_layout(int k, int& G, int& R) {
+  if (k <= 8) { G = 4; R = 2; }
+  else if (k <= 16) { G = 4; R = 4; }
+  else if (k <= 32) { G = 4; R = 8; }
+  else if (k <= 64) { G = 8; R = 8; }
+  else if (k <= 128) { G = 16; R = 8; }
+  else return -1;
+  return 0;
+}
+
+static int pick_waves(int requested, int64_t nnz, int64_t nseg) {
+  if (requested == 1 || requested == 4 || requested == 8) return requested;
+  const double avg = nseg > 0 ? (double)nnz / (double)nseg : 0.0;
+  if (avg < 1536) return 1;
+  if (avg < 98304) return 4;
+  return 8;
+}
+
+template <typename T>
+static int dev_copy_in(T** dst, const T* src, int64_t count, bool src_on_device, hipStream_t st) {
+  *dst = nullptr;
+  const size_t bytes = (size_t)(count > 0 ? count : 1) * sizeof(T);
+  HIPCK(hipMalloc((void**)dst, bytes));
+  if (count > 0)
+    HIPCK(hipMemcpyAsync(*dst, src, (size_t)count * sizeof(T), src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+  return GLRM_OK;
+}
+
+static bool is_classification(int kind) { return kind == GLRM_LOSS_LOGISTIC || kind == GLRM_LOSS_WEIGHTED_HINGE; }
+
+// Host-array validation: the checks of the GLRM constructor (src/glrm.jl:38-43,63-71) and of the
+// Bool coercion (src/losses.jl:104-106), plus structural checks of the CSR / CSC arrays.
+static int check_view(const char* name, int64_t nseg, const int64_t* ptr, const int32_t* idx, const double* vals,
+                      int64_t bound, const glrm_problem* p, bool by_idx, int64_t seg_offset) {
+  if (!ptr) return fail(GLRM_ERR_INVALID, "%s pointer array is NULL", name);
+  if (ptr[0] != 0) return fail(GLRM_ERR_INVALID, "%s[0] must be 0", name);
+  for (int64_t s = 0; s < nseg; ++s)
+    if (ptr[s + 1] < ptr[s]) return fail(GLRM_ERR_INVALID, "%s is not monotone at %lld", name, (long long)s);
+  if (ptr[nseg] > 0 && (!idx || !vals)) return fail(GLRM_ERR_INVALID, "%s index/value arrays are NULL", name);
+  for (int64_t s = 0; s < nseg; ++s) {
+    for (int64_t t = ptr[s]; t < ptr[s + 1]; ++t) {
+      if (idx[t] < 0 || idx[t] >= bound)
+        return fail(GLRM_ERR_INVALID, "%s: index %d out of range [0,%lld)", name, idx[t], (long long)bound);
+      const int64_t e = by_idx ? seg_offset + s : idx[t], f = by_idx ? idx[t] : seg_offset + s;
+      if (std::isnan(vals[t]))
+        return fail(GLRM_ERR_NONFINITE, "Observed value in entry (%lld, %lld) is NaN.", (long long)e, (long long)f);
+      const glrm_loss& l = p->n_losses == 1 ? p->losses[0] : p->losses[f];
+      if (is_classification(l.kind) && !(vals[t] == 1.0 || vals[t] == 0.0))
+        return fail(GLRM_ERR_NONFINITE, "entry in column %lld has label %g; a ClassificationLoss needs true(1)/false(0)",
+                    (long long)f, vals[t]);
+    }
+  }
+  return GLRM_OK;
+}
+
+static int check_desc(const glrm_problem* p) {
+  const int64_t ml = p->row_end - p->row_begin, nl = p->col_end - p->col_begin;
+  if (!p->losses || !(p->n_losses == 1 || p->n_losses == p->n))
+    return fail(GLRM_ERR_INVALID, "There must be as many losses as there are columns in the data matrix (n_losses=%lld, n=%lld)",
+                (long long)p->n_losses, (long long)p->n);
+  if (!p->rx || !(p->n_rx == 1 || p->n_rx == ml))
+    return fail(GLRM_ERR_INVALID, "There must be either one X regularizer or as many X regularizers as there are rows in the data matrix");
+  if (!p->ry || !(p->n_ry == 1 || p->n_ry == nl))
+    return fail(GLRM_ERR_INVALID, "There must be either one Y regularizer or as many Y regularizers as there are columns in the data matrix");
+  for (int64_t i = 0; i < p->n_losses; ++i) {
+    if (p->losses[i].kind < 0 || p->losses[i].kind >= GLRM_LOSS_KIND_COUNT)
+      return fail(GLRM_ERR_UNSUPPORTED, "loss kind %d (column %lld) is not a supported scalar loss", p->losses[i].kind, (long long)i);
+    if (p->losses[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_loss.reserved must be 0");
+  }
+  for (int64_t i = 0; i < p->n_rx; ++i) {
+    if (p->rx[i].kind < 0 || p->rx[i].kind >= GLRM_REG_KIND_COUNT) return fail(GLRM_ERR_UNSUPPORTED, "rx regularizer kind %d is not supported", p->rx[i].kind);
+    if (p->rx[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_reg.reserved must be 0");
+  }
+  for (int64_t i = 0; i < p->n_ry; ++i) {
+    if (p->ry[i].kind < 0 || p->ry[i].kind >= GLRM_REG_KIND_COUNT) return fail(GLRM_ERR_UNSUPPORTED, "ry regularizer kind %d is not supported", p->ry[i].kind);
+    if (p->ry[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_reg.reserved must be 0");
+  }
+  return GLRM_OK;
+}
+
+extern "C" void glrm_hip_destroy(glrm_handle* h) {
+  if (!h) return;
+  DeviceGuard dg(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  void* ptrs[] = {h->rowptr, h->colptr, h->colidx, h->rowidx, h->rowvals, h->colvals, h->losses, h->rx, h->ry,
+                  h->alpharow, h->alphacol, h->oX, h->oY, h->oobjcol, h->oobjrow, h->partials, h->dscalar, h->dcount,
+                  h->trials_r, h->accepts_r, h->trials_c, h->accepts_c};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  for (auto& e : h->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& e : h->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options* o) {
+  const bool on_dev = (p->flags & GLRM_PROBLEM_DEVICE_ARRAYS) != 0;
+  h->m = p->m; h->n = p->n; h->k = p->k;
+  h->rb = p->row_begin; h->re = p->row_end; h->cb = p->col_begin; h->ce = p->col_end;
+  h->ml = h->re - h->rb; h->nl = h->ce - h->cb;
+  int G, R;
+  pick_layout(p->k, G, R);
+  h->kp = G * R;
+  h->profile = o ? o->profile : 0;
+  if (o && o->stream) {
+    h->stream = (hipStream_t)o->stream;
+  } else {
+    HIPCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->own_stream = true;
+  }
+  hipStream_t st = h->stream;
+  int rc;
+  if ((rc = dev_copy_in(&h->rowptr, p->rowptr, h->ml + 1, on_dev, st))) return rc;
+  if ((rc = dev_copy_in(&h->colptr, p->colptr, h->nl + 1, on_dev, st))) return rc;
+  if (on_dev) {
+    HIPCK(hipMemcpyAsync(&h->nnz_r, p->rowptr + h->ml, 8, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(&h->nnz_c, p->colptr + h->nl, 8, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+  } else {
+    h->nnz_r = p->rowptr[h->ml];
+    h->nnz_c = p->colptr[h->nl];
+  }
+  if ((rc = dev_copy_in(&h->colidx, p->colidx, h->nnz_r, on_dev, st))) return rc;
+  if ((rc = dev_copy_in(&h->rowvals, p->rowvals, h->nnz_r, on_dev, st))) return rc;
+  if ((rc = dev_copy_in(&h->rowidx, p->rowidx, h->nnz_c, on_dev, st))) return rc;
+  if ((rc = dev_copy_in(&h->colvals, p->colvals, h->nnz_c, on_dev, st))) return rc;
+  h->n_losses = p->n_losses; h->n_rx = p->n_rx; h->n_ry = p->n_ry;
+  if ((rc = dev_copy_in(&h->losses, p->losses, p->n_losses, false, st))) return rc;
+  if ((rc = dev_copy_in(&h->rx, p->rx, p->n_rx, false, st))) return rc;
+  if ((rc = dev_copy_in(&h->ry, p->ry, p->n_ry, false, st))) return rc;
+  h->loss_quad_uniform = p->n_losses == 1 && p->losses[0].kind == GLRM_LOSS_QUAD;
+  const int64_t ml1 = h->ml > 0 ? h->ml : 1, nl1 = h->nl > 0 ? h->nl : 1;
+  HIPCK(hipMalloc((void**)&h->alpharow, ml1 * 8));
+  HIPCK(hipMalloc((void**)&h->alphacol, nl1 * 8));
+  HIPCK(hipMalloc((void**)&h->partials, SUM_BLOCKS * 8));
+  HIPCK(hipMalloc((void**)&h->dscalar, 8));
+  HIPCK(hipMalloc((void**)&h->dcount, 8));
+  HIPCK(hipMalloc((void**)&h->trials_r, ml1 * 4));
+  HIPCK(hipMalloc((void**)&h->accepts_r, ml1 * 4));
+  HIPCK(hipMalloc((void**)&h->trials_c, nl1 * 4));
+  HIPCK(hipMalloc((void**)&h->accepts_c, nl1 * 4));
+  HIPCK(hipMemsetAsync(h->trials_r, 0, ml1 * 4, st));
+  HIPCK(hipMemsetAsync(h->accepts_r, 0, ml1 * 4, st));
+  HIPCK(hipMemsetAsync(h->trials_c, 0, nl1 * 4, st));
+  HIPCK(hipMemsetAsync(h->accepts_c, 0, nl1 * 4, st));
+  h->waves_row = pick_waves(o ? o->waves_row : 0, h->nnz_r, h->ml);
+  h->waves_col = pick_waves(o ? o->waves_col : 0, h->nnz_c, h->nl);
+  HIPCK(hipStreamSynchronize(st)); // host descriptor / index arrays may be released by the caller now
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_create(glrm_handle** out, const glrm_problem* p, const glrm_options* o) {
+  if (!out || !p) return fail(GLRM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (p->m <= 0 || p->n <= 0 || p->k <= 0) return fail(GLRM_ERR_INVALID, "m, n, k must be positive");
+  if (p->m > INT32_MAX || p->n > INT32_MAX) return fail(GLRM_ERR_UNSUPPORTED, "m, n must fit int32 indices");
+  int G, R;
+  if (pick_layout(p->k, G, R)) return fail(GLRM_ERR_UNSUPPORTED, "rank k=%d is above the engine's limit of 128", p->k);
+  if (p->row_begin < 0 || p->row_end > p->m || p->row_begin > p->row_end || p->col_begin < 0 || p->col_end > p->n ||
+      p->col_begin > p->col_end)
+    return fail(GLRM_ERR_INVALID, "shard ranges out of bounds");
+  int rc = check_desc(p);
+  if (rc) return rc;
+  if (!(p->flags & GLRM_PROBLEM_DEVICE_ARRAYS)) {
+    rc = check_view("rowptr", p->row_end - p->row_begin, p->rowptr, p->colidx, p->rowvals, p->n, p, true, p->row_begin);
+    if (rc) return rc;
+    rc = check_view("colptr", p->col_end - p->col_begin, p->colptr, p->rowidx, p->colvals, p->m, p, false, p->col_begin);
+    if (rc) return rc;
+  } else if (!p->rowptr || !p->colptr) {
+    return fail(GLRM_ERR_INVALID, "rowptr / colptr are NULL");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(GLRM_ERR_HIP, "no HIP device is visible (this engine has no CPU fallback)");
+  int dev = o ? o->device_id : -1;
+  if (dev < 0) HIPCK(hipGetDevice(&dev));
+  if (dev >= ndev) return fail(GLRM_ERR_INVALID, "device_id %d out of range (%d devices)", dev, ndev);
+  DeviceGuard dg(dev);
+  if (!dg.ok) return fail(GLRM_ERR_HIP, "cannot select device %d", dev);
+  glrm_handle* h = new (std::nothrow) glrm_handle();
+  if (!h) return fail(GLRM_ERR_OOM, "out of host memory");
+  h->device = dev;
+  rc = create_impl(h, p, o);
+  if (rc) {
+    char keep[sizeof g_err];
+    memcpy(keep, g_err, sizeof keep);
+    glrm_hip_destroy(h);
+    memcpy(g_err, keep, sizeof keep);
+    return rc;
+  }
+  *out = h;
+  return GLRM_OK;
+}
+
+// ------------------------------------------------------------------ buffers and factors
+
+static int ensure_owned(glrm_handle* h) {
+  if (!h->X) {
+    if (!h->oX) { HIPCK(hipMalloc((void**)&h->oX, (size_t)h->kp * h->m * 8)); HIPCK(hipMemsetAsync(h->oX, 0, (size_t)h->kp * h->m * 8, h->stream)); }
+    h->X = h->oX;
+  }
+  if (!h->Y) {
+    if (!h->oY) { HIPCK(hipMalloc((void**)&h->oY, (size_t)h->kp * h->n * 8)); HIPCK(hipMemsetAsync(h->oY, 0, (size_t)h->kp * h->n * 8, h->stream)); }
+    h->Y = h->oY;
+  }
+  if (!h->objcol) {
+    if (!h->oobjcol) { HIPCK(hipMalloc((void**)&h->oobjcol, (size_t)h->n * 8)); HIPCK(hipMemsetAsync(h->oobjcol, 0, (size_t)h->n * 8, h->stream)); }
+    h->objcol = h->oobjcol;
+  }
+  if (!h->objrow) {
+    if (!h->oobjrow) { HIPCK(hipMalloc((void**)&h->oobjrow, (size_t)h->m * 8)); HIPCK(hipMemsetAsync(h->oobjrow, 0, (size_t)h->m * 8, h->stream)); }
+    h->objrow = h->oobjrow;
+  }
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_factor_ld(glrm_handle* h) { return h ? h->kp : fail(GLRM_ERR_INVALID, "NULL handle"); }
+
+extern "C" int glrm_hip_bind_buffers(glrm_handle* h, void* dX, void* dY, void* dObjCol, void* dObjRow) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  DeviceGuard dg(h->device);
+  h->X = (double*)dX; h->Y = (double*)dY; h->objcol = (double*)dObjCol; h->objrow = (double*)dObjRow;
+  return ensure_owned(h);
+}
+
+extern "C" int glrm_hip_set_factors(glrm_handle* h, const double* X, const double* Y) {
+  if (!h || !X || !Y) return fail(GLRM_ERR_INVALID, "NULL argument");
+  DeviceGuard dg(h->device);
+  int rc = ensure_owned(h);
+  if (rc) return rc;
+  const size_t kb = (size_t)h->k * 8, pb = (size_t)h->kp * 8;
+  if (h->kp != h->k) {
+    HIPCK(hipMemsetAsync(h->X, 0, pb * h->m, h->stream));
+    HIPCK(hipMemsetAsync(h->Y, 0, pb * h->n, h->stream));
+  }
+  HIPCK(hipMemcpy2DAsync(h->X, pb, X, kb, kb, (size_t)h->m, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpy2DAsync(h->Y, pb, Y, kb, kb, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_get_factors(glrm_handle* h, double* X, double* Y) {
+  if (!h || !X || !Y) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (!h->X || !h->Y) return fail(GLRM_ERR_INVALID, "no factors on the device yet");
+  DeviceGuard dg(h->device);
+  const size_t kb = (size_t)h->k * 8, pb = (size_t)h->kp * 8;
+  HIPCK(hipMemcpy2DAsync(X, kb, h->X, pb, kb, (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipMemcpy2DAsync(Y, kb, h->Y, pb, kb, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_reset_stepsizes(glrm_handle* h, double stepsize) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  DeviceGuard dg(h->device);
+  if (h->ml > 0) hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((h->ml + 255) / 256)), dim3(256), 0, h->stream, h->alpharow, h->ml, stepsize);
+  if (h->nl > 0) hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((h->nl + 255) / 256)), dim3(256), 0, h->stream, h->alphacol, h->nl, stepsize);
+  HIPCK(hipGetLastError());
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_synchronize(glrm_handle* h) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  DeviceGuard dg(h->device);
+  HIPCK(hipStreamSynchronize(h->stream));
+  return GLRM_OK;
+}
+
+// ------------------------------------------------------------------ sweep launch
+
+template <int G, int R, int WAVES>
+static void launch_sweep_loss(int loss, const SweepArgs& a, hipStream_t st) {
+  const unsigned grid = (unsigned)(WAVES == 1 ? (a.nseg + 3) / 4 : a.nseg);
+  const dim3 block(WAVES == 1 ? 256 : WAVES * 64);
+  switch (loss) {
+    case LOSS_QUAD_UNIFORM: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_QUAD_UNIFORM>), dim3(grid), block, 0, st, a); break;
+    case LOSS_SEGMENT: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_SEGMENT>), dim3(grid), block, 0, st, a); break;
+    default: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_PER_OBS>), dim3(grid), block, 0, st, a); break;
+  }
+}
+
+template <int G, int R>
+static void launch_sweep_waves(int waves, int loss, const SweepArgs& a, hipStream_t st) {
+  switch (waves) {
+    case 1: launch_sweep_loss<G, R, 1>(loss, a, st); break;
+    case 4: launch_sweep_loss<G, R, 4>(loss, a, st); break;
+    default: launch_sweep_loss<G, R, 8>(loss, a, st); break;
+  }
+}
+
+static void launch_sweep(int kp, int waves, int loss, const SweepArgs& a, hipStream_t st) {
+  switch (kp) {
+    case 8: launch_sweep_waves<4, 2>(waves, loss, a, st); break;
+    case 16: launch_sweep_waves<4, 4>(waves, loss, a, st); break;
+    case 32: launch_sweep_waves<4, 8>(waves, loss, a, st); break;
+    case 64: launch_sweep_waves<8, 8>(waves, loss, a, st); break;
+    default: launch_sweep_waves<16, 8>(waves, loss, a, st); break;
+  }
+}
+
+static int drain_events(glrm_handle* h) {
+  for (auto& e : h->pending) {
+    HIPCK(hipEventSynchronize(e.b));
+    float ms = 0;
+    HIPCK(hipEventElapsedTime(&ms, e.a, e.b));
+    (e.which == 0 ? h->ms_x : h->ms_y) += ms;
+    h->pool.push_back(e);
+  }
+  h->pending.clear();
+  return GLRM_OK;
+}
+
+// which: 0 = row sweep (X half-step), 1 = column sweep (Y half-step)
+static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_only) {
+  int rc = ensure_owned(h);
+  if (rc) return rc;
+  SweepArgs a{};
+  const bool rows = which == 0;
+  a.nseg = rows ? h->ml : h->nl;
+  if (a.nseg <= 0) return GLRM_OK;
+  a.ptr = rows ? h->rowptr : h->colptr;
+  a.idx = rows ? h->colidx : h->rowidx;
+  a.vals = rows ? h->rowvals : h->colvals;
+  a.own = rows ? h->X : h->Y;
+  a.own_offset = rows ? h->rb : h->cb;
+  a.other = rows ? h->Y : h->X;
+  a.alpha = rows ? h->alpharow : h->alphacol;
+  a.obj = rows ? nullptr : h->objcol;
+  a.losses = h->losses;
+  a.regs = rows ? h->rx : h->ry;
+  a.reg_single = (rows ? h->n_rx : h->n_ry) == 1;
+  a.k = h->k;
+  a.eval_only = eval_only;
+  a.min_stepsize = min_stepsize;
+  a.trials = eval_only ? nullptr : (rows ? h->trials_r : h->trials_c);
+  a.accepts = rows ? h->accepts_r : h->accepts_c;
+  int loss;
+  if (h->loss_quad_uniform) { loss = LOSS_QUAD_UNIFORM; a.loss_by_segment = 0; }
+  else if (h->n_losses == 1) { loss = LOSS_SEGMENT; a.loss_by_segment = 0; }
+  else if (rows) { loss = LOSS_PER_OBS; a.loss_by_segment = 0; }
+  else { loss = LOSS_SEGMENT; a.loss_by_segment = 1; }
+  glrm_handle::Ev ev{};
+  const bool timed = h->profile && !eval_only;
+  if (timed) {
+    if (!h->pool.empty()) { ev = h->pool.back(); h->pool.pop_back(); }
+    else { HIPCK(hipEventCreate(&ev.a)); HIPCK(hipEventCreate(&ev.b)); }
+    ev.which = which;
+    HIPCK(hipEventRecord(ev.a, h->stream));
+  }
+  launch_sweep(h->kp, rows ? h->waves_row : h->waves_col, loss, a, h->stream);
+  HIPCK(hipGetLastError());
+  if (timed) {
+    HIPCK(hipEventRecord(ev.b, h->stream));
+    h->pending.push_back(ev);
+    if (h->pending.size() >= 4096) { rc = drain_events(h); if (rc) return rc; }
+  }
+  if (!eval_only) (rows ? h->launches_x : h->launches_y) += 1;
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_step_x(glrm_handle* h, double min_stepsize) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  DeviceGuard dg(h->device);
+  return run_sweep(h, 0, min_stepsize, 0);
+}
+
+extern "C" int glrm_hip_step_y(glrm_handle* h, double min_stepsize) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  DeviceGuard dg(h->device);
+  return run_sweep(h, 1, min_stepsize, 0);
+}
+
+extern "C" int glrm_hip_col_losses(glrm_handle* h) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  DeviceGuard dg(h->device);
+  return run_sweep(h, 1, 0.0, 1);
+}
+
+static int run_penalty(glrm_handle* h, bool rows) {
+  int rc = ensure_owned(h);
+  if (rc) return rc;
+  const int64_t nseg = rows ? h->ml : h->nl;
+  if (nseg <= 0) return GLRM_OK;
+  hipLaunchKernelGGL(penalty_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, h->stream, rows ? h->X : h->Y, h->kp,
+                     h->k, rows ? h->rb : h->cb, nseg, rows ? h->rx : h->ry, (rows ? h->n_rx : h->n_ry) == 1 ? 1 : 0,
+                     rows ? h->objrow : h->objcol);
+  HIPCK(hipGetLastError());
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_row_penalties(glrm_handle* h) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  DeviceGuard dg(h->device);
+  return run_penalty(h, true);
+}
+
+extern "C" int glrm_hip_col_penalties(glrm_handle* h) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  DeviceGuard dg(h->device);
+  return run_penalty(h, false);
+}
+
+extern "C" int glrm_hip_sum(glrm_handle* h, const void* dvec, int64_t n, double* out) {
+  if (!h || !out || (n > 0 && !dvec)) return fail(GLRM_ERR_INVALID, "NULL argument");
+  DeviceGuard dg(h->device);
+  hipLaunchKernelGGL(sum_stage1, dim3(SUM_BLOCKS), dim3(SUM_THREADS), 0, h->stream, (const double*)dvec, n, h->partials);
+  hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(SUM_THREADS), 0, h->stream, h->partials, h->dscalar);
+  HIPCK(hipGetLastError());
+  HIPCK(hipMemcpyAsync(out, h->dscalar, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return GLRM_OK;
+}
+
+static int count_sum(glrm_handle* h, const int32_t* v, int64_t n, int64_t* out) {
+  *out = 0;
+  if (n <= 0) return GLRM_OK;
+  HIPCK(hipMemsetAsync(h->dcount, 0, 8, h->stream));
+  hipLaunchKernelGGL(isum_kernel, dim3(256), dim3(256), 0, h->stream, v, n, h->dcount);
+  HIPCK(hipGetLastError());
+  unsigned long long r = 0;
+  HIPCK(hipMemcpyAsync(&r, h->dcount, 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  *out = (int64_t)r;
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int reset) {
+  if (!h || !out) return fail(GLRM_ERR_INVALID, "NULL argument");
+  DeviceGuard dg(h->device);
+  int rc = drain_events(h);
+  if (rc) return rc;
+  memset(out, 0, sizeof *out);
+  out->launches_x = h->launches_x; out->launches_y = h->launches_y;
+  out->ms_x = h->ms_x; out->ms_y = h->ms_y;
+  if ((rc = count_sum(h, h->trials_r, h->ml, &out->trials_x))) return rc;
+  if ((rc = count_sum(h, h->accepts_r, h->ml, &out->accepts_x))) return rc;
+  if ((rc = count_sum(h, h->trials_c, h->nl, &out->trials_y))) return rc;
+  if ((rc = count_sum(h, h->accepts_c, h->nl, &out->accepts_y))) return rc;
+  out->nnz_rows = h->nnz_r; out->nnz_cols = h->nnz_c;
+  out->waves_row = h->waves_row; out->waves_col = h->waves_col; out->ld = h->kp;
+  if (reset) {
+    h->launches_x = h->launches_y = 0;
+    h->ms_x = h->ms_y = 0;
+    const int64_t ml1 = h->ml > 0 ? h->ml : 1, nl1 = h->nl > 0 ? h->nl : 1;
+    HIPCK(hipMemsetAsync(h->trials_r, 0, ml1 * 4, h->stream));
+    HIPCK(hipMemsetAsync(h->accepts_r, 0, ml1 * 4, h->stream));
+    HIPCK(hipMemsetAsync(h->trials_c, 0, nl1 * 4, h->stream));
+    HIPCK(hipMemsetAsync(h->accepts_c, 0, nl1 * 4, h->stream));
+  }
+  return GLRM_OK;
+}
+
+// ------------------------------------------------------------------ whole-fit API
+
+static bool single_shard(const glrm_handle* h) { return h->rb == 0 && h->re == h->m && h->cb == 0 && h->ce == h->n; }
+
+static double now_s() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// loss + rx + ry at the device-resident factors (objective(...), src/evaluate_fit.jl:4-23,91-104)
+static int device_objective(glrm_handle* h, int include_reg, double* out) {
+  int rc;
+  double loss = 0, px = 0, py = 0;
+  if ((rc = run_sweep(h, 1, 0.0, 1))) return rc;
+  if ((rc = glrm_hip_sum(h, h->objcol, h->n, &loss))) return rc;
+  if (include_reg) {
+    if ((rc = run_penalty(h, true))) return rc;
+    if ((rc = glrm_hip_sum(h, h->objrow, h->m, &px))) return rc;
+    if ((rc = run_penalty(h, false))) return rc;
+    if ((rc = glrm_hip_sum(h, h->objcol, h->n, &py))) return rc;
+  }
+  *out = loss + (px + py);
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_objective(glrm_handle* h, const double* X, const double* Y, int include_reg, double* out) {
+  if (!h || !X || !Y || !out) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (!single_shard(h)) return fail(GLRM_ERR_INVALID, "glrm_hip_objective needs a single-shard handle");
+  DeviceGuard dg(h->device);
+  int rc = glrm_hip_set_factors(h, X, Y);
+  if (rc) return rc;
+  return device_objective(h, include_reg, out);
+}
+
+extern "C" int glrm_hip_fit(glrm_handle* h, const glrm_params* prm, double* X, double* Y, double* objective,
+                            double* seconds, int64_t cap, int64_t* n_recorded) {
+  if (!h || !prm || !X || !Y || !objective || !seconds || !n_recorded) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (!single_shard(h)) return fail(GLRM_ERR_INVALID, "glrm_hip_fit needs a single-shard handle (use the step-level API per shard)");
+  if (prm->max_iter < 0 || cap < prm->max_iter + 1) return fail(GLRM_ERR_INVALID, "objective/seconds capacity must be >= max_iter+1");
+  if (prm->inner_iter_X < 1 || prm->inner_iter_Y < 1) return fail(GLRM_ERR_INVALID, "inner iteration counts must be >= 1");
+  double ynorm = 0.0; // norm(Y)==0 guard, proxgrad.jl:45-48 (the reference would hit an UndefVarError)
+  for (int64_t i = 0; i < (int64_t)h->k * h->n; ++i) ynorm += Y[i] * Y[i];
+  if (ynorm == 0.0) return fail(GLRM_ERR_INVALID, "Y is all zeros (the reference cannot start from Y == 0)");
+  DeviceGuard dg(h->device);
+  int rc;
+  if ((rc = glrm_hip_set_factors(h, X, Y))) return rc;                 // X = glrm.X; Y = glrm.Y (:43)
+  if ((rc = glrm_hip_reset_stepsizes(h, prm->stepsize))) return rc;   // :69-70
+  const double scaled_abs_tol = prm->abs_tol * (double)h->nnz_r;       // :72 (observed_features)
+  int64_t nrec = 0;
+  if ((rc = device_objective(h, 1, &objective[0]))) return rc;        // update_ch!(ch, 0, objective(...)) :76
+  seconds[0] = 0.0;
+  nrec = 1;
+  double t = now_s();
+  for (int64_t i = 1; i <= prm->max_iter; ++i) {                       // :107
+    if (prm->inner_iter_X > 1 || prm->inner_iter_Y > 1)
+      if ((rc = glrm_hip_reset_stepsizes(h, prm->stepsize))) return rc; // :112-115
+    for (int64_t in = 0; in < prm->inner_iter_X; ++in)
+      if ((rc = run_sweep(h, 0, prm->min_stepsize, 0))) return rc;    // :117-158
+    for (int64_t in = 0; in < prm->inner_iter_Y; ++in)
+      if ((rc = run_sweep(h, 1, prm->min_stepsize, 0))) return rc;    // :160-203
+    double obj = 0.0;
+    if ((rc = glrm_hip_sum(h, h->objcol, h->n, &obj))) return rc;     // obj = sum(obj_by_col) :205
+    const double dt = now_s() - t;
+    objective[nrec] = obj;
+    seconds[nrec] = seconds[nrec - 1] + dt;                            // update_ch! (src/convergence.jl:22-26)
+    ++nrec;
+    t = now_s();
+    const double dec = objective[nrec - 2] - obj;                      // :210
+    if (i > 10 && (dec < scaled_abs_tol || dec / obj < prm->rel_tol)) break; // :211-213
+  }
+  if ((rc = glrm_hip_get_factors(h, X, Y))) return rc;
+  *n_recorded = nrec;
+  return GLRM_OK;
+}

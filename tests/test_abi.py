@@ -1,0 +1,92 @@
+"""The C-ABI libraries load and export every symbol include/*.h declares (no compute calls on CPU),
+and the product path fails loudly -- never silently falls back -- when no GPU / no library is there."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import lowrankmodels.jl_amd as L
+from lowrankmodels.jl_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "lowrankmodels.jl_amd")
+
+
+def declared(header, prefix):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(" + prefix + r"\w+)\s*\(", txt)))
+
+
+def ensure_built():
+    from lowrankmodels.jl_amd import build
+    build.build_all(verbose=False)
+
+
+def test_hip_library_exports_every_declared_symbol():
+    ensure_built()
+    names = declared("glrm_hip.h", "glrm_hip_")
+    assert len(names) == len(_capi.ABI_SYMBOLS) == 19
+    assert sorted("glrm_hip_" + s for s in _capi.ABI_SYMBOLS) == names
+    lib = ctypes.CDLL(os.path.join(PKG, "libglrm_hip.so"))
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.glrm_hip_version.restype = ctypes.c_int
+    assert lib.glrm_hip_version() == _capi.ABI_VERSION
+
+
+def test_synth_library_exports_every_declared_symbol():
+    ensure_built()
+    lib = ctypes.CDLL(os.path.join(PKG, "libglrm_synth.so"))
+    for n in declared("glrm_synth.h", "glrm_synth_hip_"):
+        assert hasattr(lib, n), n
+
+
+def test_oracle_exports_the_same_entry_points():
+    import oracle as O
+    lib = O.oracle_lib()
+    for s in _capi.ABI_SYMBOLS:
+        assert hasattr(lib, "glrm_cpu_" + s), s
+    for n in declared("glrm_synth.h", "glrm_synth_cpu_"):
+        assert hasattr(lib, n), n
+
+
+def test_struct_layouts_match_the_header():
+    assert ctypes.sizeof(_capi.CLoss) == 32 and ctypes.sizeof(_capi.CReg) == 16
+    assert ctypes.sizeof(_capi.CParams) == 56 and ctypes.sizeof(_capi.COptions) == 24
+    assert ctypes.sizeof(_capi.CProblem) == 8 * 2 + 4 * 2 + 8 * 4 + 8 * 6 + 8 * 6
+    assert ctypes.sizeof(_capi.CKernelStats) == 8 * 2 + 8 * 2 + 8 * 6 + 4 * 4
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_product_path_fails_loudly_without_a_gpu():
+    ensure_built()
+    g = L.GLRM(np.random.default_rng(0).standard_normal((6, 5)), L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), 2)
+    with pytest.raises(_capi.GLRMError) as ei:
+        L.fit_b(g, verbose=False)
+    assert ei.value.code == _capi.ERR_HIP and "no CPU fallback" in ei.value.message
+
+
+def test_product_path_fails_loudly_without_the_library(monkeypatch):
+    monkeypatch.setattr(_capi, "_hip_api", None)
+    monkeypatch.setattr(_capi, "HIP_LIB_PATH", os.path.join(PKG, "does_not_exist.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _capi.hip_api()
+
+
+def test_product_sources_never_reference_the_oracle():
+    """Nothing under the package may import / load / link the oracle (tests, smoke and bench's cpu_baseline only)."""
+    bad = []
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for needle in ("libglrm_oracle", "glrm_oracle.c", "import oracle", "from oracle", "oracle/"):
+                    for line in txt.splitlines():
+                        if needle in line and not line.lstrip().startswith(("#", "//", "*", '"""')) and "oracle/" != needle:
+                            bad.append((f, line.strip()))
+                if re.search(r"CDLL\([^)]*oracle", txt):
+                    bad.append((f, "CDLL(oracle)"))
+    assert not bad, bad

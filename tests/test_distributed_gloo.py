@@ -1,0 +1,71 @@
+"""N>1 path on CPU: world_size-2 gloo run of the sharded fit (rows for the X half-step, columns for the Y
+half-step, all-gather of the updated factor between half-steps) equals the single-process fit bit for bit
+(SURVEY.md section 8(e) determinism contract)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+import lowrankmodels.jl_amd as L
+import oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run_world(tmp_path, names, nproc=2, env_extra=None):
+    out = str(tmp_path / "dist")
+    env = dict(os.environ, OMP_NUM_THREADS="1", **(env_extra or {}))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.join(HERE, "_dist_worker.py"), out] + names
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return [np.load(f"{out}.rank{i}.npz") for i in range(nproc)]
+
+
+def test_partition_balances_nnz():
+    ptr = np.concatenate([[0], np.cumsum([10] * 50 + [1000] * 2 + [10] * 48)])
+    b = L.partition(ptr, 4)
+    assert b[0] == 0 and b[-1] == 100 and all(b[i] <= b[i + 1] for i in range(4))
+    loads = [ptr[b[i + 1]] - ptr[b[i]] for i in range(4)]
+    assert max(loads) <= 1000 + ptr[-1] / 4
+    assert L.partition(np.arange(0, 101, 1) * 7, 4) == [0, 25, 50, 75, 100]  # uniform -> equal-count blocks
+    assert L.partition(np.zeros(11, dtype=np.int64), 2) == [0, 5, 10]
+
+
+@pytest.mark.parametrize("mode", ["auto", "allgather"])
+def test_two_ranks_equal_one_rank(tmp_path, mode):
+    names = ["c1", "mixed", "kmeans"]
+    ranks = run_world(tmp_path, names, 2, {"GLRM_GATHER": mode})
+    O.set_threads(1)
+    for name in names:
+        kwargs, params = cases.build_golden_case(name)
+        g = L.GLRM(**kwargs)
+        X, Y, ch = L.fit_b(g, params, verbose=False, engine=O.oracle_api())
+        for z in ranks:  # every rank ends with the full replicated factors
+            assert np.array_equal(z[name + "_X"], X), name
+            assert np.array_equal(z[name + "_Y"], Y), name
+            o = z[name + "_obj"]
+            assert len(o) == len(ch.objective)
+            assert np.array_equal(o[1:], np.array(ch.objective[1:])), name  # fixed-order sum of gathered columns
+            assert cases.rel_err(o[:1], ch.objective[:1]) < 1e-12  # initial objective: column-blocked vs one accumulator
+
+
+def test_three_ranks_ragged_blocks(tmp_path):
+    """m, n not divisible by the world size -> ragged blocks -> one broadcast per owner."""
+    ranks = run_world(tmp_path, ["nnmf"], 3)
+    kwargs, params = cases.build_golden_case("nnmf")
+    g = L.GLRM(**kwargs)
+    X, Y, ch = L.fit_b(g, params, verbose=False, engine=O.oracle_api())
+    for z in ranks:
+        assert np.array_equal(z["nnmf_X"], X) and np.array_equal(z["nnmf_Y"], Y)
+        assert np.array_equal(z["nnmf_obj"][1:], np.array(ch.objective[1:]))

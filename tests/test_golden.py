@@ -1,0 +1,121 @@
+"""CPU: the oracle reproduces the committed golden fixtures (inputs are read from the fixtures), is
+independent of its thread count, and satisfies the invariants the reference algorithm guarantees by
+construction (tier iii)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import lowrankmodels.jl_amd as L
+import oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("name", list(cases.GOLDEN_CASES))
+def test_oracle_reproduces_golden(name):
+    pa, X0, Y0, params, z = cases.load_case(os.path.join(GOLDEN, name + ".npz"))
+    O.set_threads(1)
+    obj, X, Y, st = cases.run_engine(O.oracle_api(), pa, X0, Y0, params)
+    assert len(obj) == len(z["objective"])
+    # same binary + same libm => bit-identical; a different libm (exp/log in Logistic) may move the last ulps
+    assert cases.rel_err(obj, z["objective"]) < 1e-9
+    assert cases.fro_err(X, z["X"]) < 1e-9 and cases.fro_err(Y, z["Y"]) < 1e-9
+    assert [st["trials_x"], st["trials_y"]] == list(z["trials"]) and [st["accepts_x"], st["accepts_y"]] == list(z["accepts"])
+
+
+@pytest.mark.parametrize("name", ["c1", "mixed"])
+def test_oracle_thread_count_invariant(name):
+    """rows (then columns) are independent: proxgrad_multithread.jl:118,163 -- any thread count gives the same bits."""
+    pa, X0, Y0, params, z = cases.load_case(os.path.join(GOLDEN, name + ".npz"))
+    O.set_threads(1)
+    o1, X1, Y1, _ = cases.run_engine(O.oracle_api(), pa, X0, Y0, params)
+    O.set_threads(4)
+    o4, X4, Y4, _ = cases.run_engine(O.oracle_api(), pa, X0, Y0, params)
+    O.set_threads(1)
+    assert np.array_equal(o1, o4) and np.array_equal(X1, X4) and np.array_equal(Y1, Y4)
+
+
+def test_golden_case_builders_match_fixture_inputs():
+    """The generating script and the stored inputs agree (guards against editing one without the other)."""
+    for name in cases.GOLDEN_CASES:
+        kwargs, params = cases.build_golden_case(name)
+        pa = L.GLRM(**kwargs).problem_arrays()
+        fa, X0, Y0, fparams, _ = cases.load_case(os.path.join(GOLDEN, name + ".npz"))
+        for f in ("rowptr", "colidx", "rowvals", "colptr", "rowidx", "colvals"):
+            assert np.array_equal(getattr(pa, f), getattr(fa, f)), (name, f)
+        assert pa.losses.tobytes() == fa.losses.tobytes() and pa.rx.tobytes() == fa.rx.tobytes()
+        assert np.array_equal(kwargs["X"], X0) and repr(params) == repr(fparams)
+
+
+def test_dense_faithful_mode_is_the_same_arithmetic():
+    """The reference's Theta(mnk) cost model (dense XY, full-row / full-column objectives) produces the very
+    same numbers as the observed-only evaluation."""
+    pa, X0, Y0, params, z = cases.load_case(os.path.join(GOLDEN, "nnmf.npz"))
+    api, lib = O.oracle_api(), O.oracle_lib()
+    h = api.create(pa)
+    try:
+        assert lib.glrm_cpu_set_dense_faithful(h, 1) == 0
+        X, Y = np.array(X0, order="F"), np.array(Y0, order="F")
+        obj, _ = api.fit(h, params, X, Y)
+    finally:
+        api.destroy(h)
+    assert np.array_equal(obj, z["objective"]) and np.array_equal(X, z["X"]) and np.array_equal(Y, z["Y"])
+
+
+def test_exact_rank_pca_reaches_frobenius_error():
+    """test/basic_functionality.jl:5-16: ||A - X'Y||^2 equals ch.objective[end] for exact-rank data / ZeroReg."""
+    rng = np.random.default_rng(1)
+    m, n, k = 100, 100, 5
+    A = rng.standard_normal((m, k)) @ rng.standard_normal((k, n))
+    g = L.GLRM(A, [L.QuadLoss() for _ in range(n)], L.ZeroReg(), L.ZeroReg(), 5, X=rng.standard_normal((k, m)),
+               Y=rng.standard_normal((k, n)))
+    p = L.Params(1, max_iter=200, abs_tol=0.0000001, min_stepsize=0.001)
+    X, Y, ch = L.fit_b(g, p, verbose=False, engine=O.oracle_api())
+    assert p.abs_tol > abs(np.linalg.norm(A - X.T @ Y) ** 2 - ch.objective[-1])
+    assert ch.objective[-1] < ch.objective[0]  # test/share_test.jl:23
+    assert L.objective(g, engine=O.oracle_api()) == pytest.approx(ch.objective[-1], rel=1e-12)
+
+
+def test_kmeans_separates_two_gaussians():
+    """test/runtests.jl:19-25 (KMeans = UnitOneSparse rx, ZeroReg ry, inner_iter=10): clusters of 100 and 50."""
+    rng = np.random.default_rng(21)
+    A = np.vstack([rng.standard_normal((100, 2)) + 5.0, rng.standard_normal((50, 2)) - 10.0])
+    k = 2
+    Y0 = np.asfortranarray(A[[0, 120]].T.copy())  # one seed point per blob (the reference uses init_kmeanspp!)
+    g = L.GLRM(A, L.QuadLoss(), L.UnitOneSparseConstraint(), L.ZeroReg(), k, X=rng.standard_normal((k, 150)), Y=Y0.T.copy().T)
+    X, Y, ch = L.fit_b(g, L.ProxGradParams(inner_iter=10), verbose=False, engine=O.oracle_api())
+    assert set(X.sum(axis=1).astype(int).tolist()) == {100, 50}
+
+
+def test_line_search_invariants():
+    """alpha in {base x1.05^p x0.7^q}, base in {stepsize, 1.1*min}; accepted column steps never increase the column objective;
+    ch.objective has iterations+1 entries."""
+    pa, X0, Y0, params, z = cases.load_case(os.path.join(GOLDEN, "nnmf.npz"))
+    api, lib = O.oracle_api(), O.oracle_lib()
+    h = api.create(pa)
+    try:
+        api.set_factors(h, X0, Y0)
+        api.reset_stepsizes(h, params.stepsize)
+        objcol = np.zeros(pa.n)
+        api.bind_buffers(h, None, None, objcol, None)
+        prev_cols = None
+        for it in range(8):
+            api.step_x(h, params.min_stepsize)
+            api.col_losses(h)
+            loss_before = objcol.copy()
+            api.col_penalties(h)
+            before = loss_before + objcol
+            api.step_y(h, params.min_stepsize)
+            after = objcol.copy()
+            assert np.all(after <= before * (1 + 1e-12) + 1e-12) or np.isinf(before).any()
+            ar, ac = np.zeros(pa.m), np.zeros(pa.n)
+            lib.glrm_cpu_get_stepsizes(h, ar.ctypes.data, ac.ctypes.data)
+            for a in np.concatenate([ar, ac]):
+                # alpha = base * 1.05^p * 0.7^q with base the initial step or the collapsed 1.1*min_stepsize
+                ok = any(abs(a - b * 1.05 ** p * 0.7 ** q) < 1e-12 * a for b in (params.stepsize, 1.1 * params.min_stepsize)
+                         for p in range(0, 2 * it + 3) for q in range(0, 14))
+                assert ok and a > params.min_stepsize, a
+    finally:
+        api.destroy(h)

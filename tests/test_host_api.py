@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference interface: GLRM construction, Omega bookkeeping (bit-exact),
+params, fit!/fit semantics.  The engine used here is the CPU oracle (test hook); the HIP engine runs
+the same host code in the -m gpu tests."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import lowrankmodels.jl_amd as L
+import oracle as O
+
+
+def test_params_defaults_and_inner_iter_merge():
+    p = L.ProxGradParams()
+    assert (p.stepsize, p.max_iter, p.inner_iter_X, p.inner_iter_Y) == (1.0, 100, 1, 1)
+    assert (p.abs_tol, p.rel_tol, p.min_stepsize) == (1e-5, 1e-4, 0.01)
+    p = L.ProxGradParams(2, inner_iter=10, inner_iter_X=3)
+    assert (p.inner_iter_X, p.inner_iter_Y, p.min_stepsize) == (10, 10, 0.02)  # max-merge, 0.01*stepsize
+    assert isinstance(L.Params(1, max_iter=7), L.ProxGradParams) and L.Params(1, max_iter=7).max_iter == 7
+    assert isinstance(L.HipProxGradParams(), L.AbstractParams)
+
+
+def test_constructor_dimension_checks():
+    A = np.zeros((4, 3))
+    with pytest.raises(ValueError, match="as many losses"):
+        L.GLRM(A, [L.QuadLoss()] * 2, L.ZeroReg(), L.ZeroReg(), 2)
+    with pytest.raises(ValueError, match="X regularizer"):
+        L.GLRM(A, L.QuadLoss(), [L.ZeroReg()] * 3, L.ZeroReg(), 2)
+    with pytest.raises(ValueError, match="Y regularizer"):
+        L.GLRM(A, L.QuadLoss(), L.ZeroReg(), [L.ZeroReg()] * 4, 2)
+    with pytest.raises(ValueError, match="X must be of size"):
+        L.GLRM(A, L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), 2, X=np.zeros((3, 3)))
+    with pytest.raises(ValueError, match="Y must be of size"):
+        L.GLRM(A, L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), 2, Y=np.zeros((2, 4)))
+    g = L.GLRM(A, L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), 2, X=np.ones((4, 2)))  # m x k is transposed (glrm.jl:57-60)
+    assert g.X.shape == (2, 4)
+    An = A.copy()
+    An[1, 2] = np.nan
+    with pytest.raises(ValueError, match=r"Observed value in entry \(1, 2\) is NaN"):
+        L.GLRM(An, L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), 2)
+    L.GLRM(An, L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), 2, obs=[(0, 0), (1, 1)])  # unobserved NaN is fine
+    with pytest.raises(ValueError, match="not a Bool"):
+        L.GLRM(np.full((4, 3), 2.0), L.LogisticLoss(), L.ZeroReg(), L.ZeroReg(), 2)
+
+
+def test_sort_observations_keeps_order_and_duplicates():
+    # src/modify_glrm.jl:5-18: push! in obs order, duplicates retained (test/hello_world.jl:48 samples with replacement)
+    obs = [(2, 1), (0, 1), (2, 0), (2, 1), (1, 1), (0, 0)]
+    rowptr, colidx, colptr, rowidx = L.sort_observations(obs, 3, 2)
+    feats = [list(colidx[rowptr[e]:rowptr[e + 1]]) for e in range(3)]
+    exs = [list(rowidx[colptr[f]:colptr[f + 1]]) for f in range(2)]
+    assert feats == [[1, 0], [1], [1, 0, 1]]
+    assert exs == [[2, 0], [2, 0, 2, 1]]
+    I, J = np.array([o[0] for o in obs]), np.array([o[1] for o in obs])
+    r2 = L.sort_observations((I, J), 3, 2)
+    for a, b in zip((rowptr, colidx, colptr, rowidx), r2):
+        np.testing.assert_array_equal(a, b)
+    with pytest.raises(ValueError):
+        L.sort_observations([(0, 0)], 2, 2, check_empty=True)
+
+
+def test_sparse_pattern_bookkeeping():
+    """test/sparse_test.jl:21-46: the observed sets are exactly the nonzero pattern."""
+    rng = np.random.default_rng(0)
+    m, n, k = 100, 100, 3
+    A = sp.random(m, n, density=0.5, random_state=rng, format="csc")
+    g = L.GLRM(A, L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), k)
+    assert len(g.observed_features) == m and len(g.observed_examples) == n
+    D = A.toarray()
+    for i in range(m):
+        of = set(g.observed_features[i].tolist())
+        for j in range(n):
+            assert (j in of) == (D[i, j] != 0.0)
+    for j in range(n):
+        oe = set(g.observed_examples[j].tolist())
+        for i in range(m):
+            assert (i in oe) == (D[i, j] != 0.0)
+    # findall is column-major => both lists ascending (src/glrm.jl:46-48)
+    assert all(np.all(np.diff(f) > 0) for f in g.observed_features)
+    assert all(np.all(np.diff(e) > 0) for e in g.observed_examples)
+    # values gathered at the observed entries, both views
+    pa = g.problem_arrays()
+    rows = np.repeat(np.arange(m), np.diff(pa.rowptr))
+    np.testing.assert_array_equal(pa.rowvals, D[rows, pa.colidx])
+    cols = np.repeat(np.arange(n), np.diff(pa.colptr))
+    np.testing.assert_array_equal(pa.colvals, D[pa.rowidx, cols])
+
+
+def test_default_is_fully_observed_and_singletons_broadcast():
+    A = np.arange(12.0).reshape(4, 3)
+    g = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.1), 2)
+    assert [list(f) for f in g.observed_features] == [[0, 1, 2]] * 4
+    assert [list(e) for e in g.observed_examples] == [[0, 1, 2, 3]] * 3
+    assert len(g.losses) == 3 and len(g.rx) == 4 and len(g.ry) == 3
+    pa = g.problem_arrays()
+    assert len(pa.losses) == 1 and len(pa.rx) == 1 and len(pa.ry) == 1  # homogeneous lists collapse in the ABI
+    g2 = L.GLRM(A, [L.QuadLoss(), L.HuberLoss(), L.QuadLoss()], [L.QuadReg(), L.OneReg(5), L.NonNegConstraint(), L.QuadReg()],
+                L.QuadReg(), 2)
+    pb = g2.problem_arrays(rows=(1, 3), cols=(0, 2))
+    assert len(pb.losses) == 3 and len(pb.rx) == 2 and len(pb.ry) == 1
+    assert pb.rowptr[0] == 0 and pb.rowptr[-1] == 6 and pb.colptr[-1] == 8
+
+
+def test_bool_label_coercion():
+    A = np.array([[1, 0, -1], [True, False, True]], dtype=object)
+    g = L.GLRM(A, L.LogisticLoss(), L.ZeroReg(), L.ZeroReg(), 1)
+    np.testing.assert_array_equal(g.problem_arrays().rowvals, [1, 0, 0, 1, 0, 1])
+
+
+def test_fit_inplace_warm_start_and_shared_history(capsys):
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((40, 3)) @ rng.standard_normal((3, 30))
+    g = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.1), 3, rng=rng)
+    eng = O.oracle_api()
+    X, Y, ch = L.fit_b(g, L.ProxGradParams(max_iter=20), engine=eng)
+    out = capsys.readouterr().out.splitlines()
+    assert out[0] == "Fitting GLRM" and out[1].startswith("Iteration 10: objective value = ")
+    assert X is g.X and Y is g.Y  # mutated in place, returned by reference (proxgrad.jl:219)
+    assert len(ch.objective) == len(ch.times) == 21 and ch.times[0] == 0 and np.all(np.diff(ch.times) >= 0)
+    # a second call continues from the current estimate and appends to the same history (cross_validate.jl:174)
+    n0, last = len(ch.objective), ch.objective[-1]
+    L.fit_b(g, L.ProxGradParams(max_iter=5), ch=ch, verbose=False, engine=eng)
+    assert len(ch.objective) == n0 + 6
+    assert ch.objective[-1] < last
+    # non-mutating fit returns X' and restores the estimate (src/fit.jl:24-31)
+    Xb, Yb = g.X.copy(), g.Y.copy()
+    Xt, Y2, _ = L.fit(g, L.ProxGradParams(max_iter=3), verbose=False, engine=eng)
+    assert Xt.shape == (40, 3) and np.array_equal(g.X, Xb) and np.array_equal(g.Y, Yb)
+    assert not np.array_equal(Xt.T, Xb)
+
+
+def test_engine_error_codes():
+    from lowrankmodels.jl_amd import _capi
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal((6, 5))
+    g = L.GLRM(A, L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), 2, rng=rng)
+    eng = O.oracle_api()
+    g.Y[...] = 0
+    with pytest.raises(ValueError, match="all zeros"):
+        L.fit_b(g, engine=eng, verbose=False)
+    pa = g.problem_arrays()
+    pa.rowvals = pa.rowvals.copy()
+    pa.rowvals[3] = np.nan
+    with pytest.raises(_capi.GLRMError) as ei:
+        eng.create(pa)
+    assert ei.value.code == _capi.ERR_NONFINITE and "is NaN" in ei.value.message
+    pa = g.problem_arrays()
+    pa.losses = pa.losses.copy()
+    pa.losses["kind"] = 42
+    with pytest.raises(_capi.GLRMError) as ei:
+        eng.create(pa)
+    assert ei.value.code == _capi.ERR_UNSUPPORTED
+    pa = g.problem_arrays()
+    pa.colidx = pa.colidx.copy()
+    pa.colidx[0] = 99
+    with pytest.raises(_capi.GLRMError) as ei:
+        eng.create(pa)
+    assert ei.value.code == _capi.ERR_INVALID

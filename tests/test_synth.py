@@ -1,0 +1,40 @@
+"""CPU generator of the synthetic workloads (include/glrm_synth.h): Omega is stratified (sorted, unique, q per
+row), the CSR and CSC views describe the same set with the same values, shards concatenate to the whole."""
+import numpy as np
+
+import oracle as O
+
+
+def test_stratified_omega_and_views_agree():
+    m, n, k, q = 300, 120, 4, 12
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, q, seed=5, loss_mix=1)
+    assert np.array_equal(rowptr, np.arange(m + 1) * q)
+    S = n // q
+    ci = colidx.reshape(m, q)
+    assert np.all(np.diff(ci, axis=1) > 0) and np.all(ci // S == np.arange(q))  # one per stratum, sorted, unique
+    assert colptr[-1] == m * q
+    rows_of_csr = np.repeat(np.arange(m), q)
+    a = set(zip(rows_of_csr.tolist(), colidx.tolist()))
+    cols_of_csc = np.repeat(np.arange(n), np.diff(colptr))
+    b = set(zip(rowidx.tolist(), cols_of_csc.tolist()))
+    assert a == b and len(a) == m * q
+    for f in range(n):
+        assert np.all(np.diff(rowidx[colptr[f]:colptr[f + 1]]) > 0)  # ascending rows (findall order)
+    va = dict(zip(zip(rows_of_csr.tolist(), colidx.tolist()), rowvals.tolist()))
+    vb = dict(zip(zip(rowidx.tolist(), cols_of_csc.tolist()), colvals.tolist()))
+    assert va == vb
+    # loss_mix: f%3==1 -> labels in {0,1}; f%3==2 -> ordinal levels 1..5
+    kinds = cols_of_csc % 3
+    assert set(np.unique(colvals[kinds == 1]).tolist()) <= {0.0, 1.0}
+    assert set(np.unique(colvals[kinds == 2]).tolist()) <= {1.0, 2.0, 3.0, 4.0, 5.0}
+    assert abs(X0.std() - 1) < 0.1 and abs(Y0.std() - 1) < 0.15
+
+
+def test_shards_concatenate_to_the_whole():
+    m, n, k, q = 200, 60, 3, 6
+    full = O.synth_cpu(m, n, k, q, seed=9)
+    a = O.synth_cpu(m, n, k, q, seed=9, rows=(0, 80), cols=(0, 25))
+    b = O.synth_cpu(m, n, k, q, seed=9, rows=(80, 200), cols=(25, 60))
+    assert np.array_equal(np.concatenate([a[1], b[1]]), full[1]) and np.array_equal(np.concatenate([a[2], b[2]]), full[2])
+    assert np.array_equal(np.concatenate([a[4], b[4]]), full[4]) and np.array_equal(np.concatenate([a[5], b[5]]), full[5])
+    assert np.array_equal(np.concatenate([a[3], a[3][-1] + b[3][1:]]), full[3])
