@@ -136,7 +136,10 @@ class ShardedFit:
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.api, self.group = torch, dist, api, group
-        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        if dist.is_available() and dist.is_initialized():
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        else:  # single process: the gathers below are no-ops
+            self.rank, self.world = 0, 1
         self.row_bounds, self.col_bounds = list(row_bounds), list(col_bounds)
         self.m, self.n, self.k = prob.m, prob.n, prob.k
         self.device = device if device is not None else torch.device("cpu")
@@ -149,7 +152,7 @@ class ShardedFit:
         self.dX, self.dY, self.dObjCol, self.dObjRow = z(self.m * self.ld), z(self.n * self.ld), z(self.n), z(self.m)
         api.bind_buffers(self.h, self.dX.data_ptr(), self.dY.data_ptr(), self.dObjCol.data_ptr(), self.dObjRow.data_ptr())
         mode = os.environ.get("GLRM_GATHER", "auto")
-        self._inplace_ok = mode != "broadcast" and (mode == "allgather" or dist.get_backend(group) == "nccl")
+        self._inplace_ok = self.world > 1 and mode != "broadcast" and (mode == "allgather" or dist.get_backend(group) == "nccl")
 
     def close(self):
         if self.h is not None:
@@ -160,6 +163,8 @@ class ShardedFit:
         """Make ``buf`` (global length) identical on every rank: rank r contributed
         buf[bounds[r]*unit : bounds[r+1]*unit].  Equal blocks -> one in-place all-gather (each GPU
         pushes its 1/G slice to its peers); ragged blocks -> one broadcast per owner."""
+        if self.world == 1:
+            return
         dist, sizes = self.dist, [(bounds[r + 1] - bounds[r]) * unit for r in range(self.world)]
         if self._inplace_ok and len(set(sizes)) == 1 and sizes[0] > 0:
             own = buf[bounds[self.rank] * unit: bounds[self.rank + 1] * unit]

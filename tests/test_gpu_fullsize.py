@@ -1,0 +1,125 @@
+"""-m gpu: device generator vs CPU generator, and the BASELINE single-GPU configuration (C2: 1M x 10k, rank 32,
+5 % observed, QuadReg) checked through size-independent properties and an oracle spot check on sampled rows /
+columns (the oracle cannot run 5e8 observations in seconds; it can run the sampled segments exactly)."""
+import numpy as np
+import pytest
+
+import lowrankmodels.jl_amd as L
+import oracle as O
+from lowrankmodels.jl_amd import _capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_generator_matches_cpu_generator():
+    import torch
+    m, n, k, q = 3000, 240, 8, 24
+    for mix, vm in ((0, 0), (1, 0), (0, 1)):
+        w = synth.DeviceWorkload(m, n, k, q, rows=(100, 2500), cols=(30, 200), seed=77, loss_mix=mix, value_model=vm)
+        c = O.synth_cpu(m, n, k, q, seed=77, loss_mix=mix, value_model=vm, rows=(100, 2500), cols=(30, 200))
+        assert np.array_equal(w.rowptr.cpu().numpy(), c[0]) and np.array_equal(w.colidx.cpu().numpy()[:w.nnz_rows], c[1])
+        assert np.array_equal(w.colptr.cpu().numpy(), c[3]) and np.array_equal(w.rowidx.cpu().numpy()[:w.nnz_cols], c[4])
+        rv, cv = w.rowvals.cpu().numpy()[:w.nnz_rows], w.colvals.cpu().numpy()[:w.nnz_cols]
+        if mix == 0:  # integer hash -> uniform, fma chain: bit-identical on host and device
+            assert np.array_equal(rv, c[2]) and np.array_equal(cv, c[5])
+        else:  # labels go through exp(): a label may flip when the uniform draw sits within an ulp of the sigmoid
+            assert np.mean(rv != c[2]) < 1e-4 and np.mean(cv != c[5]) < 1e-4
+    X, Y = w.init_factors(8)
+    X0, Y0 = c[6], c[7]
+    np.testing.assert_allclose(X.cpu().numpy().reshape(m, 8).T, X0, rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(Y.cpu().numpy().reshape(n, 8).T, Y0, rtol=1e-12, atol=1e-14)
+
+
+@pytest.mark.parametrize("scale", [1])
+def test_c2_full_size_properties(scale):
+    """BASELINE configs[1] at full size.  Properties: (1) the recorded objective decreases monotonically after the
+    first iterations and equals an independent re-evaluation of sum(loss)+ry; (2) two runs are bit-identical;
+    (3) one X half-step and one Y half-step on sampled rows / columns agree with the oracle run on exactly
+    those segments (same Omega, same values, same opposing factor) to 1e-9."""
+    import torch
+    m, n, k, q = 1_000_000 // scale, 10_000, 32, 500
+    api = _capi.hip_api()
+    w = synth.DeviceWorkload(m, n, k, q)
+    assert w.nnz_rows == w.nnz_cols == m * q
+    h = api.create(w.problem(), stream=torch.cuda.current_stream().cuda_stream)
+    ld = api.factor_ld(h)
+    assert ld == 32
+    st = api.kernel_stats(h)
+    assert st["waves_row"] == 1 and st["waves_col"] == 4
+    dX, dY = w.init_factors(ld)
+    dC, dR = torch.zeros(n, dtype=torch.float64, device=dX.device), torch.zeros(m, dtype=torch.float64, device=dX.device)
+    api.bind_buffers(h, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())
+    X_init, Y_init = dX.clone(), dY.clone()
+    p = L.ProxGradParams()
+
+    def run(iters):
+        dX.copy_(X_init); dY.copy_(Y_init)
+        api.reset_stepsizes(h, p.stepsize)
+        objs = []
+        for _ in range(iters):
+            api.step_x(h, p.min_stepsize)
+            api.step_y(h, p.min_stepsize)
+            objs.append(api.sum(h, dC.data_ptr(), n))
+        return objs, dX.clone(), dY.clone()
+
+    # (3) spot check of the first half-steps against the oracle on sampled segments
+    rows = np.array([0, 1, 17, 4242, 500_000 // scale, m - 1])
+    Yh = Y_init.cpu().numpy().reshape(n, ld)[:, :k]
+    Xh_rows = X_init.cpu().numpy().reshape(m, ld)[rows, :k]
+    rp = w.rowptr.cpu().numpy()
+    api.reset_stepsizes(h, p.stepsize)
+    api.step_x(h, p.min_stepsize)
+    X_after = dX.cpu().numpy().reshape(m, ld)
+    one = np.array([synth.QUAD], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 1.0)], dtype=_capi.REG_DTYPE)
+    oapi = O.oracle_api()
+    for i, e in enumerate(rows):
+        ci = w.colidx[rp[e]:rp[e + 1]].cpu().numpy()
+        va = w.rowvals[rp[e]:rp[e + 1]].cpu().numpy()
+        pa = _capi.ProblemArrays(1, n, k, np.array([0, len(ci)], dtype=np.int64), ci, va, np.zeros(n + 1, dtype=np.int64),
+                                 np.zeros(0, np.int32), np.zeros(0), one, reg, reg)
+        ho = oapi.create(pa)
+        oapi.set_factors(ho, np.asfortranarray(Xh_rows[i:i + 1].T), np.asfortranarray(Yh.T))
+        oapi.reset_stepsizes(ho, p.stepsize)
+        oapi.step_x(ho, p.min_stepsize)
+        xo, yo = np.zeros((k, 1), order="F"), np.zeros((k, n), order="F")
+        oapi.get_factors(ho, xo, yo)
+        oapi.destroy(ho)
+        np.testing.assert_allclose(X_after[e, :k], xo[:, 0], rtol=1e-9, atol=1e-12)
+    cols = np.array([0, 3, 5000, n - 1])
+    cp = w.colptr.cpu().numpy()
+    X_full = X_after[:, :k]
+    api.step_y(h, p.min_stepsize)
+    Y_after = dY.cpu().numpy().reshape(n, ld)
+    objc = dC.cpu().numpy()
+    for f in cols:
+        ri = w.rowidx[cp[f]:cp[f + 1]].cpu().numpy()
+        va = w.colvals[cp[f]:cp[f + 1]].cpu().numpy()
+        assert np.all(np.diff(ri) > 0)
+        pa = _capi.ProblemArrays(m, 1, k, np.zeros(m + 1, dtype=np.int64), np.zeros(0, np.int32), np.zeros(0),
+                                 np.array([0, len(ri)], dtype=np.int64), ri, va, one, reg, reg)
+        ho = oapi.create(pa)
+        oc = np.zeros(1)
+        oapi.bind_buffers(ho, None, None, oc, None)
+        oapi.set_factors(ho, np.asfortranarray(X_full.T), np.asfortranarray(Yh[f:f + 1].T))
+        oapi.reset_stepsizes(ho, p.stepsize)
+        oapi.step_y(ho, p.min_stepsize)
+        xo, yo = np.zeros((k, m), order="F"), np.zeros((k, 1), order="F")
+        oapi.get_factors(ho, xo, yo)
+        oapi.destroy(ho)
+        np.testing.assert_allclose(Y_after[f, :k], yo[:, 0], rtol=1e-9, atol=1e-12)
+        assert objc[f] == pytest.approx(oc[0], rel=1e-9)
+
+    # (1) + (2)
+    o1, X1, Y1 = run(6)
+    o2, X2, Y2 = run(6)
+    assert o1 == o2 and torch.equal(X1, X2) and torch.equal(Y1, Y2)
+    assert all(o1[i + 1] < o1[i] for i in range(1, 5)), o1
+    api.col_losses(h)
+    loss = api.sum(h, dC.data_ptr(), n)
+    api.col_penalties(h)
+    pen = api.sum(h, dC.data_ptr(), n)
+    assert loss + pen == pytest.approx(o1[-1], rel=1e-10)
+    st = api.kernel_stats(h)
+    assert st["nnz_rows"] == m * q and st["trials_x"] >= st["accepts_x"] > 0
+    api.destroy(h)

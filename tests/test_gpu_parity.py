@@ -1,0 +1,267 @@
+"""-m gpu: the HIP engine (through the C ABI) against the CPU oracle on the same seeded inputs, against the
+committed golden fixtures, and -- at full BASELINE size -- through size-independent properties.
+
+Tolerance (north star): 1e-5 relative on the objective trajectory and on the factors (Frobenius-relative);
+index / observation bookkeeping bit-exact.  In practice the fp64 engine agrees to ~1e-12 because the
+per-entry arithmetic is the same expression tree and only the summation order differs.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import lowrankmodels.jl_amd as L
+import oracle as O
+from lowrankmodels.jl_amd import _capi
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def hip():
+    return _capi.hip_api()
+
+
+def compare(pa, X0, Y0, params, tol=TOL, **create_kw):
+    O.set_threads(4)
+    o_c, X_c, Y_c, st_c = cases.run_engine(O.oracle_api(), pa, X0, Y0, params)
+    o_g, X_g, Y_g, st_g = cases.run_engine(hip(), pa, X0, Y0, params, **create_kw)
+    assert len(o_g) == len(o_c), (len(o_g), len(o_c))
+    e_obj, e_x, e_y = cases.rel_err(o_g, o_c), cases.fro_err(X_g, X_c), cases.fro_err(Y_g, Y_c)
+    assert e_obj < tol and e_x < tol and e_y < tol, (e_obj, e_x, e_y)
+    # accept / reject agreement (branch-fragile strict `<`): totals must match closely
+    for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
+        assert abs(st_g[key] - st_c[key]) <= max(2, 0.002 * st_c[key]), (key, st_g[key], st_c[key])
+    assert st_g["nnz_rows"] == st_c["nnz_rows"] and st_g["nnz_cols"] == st_c["nnz_cols"]
+    return e_obj, e_x, e_y
+
+
+@pytest.mark.parametrize("name", list(cases.GOLDEN_CASES))
+def test_golden_fixtures(name):
+    pa, X0, Y0, params, z = cases.load_case(os.path.join(GOLDEN, name + ".npz"))
+    obj, X, Y, st = cases.run_engine(hip(), pa, X0, Y0, params)
+    assert len(obj) == len(z["objective"])
+    assert cases.rel_err(obj, z["objective"]) < TOL
+    assert cases.fro_err(X, z["X"]) < TOL and cases.fro_err(Y, z["Y"]) < TOL
+    compare(pa, X0, Y0, params)
+
+
+def random_problem(rng, m, n, k, density, losses=None, rx=None, ry=None, dup=False):
+    losses = L.QuadLoss() if losses is None else losses
+    rx = L.QuadReg(0.1) if rx is None else rx
+    ry = L.QuadReg(0.1) if ry is None else ry
+    Z = rng.standard_normal((m, k)) @ rng.standard_normal((k, n)) / np.sqrt(k)
+    A = Z + 0.1 * rng.standard_normal((m, n))
+    if density >= 1.0:
+        obs = None
+    else:
+        I, J = np.nonzero(rng.random((m, n)) < density)
+        if dup:
+            extra = rng.integers(0, len(I), len(I) // 10)
+            I, J = np.concatenate([I, I[extra]]), np.concatenate([J, J[extra]])
+            perm = rng.permutation(len(I))
+            I, J = I[perm], J[perm]
+        obs = (I, J)
+    X0, Y0 = rng.standard_normal((k, m)), rng.standard_normal((k, n))
+    g = L.GLRM(A, losses, rx, ry, k, obs=obs, X=X0, Y=Y0)
+    return g.problem_arrays(), np.asfortranarray(X0), np.asfortranarray(Y0)
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 8, 9, 16, 31, 32, 33, 64, 100, 128])
+def test_every_rank_layout(k):
+    """k <= 8 / 16 / 32 / 64 / 128 select the (G,R) lane layouts; non-multiples exercise the zero padding."""
+    rng = np.random.default_rng(100 + k)
+    pa, X0, Y0 = random_problem(rng, 150, 90, k, 0.4)
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=12))
+
+
+@pytest.mark.parametrize("wr,wc", [(1, 1), (4, 4), (8, 8), (1, 8), (4, 1)])
+def test_waves_per_segment_variants(wr, wc):
+    """1 / 4 / 8 wavefronts per row or column (cross-wave LDS combine) give the same trajectory."""
+    rng = np.random.default_rng(7)
+    pa, X0, Y0 = random_problem(rng, 400, 60, 32, 0.5, rx=L.NonNegConstraint(), ry=L.NonNegConstraint())
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=15), waves_row=wr, waves_col=wc)
+
+
+def test_auto_wave_selection_long_columns():
+    rng = np.random.default_rng(8)
+    pa, X0, Y0 = random_problem(rng, 6000, 12, 16, 0.6)  # ~3600 obs per column -> 4 waves per column
+    h = hip().create(pa)
+    st = hip().kernel_stats(h)
+    hip().destroy(h)
+    assert st["waves_col"] == 4 and st["waves_row"] == 1 and st["ld"] == 16
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=10))
+
+
+LOSS_CASES = {
+    "l1": L.L1Loss(1.3), "huber": L.HuberLoss(0.9, crossover=0.6), "quantile": L.QuantileLoss(1.1, quantile=0.3),
+    "periodic": L.PeriodicLoss(2.5, 0.8), "quad_scaled": L.QuadLoss(2.5),
+}
+
+
+@pytest.mark.parametrize("name", list(LOSS_CASES))
+def test_real_valued_losses(name):
+    rng = np.random.default_rng(31)
+    pa, X0, Y0 = random_problem(rng, 120, 70, 6, 0.5, losses=LOSS_CASES[name], rx=L.QuadReg(0.05), ry=L.OneReg(0.05))
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=20))
+
+
+def test_classification_count_and_ordinal_losses():
+    rng = np.random.default_rng(32)
+    m, n, k = 140, 60, 4
+    Z = rng.standard_normal((m, k)) @ rng.standard_normal((k, n)) / 2
+    A = np.zeros((m, n))
+    losses = []
+    for f in range(n):
+        r = f % 4
+        if r == 0:
+            A[:, f] = rng.random(m) < 1 / (1 + np.exp(-Z[:, f])); losses.append(L.LogisticLoss(0.7))
+        elif r == 1:
+            A[:, f] = rng.random(m) < 0.5; losses.append(L.WeightedHingeLoss(1.2, case_weight_ratio=2.0))
+        elif r == 2:
+            A[:, f] = rng.poisson(np.exp(np.clip(Z[:, f], -2, 1.5))); losses.append(L.PoissonLoss())
+        else:
+            A[:, f] = np.clip(np.round(4 + 2 * Z[:, f]), 1, 7); losses.append(L.OrdinalHingeLoss(1, 7, 0.9))
+    I, J = np.nonzero(rng.random((m, n)) < 0.6)
+    X0, Y0 = 0.3 * rng.standard_normal((k, m)), 0.3 * rng.standard_normal((k, n))
+    g = L.GLRM(A, losses, L.QuadReg(0.5), L.QuadReg(0.5), k, obs=(I, J), X=X0, Y=Y0)
+    compare(g.problem_arrays(), np.asfortranarray(X0), np.asfortranarray(Y0), L.ProxGradParams(max_iter=25))
+    # homogeneous non-quadratic loss takes the segment-uniform kernel variant for rows as well
+    g2 = L.GLRM((A[:, ::4] > 0).astype(float), L.LogisticLoss(), L.QuadReg(0.1), L.QuadReg(0.1), k, X=X0, Y=Y0[:, ::4].copy())
+    compare(g2.problem_arrays(), np.asfortranarray(X0), np.asfortranarray(Y0[:, ::4]), L.ProxGradParams(max_iter=15))
+
+
+def test_per_row_and_per_column_regularizers():
+    rng = np.random.default_rng(33)
+    m, n, k = 90, 50, 5
+    kinds = [L.QuadReg(0.3), L.OneReg(0.2), L.NonNegConstraint(), L.ZeroReg(), L.UnitOneSparseConstraint()]
+    rx = [kinds[i % 5] for i in range(m)]
+    ry = [kinds[(i * 3) % 4] for i in range(n)]
+    pa, X0, Y0 = random_problem(rng, m, n, k, 0.5, rx=rx, ry=ry)
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=20))
+
+
+def test_duplicates_empty_segments_and_single_entries():
+    rng = np.random.default_rng(34)
+    m, n, k = 80, 40, 7
+    pa, X0, Y0 = random_problem(rng, m, n, k, 0.3, dup=True)
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=15))
+    A = rng.standard_normal((m, n))
+    feats = [[] for _ in range(m)]
+    exs = [[] for _ in range(n)]
+    feats[3] = [5]; feats[10] = [0, 0, 0, 39]; feats[79] = list(range(n))  # rows 0..2 etc. stay empty
+    exs[5] = [3]; exs[0] = [10, 10, 10]; exs[39] = list(range(m)) + [10]
+    X0, Y0 = rng.standard_normal((k, m)), rng.standard_normal((k, n))
+    g = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.OneReg(0.1), k, observed_features=feats, observed_examples=exs, X=X0, Y=Y0)
+    compare(g.problem_arrays(), np.asfortranarray(X0), np.asfortranarray(Y0), L.ProxGradParams(max_iter=15))
+
+
+def test_moderate_sparse_shape_k32():
+    """10^4 x 10^3, rank 32, 5 % observed, QuadReg (the C2 recipe at 1/1000 of the size)."""
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(10000, 1000, 32, 50)
+    one = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 1.0)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(10000, 1000, 32, rowptr, colidx, rowvals, colptr, rowidx, colvals, one, reg, reg)
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=12))
+
+
+def test_objective_entry_point():
+    rng = np.random.default_rng(35)
+    pa, X0, Y0 = random_problem(rng, 70, 30, 4, 0.5, rx=L.OneReg(0.3))
+    for include in (True, False):
+        vals = []
+        for api in (hip(), O.oracle_api()):
+            h = api.create(pa)
+            vals.append(api.objective(h, X0, Y0, include))
+            api.destroy(h)
+        assert vals[0] == pytest.approx(vals[1], rel=1e-12)
+
+
+def test_host_level_fit_and_handle_reuse():
+    rng = np.random.default_rng(36)
+    A = rng.standard_normal((60, 4)) @ rng.standard_normal((4, 45))
+    X0, Y0 = rng.standard_normal((4, 60)), rng.standard_normal((4, 45))
+    g = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.1), 4, X=X0, Y=Y0)
+    gc = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.1), 4, X=X0, Y=Y0)
+    p = L.HipProxGradParams(max_iter=1)
+    ch, chc = L.ConvergenceHistory("cv_by_iter"), L.ConvergenceHistory("cv_by_iter")
+    for _ in range(5):  # cv_by_iter pattern: max_iter=1, shared history, warm start (cross_validate.jl:164-175)
+        L.fit_b(g, p, ch=ch, verbose=False)
+        L.fit_b(gc, p, ch=chc, verbose=False, engine=O.oracle_api())
+    assert len(ch.objective) == 10
+    assert cases.rel_err(ch.objective, chc.objective) < TOL and cases.fro_err(g.X, gc.X) < TOL
+    assert L.objective(g) == pytest.approx(L.objective(gc, engine=O.oracle_api()), rel=1e-10)
+    g.close()
+
+
+def test_error_codes_on_device():
+    rng = np.random.default_rng(37)
+    pa, X0, Y0 = random_problem(rng, 20, 10, 3, 0.5)
+    api = hip()
+    bad = _capi.ProblemArrays(pa.m, pa.n, 200, pa.rowptr, pa.colidx, pa.rowvals, pa.colptr, pa.rowidx, pa.colvals, pa.losses, pa.rx, pa.ry)
+    with pytest.raises(_capi.GLRMError) as ei:
+        api.create(bad)
+    assert ei.value.code == _capi.ERR_UNSUPPORTED
+    pa.colvals = pa.colvals.copy(); pa.colvals[0] = np.nan
+    with pytest.raises(_capi.GLRMError) as ei:
+        api.create(pa)
+    assert ei.value.code == _capi.ERR_NONFINITE
+    pa, X0, Y0 = random_problem(rng, 20, 10, 3, 0.5)
+    h = api.create(pa)
+    with pytest.raises(_capi.GLRMError) as ei:
+        api.fit(h, L.ProxGradParams(max_iter=3), X0, np.zeros_like(Y0))
+    assert ei.value.code == _capi.ERR_INVALID
+    api.destroy(h)
+
+
+def test_two_shards_on_one_gpu_equal_one_shard():
+    """Sharding only re-labels which handle runs an independent row / column: two shard handles bound to the
+    same device buffers, stepped one after the other, give the single-handle bits."""
+    import torch
+    rng = np.random.default_rng(38)
+    m, n, k = 500, 120, 32
+    pa, X0, Y0 = random_problem(rng, m, n, k, 0.3)
+    api = hip()
+    params = L.ProxGradParams(max_iter=6)
+    o1, X1, Y1, _ = cases.run_engine(api, pa, X0, Y0, params)
+    def shard(rb, re, cb, ce):
+        r0, r1, c0, c1 = pa.rowptr[rb], pa.rowptr[re], pa.colptr[cb], pa.colptr[ce]
+        return _capi.ProblemArrays(m, n, k, np.ascontiguousarray(pa.rowptr[rb:re + 1] - r0), np.ascontiguousarray(pa.colidx[r0:r1]),
+                                   np.ascontiguousarray(pa.rowvals[r0:r1]), np.ascontiguousarray(pa.colptr[cb:ce + 1] - c0),
+                                   np.ascontiguousarray(pa.rowidx[c0:c1]), np.ascontiguousarray(pa.colvals[c0:c1]),
+                                   pa.losses, pa.rx, pa.ry, rb, re, cb, ce)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    hs = [api.create(shard(0, 230, 0, 50), stream=stream), api.create(shard(230, m, 50, n), stream=stream)]
+    ld = api.factor_ld(hs[0])
+    dX, dY = torch.zeros(m * ld, dtype=torch.float64, device=dev), torch.zeros(n * ld, dtype=torch.float64, device=dev)
+    dC, dR = torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(m, dtype=torch.float64, device=dev)
+    for h in hs:
+        api.bind_buffers(h, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())
+    api.set_factors(hs[0], X0, Y0)
+    for h in hs:
+        api.reset_stepsizes(h, params.stepsize)
+    objs = []
+    for _ in range(params.max_iter):
+        for h in hs:
+            api.step_x(h, params.min_stepsize)
+        for h in hs:
+            api.step_y(h, params.min_stepsize)
+        objs.append(api.sum(hs[0], dC.data_ptr(), n))
+    X2, Y2 = np.zeros_like(X0), np.zeros_like(Y0)
+    api.get_factors(hs[0], X2, Y2)
+    for h in hs:
+        api.destroy(h)
+    assert np.array_equal(X1, X2) and np.array_equal(Y1, Y2) and np.array_equal(o1[1:], np.array(objs))
+
+
+def test_runs_are_bitwise_deterministic():
+    rng = np.random.default_rng(39)
+    pa, X0, Y0 = random_problem(rng, 300, 200, 64, 0.2)
+    params = L.ProxGradParams(max_iter=8)
+    a = cases.run_engine(hip(), pa, X0, Y0, params)
+    b = cases.run_engine(hip(), pa, X0, Y0, params)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
