@@ -136,7 +136,11 @@ typedef struct glrm_options {
   int32_t profile;   /* 1 = bracket every sweep launch with HIP events (glrm_hip_kernel_stats) */
   int32_t waves_row; /* waves cooperating on one row   (0 = choose from mean |Omega_e|; 1, 4 or 8) */
   int32_t waves_col; /* waves cooperating on one column (0 = choose from mean |Omega^f|) */
-  void* stream;      /* hipStream_t to launch on; NULL = the handle creates its own */
+  void* stream;      /* hipStream_t to launch on */
+  int32_t caller_stream; /* 0: stream==NULL means "the handle creates a private non-blocking stream";
+                            1: launch on `stream` exactly as given, even NULL (the legacy default stream) --
+                            what a host that orders its own collectives on that stream must pass */
+  int32_t reserved;  /* must be 0 */
 } glrm_options;
 
 typedef struct glrm_handle glrm_handle;

