@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20260926)
     ap.add_argument("--waves-row", type=int, default=0)
     ap.add_argument("--waves-col", type=int, default=0)
+    ap.add_argument("--tiled", type=int, default=0, help="0 auto, 1 gather sweeps only, 2 LDS-tiled sweeps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000)
     args = ap.parse_args()
@@ -109,7 +110,7 @@ def main():
     t_gen = time.time() - t_gen
     t_create = time.time()
     sf = ShardedFit(api, w.problem(), rbs, cbs, device=device, stream=torch.cuda.current_stream().cuda_stream,
-                    opts=dict(profile=1, waves_row=args.waves_row, waves_col=args.waves_col))
+                    opts=dict(profile=1, waves_row=args.waves_row, waves_col=args.waves_col, tiled=args.tiled))
     nnz_r, nnz_c = w.nnz_rows, w.nnz_cols
     w.free_sources()
     t_create = time.time() - t_create
@@ -155,14 +156,21 @@ def main():
         bpu = algorithmic_bytes_per_update(k)
         ms_x = st["ms_x"] / max(st["launches_x"], 1)
         ms_y = st["ms_y"] / max(st["launches_y"], 1)
-        dom = "col_sweep" if ms_y >= ms_x else "row_sweep"
+        tiled_row, tiled_col = bool(st["tiled"] & 1), bool(st["tiled"] & 2)
+        # dominant kernel = the longest single kernel.  The gather column sweep and both row sweeps are one kernel per
+        # half-step; the LDS-tiled column sweep is four launches (pass, reduce, trial pass, decide) of which the two
+        # passes are about half the half-step each, so there the row sweep kernel is the longest.
+        dom = "row_sweep" if (ms_x >= ms_y or tiled_col) else "col_sweep"
         dom_ms, dom_nnz = (ms_y, nnz_c) if dom == "col_sweep" else (ms_x, nnz_r)
+        dom_tiled = tiled_col if dom == "col_sweep" else tiled_row
+        dom_name = {("row_sweep", True): "tiled_sweep_kernel (X half-step, LDS-tiled)", ("row_sweep", False): "sweep_kernel<WAVES=1> (X half-step, gather)",
+                    ("col_sweep", False): "sweep_kernel<WAVES=4> (Y half-step, gather)", ("col_sweep", True): "tiled_col_pass_kernel x2 + reduce/decide (Y half-step)"}[(dom, dom_tiled)]
         achieved = dom_nnz * bpu / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(f"{dom}_k{k}_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(f"{dom}_k{k}_{'tiled' if dom_tiled else 'gather'}_bytes_per_launch")
             except Exception:
                 traffic = None
         nseg_r, nseg_c = rbs[1] - rbs[0], cbs[1] - cbs[0]
@@ -173,10 +181,14 @@ def main():
             "config": {"workload": f"BASELINE configs[1] (C2): {m} x {n}, rank {k}, QuadLoss, {100.0 * q / n:.3g}% observed "
                                    f"({tot_r} observations), QuadReg(1.0) on X and Y, ProxGradParams defaults, stop rule off",
                        "m": m, "n": n, "k": k, "observed": tot_r, "parallelism": f"rows/cols sharded over {world} GPU(s), X,Y replicated",
-                       "waves_row": st["waves_row"], "waves_col": st["waves_col"]},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "waves_row": st["waves_row"], "waves_col": st["waves_col"],
+                       "row_sweep": "lds-tiled" if tiled_row else "gather", "col_sweep": "lds-tiled" if tiled_col else "gather"},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_update": bpu, "updates_per_launch": dom_nnz, "avg_launch_ms": dom_ms},
+                         "algorithmic_bytes_per_update": bpu, "updates_per_launch": dom_nnz, "avg_launch_ms": dom_ms,
+                         "note": "algorithmic bytes assume every update fetches its own k-vector (SURVEY.md 8(d)); the LDS-tiled "
+                                 "sweeps fetch a factor vector once per workgroup and tile, so frac > 1 means on-chip reuse, "
+                                 "and `traffic` (PMC) is what actually crossed the fabric"},
             "kernels": {"row_sweep_ms": ms_x, "col_sweep_ms": ms_y,
                         "row_sweep_GBps_algorithmic": nnz_r * bpu / (ms_x * 1e-3) / 1e9 if ms_x > 0 else None,
                         "col_sweep_GBps_algorithmic": nnz_c * bpu / (ms_y * 1e-3) / 1e9 if ms_y > 0 else None,

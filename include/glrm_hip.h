@@ -140,7 +140,8 @@ typedef struct glrm_options {
   int32_t caller_stream; /* 0: stream==NULL means "the handle creates a private non-blocking stream";
                             1: launch on `stream` exactly as given, even NULL (the legacy default stream) --
                             what a host that orders its own collectives on that stream must pass */
-  int32_t reserved;  /* must be 0 */
+  int32_t tiled;     /* sweep kernels: 0 = choose (LDS-tiled when the index lists are sorted and dense enough),
+                        1 = gather sweeps only, 2 = LDS-tiled sweeps wherever the lists are sorted */
 } glrm_options;
 
 typedef struct glrm_handle glrm_handle;
@@ -202,7 +203,8 @@ typedef struct glrm_kernel_stats {
   int64_t trials_x, trials_y;  /* line-search trials taken (sum over segments and sweeps) */
   int64_t accepts_x, accepts_y;
   int64_t nnz_rows, nnz_cols;  /* |Omega| of the local CSR / CSC */
-  int32_t waves_row, waves_col, ld, reserved;
+  int32_t waves_row, waves_col, ld;
+  int32_t tiled;               /* bit0: LDS-tiled row sweep in use, bit1: LDS-tiled column sweep in use */
 } glrm_kernel_stats;
 
 int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int reset);

@@ -31,7 +31,7 @@ struct CParams
     stepsize::Float64; max_iter::Int64; inner_iter_X::Int64; inner_iter_Y::Int64
     abs_tol::Float64; rel_tol::Float64; min_stepsize::Float64
 end
-struct COptions; device_id::Int32; profile::Int32; waves_row::Int32; waves_col::Int32; stream::Ptr{Cvoid}; caller_stream::Int32; reserved::Int32; end
+struct COptions; device_id::Int32; profile::Int32; waves_row::Int32; waves_col::Int32; stream::Ptr{Cvoid}; caller_stream::Int32; tiled::Int32; end
 
 "The 7 ProxGradParams fields (src/algorithms/proxgrad.jl:4-12) + the device ordinal."
 mutable struct HipProxGradParams <: AbstractParams

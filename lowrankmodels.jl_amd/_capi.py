@@ -61,7 +61,7 @@ class CParams(C.Structure):
 
 class COptions(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("profile", C.c_int32), ("waves_row", C.c_int32), ("waves_col", C.c_int32),
-                ("stream", C.c_void_p), ("caller_stream", C.c_int32), ("reserved", C.c_int32)]
+                ("stream", C.c_void_p), ("caller_stream", C.c_int32), ("tiled", C.c_int32)]
 
 
 class CKernelStats(C.Structure):
@@ -69,7 +69,7 @@ class CKernelStats(C.Structure):
         ("launches_x", C.c_int64), ("launches_y", C.c_int64), ("ms_x", C.c_double), ("ms_y", C.c_double),
         ("trials_x", C.c_int64), ("trials_y", C.c_int64), ("accepts_x", C.c_int64), ("accepts_y", C.c_int64),
         ("nnz_rows", C.c_int64), ("nnz_cols", C.c_int64),
-        ("waves_row", C.c_int32), ("waves_col", C.c_int32), ("ld", C.c_int32), ("reserved", C.c_int32),
+        ("waves_row", C.c_int32), ("waves_col", C.c_int32), ("ld", C.c_int32), ("tiled", C.c_int32),
     ]
 
     def asdict(self):
@@ -141,7 +141,7 @@ class Api:
             raise GLRMError(rc, self.last_error())
 
     # -- lifecycle --------------------------------------------------------------------
-    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=None):
+    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=None, tiled=0):
         """``stream=None``: the handle creates a private stream.  ``stream=<int>``: launch on exactly that
         hipStream_t -- 0 is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns
         for the default stream), so kernels stay ordered with the caller's other work on it."""
@@ -153,7 +153,7 @@ class Api:
         p.losses, p.n_losses = _ptr(prob.losses), len(prob.losses)
         p.rx, p.n_rx = _ptr(prob.rx), len(prob.rx)
         p.ry, p.n_ry = _ptr(prob.ry), len(prob.ry)
-        o = COptions(device_id, profile, waves_row, waves_col, (stream or None), 0 if stream is None else 1, 0)
+        o = COptions(device_id, profile, waves_row, waves_col, (stream or None), 0 if stream is None else 1, tiled)
         h = C.c_void_p()
         self._ck(self._f["create"](C.byref(h), C.byref(p), C.byref(o)))
         return h

@@ -16,7 +16,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 TARGETS = {
-    "libglrm_hip.so": (["glrm_hip.hip"], ["glrm_device.hpp", "../../include/glrm_hip.h"]),
+    "libglrm_hip.so": (["glrm_hip.hip", "glrm_tiled.hip"],
+                       ["glrm_device.hpp", "glrm_tiled.hpp", "glrm_engine.hpp", "../../include/glrm_hip.h"]),
     "libglrm_synth.so": (["glrm_synth.hip"], ["../../include/glrm_synth.h"]),
 }
 
@@ -35,10 +36,23 @@ def build_all(force=False, verbose=True):
         src_paths = [os.path.join(CSRC, s) for s in srcs]
         deps = src_paths + [os.path.normpath(os.path.join(CSRC, h)) for h in hdrs]
         if force or _stale(out, deps):
-            cmd = [HIPCC] + FLAGS + src_paths + ["-o", out]
+            # one hipcc -c per source, in parallel, then link
+            objs, procs = [], []
+            for sp in src_paths:
+                obj = os.path.join(PKG, "build", os.path.basename(sp) + ".o")
+                os.makedirs(os.path.dirname(obj), exist_ok=True)
+                cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", sp, "-o", obj]
+                if verbose:
+                    print("[build]", " ".join(cmd), flush=True)
+                procs.append((cmd, subprocess.Popen(cmd)))
+                objs.append(obj)
+            for cmd, pr in procs:
+                if pr.wait() != 0:
+                    raise subprocess.CalledProcessError(pr.returncode, cmd)
+            link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
             if verbose:
-                print("[build]", " ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+                print("[build]", " ".join(link), flush=True)
+            subprocess.run(link, check=True)
             built.append(name)
     return built
 

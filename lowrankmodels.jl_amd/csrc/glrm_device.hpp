@@ -34,13 +34,13 @@ constexpr int DPP_XOR2 = 0x4E;         // quad_perm:[2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8 lanes
 constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i inside each 16 lanes
 
-// Butterfly all-reduce over the G consecutive lanes of a group (G = 4, 8 or 16).  Every lane of
+// Butterfly all-reduce over the G consecutive lanes of a group (G = 1, 2, 4, 8 or 16).  Every lane of
 // the group ends with the bit-identical sum (each step adds two values that are already equal
 // across the sub-group, and + commutes).
 template <int G>
 __device__ __forceinline__ double group_sum(double v) {
-  v += dpp_f64<DPP_XOR1>(v);
-  v += dpp_f64<DPP_XOR2>(v);
+  if constexpr (G >= 2) v += dpp_f64<DPP_XOR1>(v);
+  if constexpr (G >= 4) v += dpp_f64<DPP_XOR2>(v);
   if constexpr (G >= 8) v += dpp_f64<DPP_HALF_MIRROR>(v);
   if constexpr (G >= 16) v += dpp_f64<DPP_MIRROR>(v);
   return v;
@@ -229,8 +229,8 @@ __device__ __forceinline__ void reg_prox(const RegDesc& r, Vec<G, R>& u, double 
       auto merge = [&](double ob, int oi) {
         if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
       };
-      merge(dpp_f64<DPP_XOR1>(best), dpp_i32<DPP_XOR1>(bi));
-      merge(dpp_f64<DPP_XOR2>(best), dpp_i32<DPP_XOR2>(bi));
+      if constexpr (G >= 2) merge(dpp_f64<DPP_XOR1>(best), dpp_i32<DPP_XOR1>(bi));
+      if constexpr (G >= 4) merge(dpp_f64<DPP_XOR2>(best), dpp_i32<DPP_XOR2>(bi));
       if constexpr (G >= 8) merge(dpp_f64<DPP_HALF_MIRROR>(best), dpp_i32<DPP_HALF_MIRROR>(bi));
       if constexpr (G >= 16) merge(dpp_f64<DPP_MIRROR>(best), dpp_i32<DPP_MIRROR>(bi));
 #pragma unroll

@@ -1,0 +1,84 @@
+// glrm_engine.hpp -- host-side declarations shared by the two translation units of libglrm_hip.so
+// (glrm_hip.hip: C ABI + gather sweeps; glrm_tiled.hip: LDS-tiled sweeps).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../include/glrm_hip.h"
+
+enum { LOSS_QUAD_UNIFORM = 0, LOSS_SEGMENT = 1, LOSS_PER_OBS = 2 };
+
+extern thread_local char g_err[768];
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIPCK(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess)                                                                             \
+      return fail(e_ == hipErrorOutOfMemory ? GLRM_ERR_OOM : GLRM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                                         \
+  } while (0)
+
+struct glrm_handle {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int64_t m = 0, n = 0;
+  int k = 0, kp = 0, G = 4, R = 2;
+  int unroll_row = 1, unroll_col = 1;
+  // LDS-tiled sweeps (glrm_tiled.hpp)
+  bool rows_sorted = false, cols_sorted = false;
+  int tiled_opt = 0;                  // glrm_options.tiled
+  int tiled_row = 0, tiled_col = 0;   // 0 = gather sweep, 1 = tiled
+  int tG = 4, tR = 2;                 // lane layout of the tiled kernels (kp = tG*tR)
+  int tile_cfg = 0;                   // 0: 8 waves + ~64 KB tile, 1: 16 waves + ~128 KB tile
+  int nsup = 0, tiles_per_sup = 0;
+  double *part = nullptr, *gsum = nullptr, *trialbuf = nullptr, *joldbuf = nullptr;
+  int32_t *activebuf = nullptr, *ntrialbuf = nullptr;
+  unsigned int* nactive = nullptr;
+  int* dflag = nullptr;
+  int64_t rb = 0, re = 0, cb = 0, ce = 0, ml = 0, nl = 0, nnz_r = 0, nnz_c = 0;
+  int64_t *rowptr = nullptr, *colptr = nullptr;
+  int32_t *colidx = nullptr, *rowidx = nullptr;
+  double *rowvals = nullptr, *colvals = nullptr;
+  glrm_loss* losses = nullptr;
+  int64_t n_losses = 0;
+  bool loss_quad_uniform = false;
+  glrm_reg *rx = nullptr, *ry = nullptr;
+  int64_t n_rx = 0, n_ry = 0;
+  double *alpharow = nullptr, *alphacol = nullptr;
+  double *X = nullptr, *Y = nullptr, *objcol = nullptr, *objrow = nullptr;             // in use (bound or owned)
+  double *oX = nullptr, *oY = nullptr, *oobjcol = nullptr, *oobjrow = nullptr;         // owned
+  double *partials = nullptr, *dscalar = nullptr;
+  unsigned long long* dcount = nullptr;
+  int32_t *trials_r = nullptr, *accepts_r = nullptr, *trials_c = nullptr, *accepts_c = nullptr;
+  int waves_row = 1, waves_col = 4;
+  int profile = 0;
+  struct Ev { hipEvent_t a, b; int which; };
+  std::vector<Ev> pending, pool;
+  int64_t launches_x = 0, launches_y = 0;
+  double ms_x = 0, ms_y = 0;
+};
+
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return (v && *v) ? atoi(v) : dflt;
+}
+
+
+// LDS-tiled sweeps (glrm_tiled.hip)
+int glrm_setup_tiled(glrm_handle* h);
+int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only);

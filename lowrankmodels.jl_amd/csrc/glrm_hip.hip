@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "glrm_device.hpp"
+#include "glrm_engine.hpp"
 
 using namespace glrm;
 
@@ -53,7 +54,6 @@ struct SweepArgs {
   int32_t* accepts;
 };
 
-enum { LOSS_QUAD_UNIFORM = 0, LOSS_SEGMENT = 1, LOSS_PER_OBS = 2 };
 
 // One pass over the segment for one wave: J = sum of losses at u = <xv, other[idx]>, and (GRAD)
 // g = sum of dL * other[idx].  Returns wave-level totals replicated in every lane.
@@ -350,53 +350,7 @@ __global__ void isum_kernel(const int32_t* v, int64_t n, unsigned long long* out
 
 // =============================================================================== host side
 
-static thread_local char g_err[768];
-
-static int fail(int code, const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof g_err, fmt, ap);
-  va_end(ap);
-  return code;
-}
-
-#define HIPCK(expr)                                                                                   \
-  do {                                                                                                \
-    hipError_t e_ = (expr);                                                                           \
-    if (e_ != hipSuccess)                                                                             \
-      return fail(e_ == hipErrorOutOfMemory ? GLRM_ERR_OOM : GLRM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
-                  hipGetErrorString(e_), __FILE__, __LINE__);                                         \
-  } while (0)
-
-struct glrm_handle {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  bool own_stream = false;
-  int64_t m = 0, n = 0;
-  int k = 0, kp = 0, G = 4, R = 2;
-  int unroll_row = 1, unroll_col = 1;
-  int64_t rb = 0, re = 0, cb = 0, ce = 0, ml = 0, nl = 0, nnz_r = 0, nnz_c = 0;
-  int64_t *rowptr = nullptr, *colptr = nullptr;
-  int32_t *colidx = nullptr, *rowidx = nullptr;
-  double *rowvals = nullptr, *colvals = nullptr;
-  glrm_loss* losses = nullptr;
-  int64_t n_losses = 0;
-  bool loss_quad_uniform = false;
-  glrm_reg *rx = nullptr, *ry = nullptr;
-  int64_t n_rx = 0, n_ry = 0;
-  double *alpharow = nullptr, *alphacol = nullptr;
-  double *X = nullptr, *Y = nullptr, *objcol = nullptr, *objrow = nullptr;             // in use (bound or owned)
-  double *oX = nullptr, *oY = nullptr, *oobjcol = nullptr, *oobjrow = nullptr;         // owned
-  double *partials = nullptr, *dscalar = nullptr;
-  unsigned long long* dcount = nullptr;
-  int32_t *trials_r = nullptr, *accepts_r = nullptr, *trials_c = nullptr, *accepts_c = nullptr;
-  int waves_row = 1, waves_col = 4;
-  int profile = 0;
-  struct Ev { hipEvent_t a, b; int which; };
-  std::vector<Ev> pending, pool;
-  int64_t launches_x = 0, launches_y = 0;
-  double ms_x = 0, ms_y = 0;
-};
+thread_local char g_err[768];
 
 struct DeviceGuard {
   int prev = -1;
@@ -413,11 +367,6 @@ struct DeviceGuard {
 
 extern "C" int glrm_hip_version(void) { return GLRM_HIP_ABI_VERSION; }
 extern "C" const char* glrm_hip_last_error(void) { return g_err; }
-
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return (v && *v) ? atoi(v) : dflt;
-}
 
 // kp = G*R >= k.  Default layouts; GLRM_HIP_LANES_PER_OBS (tuning knob) selects another G for the same kp.
 static int pick_layout(int k, int& G, int& R) {
@@ -515,7 +464,8 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
   (void)hipStreamSynchronize(h->stream);
   void* ptrs[] = {h->rowptr, h->colptr, h->colidx, h->rowidx, h->rowvals, h->colvals, h->losses, h->rx, h->ry,
                   h->alpharow, h->alphacol, h->oX, h->oY, h->oobjcol, h->oobjrow, h->partials, h->dscalar, h->dcount,
-                  h->trials_r, h->accepts_r, h->trials_c, h->accepts_c};
+                  h->trials_r, h->accepts_r, h->trials_c, h->accepts_c, h->part, h->gsum, h->trialbuf, h->joldbuf,
+                  h->activebuf, h->ntrialbuf, h->nactive, h->dflag};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : h->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -534,6 +484,7 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   h->unroll_row = env_int("GLRM_HIP_UNROLL_ROW", 2) == 2 ? 2 : 1; // 2 observations per group in flight: -20 % on the L2-latency-bound row sweep
   h->unroll_col = env_int("GLRM_HIP_UNROLL_COL", 1) == 2 ? 2 : 1;
   h->profile = o ? o->profile : 0;
+  h->tiled_opt = o ? o->tiled : 0;
   if (o && (o->stream || o->caller_stream)) {
     h->stream = (hipStream_t)o->stream; // may be NULL = the legacy default stream (caller_stream)
   } else {
@@ -577,6 +528,8 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   HIPCK(hipMemsetAsync(h->accepts_c, 0, nl1 * 4, st));
   h->waves_row = pick_waves(o ? o->waves_row : 0, h->nnz_r, h->ml);
   h->waves_col = pick_waves(o ? o->waves_col : 0, h->nnz_c, h->nl);
+  int rc2 = glrm_setup_tiled(h);
+  if (rc2) return rc2;
   HIPCK(hipStreamSynchronize(st)); // host descriptor / index arrays may be released by the caller now
   return GLRM_OK;
 }
@@ -792,7 +745,13 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
     ev.which = which;
     HIPCK(hipEventRecord(ev.a, h->stream));
   }
-  launch_sweep(h->G, h->R, rows ? h->waves_row : h->waves_col, loss, rows ? h->unroll_row : h->unroll_col, a, h->stream);
+  const bool tiled = rows ? (h->tiled_row && !eval_only) : h->tiled_col;
+  if (tiled) {
+    rc = glrm_run_tiled(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
+    if (rc) return rc;
+  } else {
+    launch_sweep(h->G, h->R, rows ? h->waves_row : h->waves_col, loss, rows ? h->unroll_row : h->unroll_col, a, h->stream);
+  }
   HIPCK(hipGetLastError());
   if (timed) {
     HIPCK(hipEventRecord(ev.b, h->stream));
@@ -883,6 +842,7 @@ extern "C" int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int
   if ((rc = count_sum(h, h->accepts_c, h->nl, &out->accepts_y))) return rc;
   out->nnz_rows = h->nnz_r; out->nnz_cols = h->nnz_c;
   out->waves_row = h->waves_row; out->waves_col = h->waves_col; out->ld = h->kp;
+  out->tiled = (h->tiled_row ? 1 : 0) | (h->tiled_col ? 2 : 0); // bit0: tiled row sweep, bit1: tiled column sweep
   if (reset) {
     h->launches_x = h->launches_y = 0;
     h->ms_x = h->ms_y = 0;

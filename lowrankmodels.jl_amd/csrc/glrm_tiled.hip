@@ -1,0 +1,175 @@
+// glrm_tiled.hip -- host side + instantiations of the LDS-tiled sweeps (kernels in glrm_tiled.hpp).
+// Separate translation unit so that the two kernel families compile in parallel.
+#include <hip/hip_runtime.h>
+
+#include "glrm_engine.hpp"
+#include "glrm_tiled.hpp"
+
+using namespace glrm;
+
+// ------------------------------------------------------------------ LDS-tiled sweeps: setup and launch
+
+// opposing vectors per LDS tile (rows are padded by 16 B): cfg 0 = 64 KB tile, 8 waves, two workgroups per CU;
+// cfg 1 = 150 KB tile, 16 waves, one workgroup per CU (fewer barriers, fewer factor re-reads)
+constexpr int tile_rows_c(int kp, int cfg) { return ((cfg ? 150 * 1024 : 64 * 1024) / (kp * 8 + 16)) / 16 * 16; }
+static int tile_rows(int kp, int cfg) { return tile_rows_c(kp, cfg); }
+
+int glrm_setup_tiled(glrm_handle* h) {
+  hipStream_t st = h->stream;
+  HIPCK(hipMalloc((void**)&h->dflag, 2 * sizeof(int)));
+  HIPCK(hipMemsetAsync(h->dflag, 0, 2 * sizeof(int), st));
+  if (h->ml > 0) hipLaunchKernelGGL(check_sorted_kernel, dim3((unsigned)h->ml), dim3(64), 0, st, h->rowptr, h->colidx, h->ml, h->dflag);
+  if (h->nl > 0) hipLaunchKernelGGL(check_sorted_kernel, dim3((unsigned)h->nl), dim3(256), 0, st, h->colptr, h->rowidx, h->nl, h->dflag + 1);
+  HIPCK(hipGetLastError());
+  int flags[2] = {0, 0};
+  HIPCK(hipMemcpyAsync(flags, h->dflag, sizeof flags, hipMemcpyDeviceToHost, st));
+  HIPCK(hipStreamSynchronize(st));
+  h->rows_sorted = flags[0] == 0;
+  h->cols_sorted = flags[1] == 0;
+  h->tile_cfg = env_int("GLRM_HIP_TILE_CFG", 1) ? 1 : 0;
+  h->tG = h->G;
+  h->tR = h->R;
+
+  const int T = tile_rows(h->kp, h->tile_cfg);
+  // expected observations of one segment inside one tile; the tiled sweeps pay off when a staged
+  // vector is reused by several of the workgroup's segments
+  const double per_tile_r = h->ml > 0 ? (double)h->nnz_r / (double)h->ml * T / (double)h->n : 0.0;
+  const double per_tile_c = h->nl > 0 ? (double)h->nnz_c / (double)h->nl * T / (double)h->m : 0.0;
+  // h->tiled_opt (glrm_options.tiled): 0 auto, 1 gather sweeps only, 2 tiled wherever the index lists are sorted.
+  // GLRM_HIP_TILED (tuning): bit0 rows, bit1 columns; overrides the option.
+  int want = h->tiled_opt == 1 ? 0 : (h->tiled_opt == 2 ? 3 : -1);
+  want = env_int("GLRM_HIP_TILED", want);
+  h->tiled_row = h->rows_sorted && (want < 0 ? (per_tile_r >= 4.0 && h->ml >= 2048) : (want & 1)) ? 1 : 0;
+  h->tiled_col = h->cols_sorted && (want < 0 ? (per_tile_c >= 4.0 && h->nl >= 256) : ((want >> 1) & 1)) ? 1 : 0;
+  const int64_t ntiles = (h->m + T - 1) / T;
+  int64_t nsup = ntiles < 32 ? ntiles : 32;
+  h->tiles_per_sup = (int)((ntiles + nsup - 1) / nsup);
+  h->nsup = (int)((ntiles + h->tiles_per_sup - 1) / h->tiles_per_sup);
+  if (h->tiled_col) {
+    const int64_t nl1 = h->nl > 0 ? h->nl : 1;
+    HIPCK(hipMalloc((void**)&h->part, (size_t)nl1 * h->nsup * (h->kp + 2) * 8));
+    HIPCK(hipMalloc((void**)&h->gsum, (size_t)nl1 * h->kp * 8));
+    HIPCK(hipMalloc((void**)&h->trialbuf, (size_t)nl1 * h->kp * 8));
+    HIPCK(hipMalloc((void**)&h->joldbuf, (size_t)nl1 * 8));
+    HIPCK(hipMalloc((void**)&h->activebuf, (size_t)nl1 * 4));
+    HIPCK(hipMalloc((void**)&h->ntrialbuf, (size_t)nl1 * 4));
+    HIPCK(hipMalloc((void**)&h->nactive, 4));
+  }
+  return GLRM_OK;
+}
+
+template <typename K>
+static int set_lds(K kernel, int bytes) {
+  if (bytes > 65536) HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return GLRM_OK;
+}
+
+// kind: 0 = whole sweep (tiled_sweep_kernel), 1 = column pass 1, 2 = column trial pass
+template <int G, int R, int NW, int TILE, int LOSS>
+static int launch_tiled_inst(int kind, const TiledArgs& a, hipStream_t st) {
+  constexpr int SPB = NW * (64 / G);
+  const int lds = TILE * tile_row_bytes<G, R>();
+  const unsigned gx = (unsigned)((a.nseg + SPB - 1) / SPB);
+  int rc = GLRM_OK;
+  if (kind == 0) {
+    if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS>), dim3(gx), dim3(NW * 64), lds, st, a);
+  } else if (kind == 1) {
+    if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
+  } else {
+    if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
+  }
+  return GLRM_OK;
+}
+
+template <int G, int R>
+static int launch_tiled_layout(int cfg, int loss, int kind, const TiledArgs& a, hipStream_t st) {
+  constexpr int KP = G * R, T0 = tile_rows_c(KP, 0), T1 = tile_rows_c(KP, 1);
+#define GLRM_TL(LOSSV)                                                                   \
+  (cfg ? launch_tiled_inst<G, R, 16, T1, LOSSV>(kind, a, st) : launch_tiled_inst<G, R, 8, T0, LOSSV>(kind, a, st))
+  switch (loss) {
+    case LOSS_QUAD_UNIFORM: return GLRM_TL(0);
+    case LOSS_SEGMENT: return GLRM_TL(1);
+    default: return GLRM_TL(2);
+  }
+#undef GLRM_TL
+}
+
+static int launch_tiled(glrm_handle* h, int loss, int kind, const TiledArgs& a) {
+  switch (h->tG * 100 + h->tR) {
+    case 402: return launch_tiled_layout<4, 2>(h->tile_cfg, loss, kind, a, h->stream);
+    case 404: return launch_tiled_layout<4, 4>(h->tile_cfg, loss, kind, a, h->stream);
+    case 408: return launch_tiled_layout<4, 8>(h->tile_cfg, loss, kind, a, h->stream);
+    case 808: return launch_tiled_layout<8, 8>(h->tile_cfg, loss, kind, a, h->stream);
+    case 1608: return launch_tiled_layout<16, 8>(h->tile_cfg, loss, kind, a, h->stream);
+    default: return fail(GLRM_ERR_UNSUPPORTED, "no tiled kernel for lane layout G=%d R=%d", h->tG, h->tR);
+  }
+}
+
+template <int G, int R>
+static void launch_col_small(int which, const TiledArgs& a, hipStream_t st) {
+  const unsigned gx = (unsigned)((a.nseg + 4 * (64 / G) - 1) / (4 * (64 / G)));
+  if (which == 0) hipLaunchKernelGGL((col_reduce_kernel<G, R>), dim3(gx), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((col_decide_kernel<G, R>), dim3(gx), dim3(256), 0, st, a);
+}
+
+static void launch_col_small_any(glrm_handle* h, int which, const TiledArgs& a) {
+  switch (h->tG * 100 + h->tR) {
+
+    case 402: launch_col_small<4, 2>(which, a, h->stream); break;
+    case 404: launch_col_small<4, 4>(which, a, h->stream); break;
+    case 408: launch_col_small<4, 8>(which, a, h->stream); break;
+    case 808: launch_col_small<8, 8>(which, a, h->stream); break;
+    default: launch_col_small<16, 8>(which, a, h->stream); break;
+  }
+}
+
+// The tiled variants of run_sweep's launch.  Rows: one kernel.  Columns: pass 1 -> reduce -> rounds of
+// (trial pass, decide) until no column is still searching (the count is read back once per round).
+int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only) {
+  TiledArgs a{};
+  a.nseg = rows ? h->ml : h->nl;
+  a.ptr = rows ? h->rowptr : h->colptr;
+  a.idx = rows ? h->colidx : h->rowidx;
+  a.vals = rows ? h->rowvals : h->colvals;
+  a.own = rows ? h->X : h->Y;
+  a.own_offset = rows ? h->rb : h->cb;
+  a.other = rows ? h->Y : h->X;
+  a.n_other = rows ? h->n : h->m;
+  a.alpha = rows ? h->alpharow : h->alphacol;
+  a.obj = rows ? nullptr : h->objcol;
+  a.losses = h->losses;
+  a.loss_by_segment = loss_by_segment;
+  a.regs = rows ? h->rx : h->ry;
+  a.reg_single = (rows ? h->n_rx : h->n_ry) == 1;
+  a.k = h->k;
+  a.min_stepsize = min_stepsize;
+  a.trials = rows ? h->trials_r : h->trials_c;
+  a.accepts = rows ? h->accepts_r : h->accepts_c;
+  a.eval_only = eval_only;
+  if (rows) return launch_tiled(h, loss, 0, a);
+  a.nsup = h->nsup;
+  a.tiles_per_sup = h->tiles_per_sup;
+  a.part = h->part; a.gsum = h->gsum; a.trial = h->trialbuf; a.jold = h->joldbuf;
+  a.active = h->activebuf; a.ntrial = h->ntrialbuf; a.nactive = h->nactive;
+  int rc;
+  HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
+  if ((rc = launch_tiled(h, loss, 1, a))) return rc;
+  launch_col_small_any(h, 0, a);
+  HIPCK(hipGetLastError());
+  if (eval_only) return GLRM_OK;
+  for (int round = 0; round < 64; ++round) {
+    unsigned int nact = 0;
+    HIPCK(hipMemcpyAsync(&nact, h->nactive, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    if (nact == 0) break;
+    HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
+    if ((rc = launch_tiled(h, loss, 2, a))) return rc;
+    launch_col_small_any(h, 1, a);
+    HIPCK(hipGetLastError());
+  }
+  return GLRM_OK;
+}
+

@@ -1,0 +1,467 @@
+// glrm_tiled.hpp -- LDS-tiled sweeps: the opposing factor is staged through LDS tile by tile and every
+// lane group owns ONE segment (row or column) whose observations it walks in list order.
+//
+// Why: in the gather sweeps (glrm_hip.hip) every observation fetches its own k-vector of the opposing
+// factor from L2 / Infinity Cache / HBM (2 x 128-byte lines at k=32), which is what bounds them
+// (profiles/r01_baseline_pmc_summary.md).  Here a workgroup of NW waves owns SPB = NW*64/G segments; it
+// loops over tiles of TILE consecutive opposing vectors, copies the tile into LDS once (coalesced 16-byte
+// loads) and every group consumes the observations of its segment that fall into the tile from LDS.  A
+// factor vector is thus read from memory once per (workgroup, pass) instead of once per observation, and
+// the per-observation traffic left is the 12-byte (index, value) stream.
+//
+// Requirements: the segment's index list is non-decreasing (true for `findall` / sparse input,
+// src/glrm.jl:46-48; checked at create, otherwise the gather sweeps are used).  Duplicates are fine.
+//
+// Summation order: a group accumulates its segment's losses and gradient sequentially in list order --
+// the reference's own order (src/algorithms/proxgrad.jl:122-132, src/evaluate_fit.jl:28-32).  The column
+// sweep additionally splits the rows into NSUP super-tiles whose partial sums are added in order; NSUP
+// depends only on (m, TILE), never on the shard layout, so results stay independent of the GPU count.
+#pragma once
+
+#include "glrm_device.hpp"
+
+namespace glrm {
+
+struct TiledArgs {
+  int64_t nseg;          // local segments
+  const int64_t* ptr;    // nseg+1
+  const int32_t* idx;    // non-decreasing inside every segment
+  const double* vals;
+  double* own;           // factor being updated (global array, ld = KP)
+  int64_t own_offset;    // global id of local segment 0
+  const double* other;   // opposing factor (global array, ld = KP)
+  int64_t n_other;       // number of opposing vectors
+  double* alpha;         // per local segment
+  double* obj;           // per GLOBAL segment (nullable)
+  const glrm_loss* losses;
+  int loss_by_segment;
+  const glrm_reg* regs;
+  int reg_single;
+  int k;
+  double min_stepsize;
+  int32_t* trials;
+  int32_t* accepts;
+  // column sweep (split over super-tiles)
+  int nsup;              // number of super-tiles
+  int tiles_per_sup;     // tiles per super-tile
+  double* part;          // [nseg][nsup][KP+2]: partial gradient (KP), partial loss sum, pad
+  double* gsum;          // [nseg][KP]   reduced gradient (kept for later trials)
+  double* trial;         // [nseg][KP]   current trial point
+  double* jold;          // [nseg]
+  int32_t* active;       // [nseg] 1 while the segment's line search is still running
+  int32_t* ntrial;       // [nseg] trials taken in this sweep
+  unsigned int* nactive; // device counter of still-active segments
+  int eval_only;         // col_reduce: obj = sum of losses, nothing else
+};
+
+template <int G>
+__device__ __forceinline__ int group_bcast_i32(int v, int u, int lane) {
+  if constexpr (G == 1) {
+    return v;
+  } else if constexpr (G == 2) {
+    return u == 0 ? __builtin_amdgcn_update_dpp(v, v, 0xA0, 0xF, 0xF, false)  // quad_perm:[0,0,2,2]
+                  : __builtin_amdgcn_update_dpp(v, v, 0xF5, 0xF, 0xF, false); // quad_perm:[1,1,3,3]
+  } else if constexpr (G == 4) {
+    switch (u) { // compile-time after unrolling
+      case 0: return __builtin_amdgcn_update_dpp(v, v, 0x00, 0xF, 0xF, false);
+      case 1: return __builtin_amdgcn_update_dpp(v, v, 0x55, 0xF, 0xF, false);
+      case 2: return __builtin_amdgcn_update_dpp(v, v, 0xAA, 0xF, 0xF, false);
+      default: return __builtin_amdgcn_update_dpp(v, v, 0xFF, 0xF, 0xF, false);
+    }
+  } else {
+    return __shfl(v, (lane & ~(G - 1)) + u, 64);
+  }
+}
+template <int G>
+__device__ __forceinline__ double group_bcast_f64(double v, int u, int lane) {
+  const int lo = group_bcast_i32<G>(__double2loint(v), u, lane), hi = group_bcast_i32<G>(__double2hiint(v), u, lane);
+  return __hiloint2double(hi, lo);
+}
+
+template <int G, int R>
+constexpr int tile_row_bytes() { return G * R * 8 + 16; } // +16 B pad: consecutive rows start 4 banks apart
+
+// Copy opposing vectors [lo, hi) into LDS (coalesced 16-byte loads, padded rows).
+template <int G, int R, int NT>
+__device__ __forceinline__ void stage_tile(const double* __restrict__ other, int64_t lo, int64_t hi, char* lds) {
+  constexpr int KPB = G * R * 8, ROWB = tile_row_bytes<G, R>();
+  const char* src = reinterpret_cast<const char*>(other) + lo * KPB;
+  const int total = (int)(hi - lo) * KPB;
+  constexpr int U = 4; // 4 x 16-byte loads in flight per thread before the LDS writes
+  for (int base = 0; base < total; base += NT * 16 * U) {
+    double2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { // unconditional loads (clamped), predicated writes
+      int off = base + (u * NT + (int)threadIdx.x) * 16;
+      off = off < total ? off : total - 16;
+      v[u] = *reinterpret_cast<const double2*>(src + off);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int off = base + (u * NT + (int)threadIdx.x) * 16;
+      if (off < total) {
+        const int row = off / KPB, col = off - row * KPB;
+        *reinterpret_cast<double2*>(lds + row * ROWB + col) = v[u];
+      }
+    }
+  }
+}
+
+// One pass of every group of the workgroup over tiles [tile_begin, tile_end).
+//   xv      the point at which the segment's losses are evaluated
+//   g, J    outputs: gradient (GRAD) and loss sum of the segment's observations inside those tiles
+//   pos     in/out: position in the segment's list (first entry with idx >= tile_begin*TILE on entry)
+//   active  group-uniform; inactive groups only take part in staging and barriers
+template <int G, int R, int NW, int TILE, int LOSS, bool GRAD>
+__device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const Vec<G, R>& xv, Vec<G, R>& g, double& J,
+                                           bool active, int64_t& pos, int64_t end, int tile_begin, int tile_end,
+                                           const LossDesc& segloss, int lane, int j) {
+  constexpr int ROWB = tile_row_bytes<G, R>(), NT = NW * 64;
+  const double two_scale = 2 * segloss.scale;
+  J = 0.0;
+  if (GRAD) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) g.v[i] = make_double2(0.0, 0.0);
+  }
+  const int32_t* __restrict__ idx = a.idx;
+  const double* __restrict__ vals = a.vals;
+  // current batch: lane j of the group holds entry pos + j.  Batch loads are UNCONDITIONAL (address clamped
+  // into the segment, validity applied when the entry is used) so that the compiler can keep the prefetch of
+  // the next batch in flight with a counted s_waitcnt instead of draining the queue at every branch merge.
+  const int64_t last = end > 0 ? end - 1 : 0; // idx/vals always hold at least one element
+  auto load_entry = [&](int64_t p, int& c, double& av) {
+    const int64_t q = p < last ? p : last;
+    c = idx[q];
+    av = vals[q];
+  };
+  int cb;
+  double ab;
+  load_entry(pos + j, cb, ab);
+  if (!(active && pos + j < end)) cb = 0x7fffffff;
+  for (int t = tile_begin; t < tile_end; ++t) {
+    const int64_t lo = (int64_t)t * TILE;
+    const int64_t hi = lo + TILE < a.n_other ? lo + TILE : a.n_other;
+    __syncthreads(); // everybody is done with the previous tile
+    stage_tile<G, R, NT>(a.other, lo, hi, lds);
+    __syncthreads();
+    bool done = !active;
+    while (!done) {
+      int cn; // prefetch the next batch while this one is consumed
+      double an;
+      load_entry(pos + G + j, cn, an);
+      const bool next_ok = pos + G + j < end;
+      int nproc = 0;
+#pragma unroll
+      for (int u = 0; u < G; ++u) {
+        const int c = group_bcast_i32<G>(cb, u, lane);
+        const double av = group_bcast_f64<G>(ab, u, lane);
+        if (!done && c < (int)hi) { // c == INT_MAX past the end of the segment
+          const char* rowp = lds + (c - (int)lo) * ROWB + j * 16;
+          double2 y[R / 2];
+#pragma unroll
+          for (int i = 0; i < R / 2; ++i) y[i] = *reinterpret_cast<const double2*>(rowp + i * (2 * G * 8));
+          double dot = 0.0;
+#pragma unroll
+          for (int i = 0; i < R / 2; ++i) {
+            dot = fma(xv.v[i].x, y[i].x, dot);
+            dot = fma(xv.v[i].y, y[i].y, dot);
+          }
+          dot = group_sum<G>(dot);
+          double L, dL;
+          if constexpr (LOSS == 0) {
+            const double d = dot - av;
+            L = segloss.scale * (d * d);
+            dL = d * two_scale; // == (2*d)*scale bit for bit: doubling is exact
+          } else if constexpr (LOSS == 1) {
+            loss_both<GRAD>(segloss, dot, av, L, dL);
+          } else {
+            const LossDesc lo_ = load_loss(a.losses, c);
+            loss_both<GRAD>(lo_, dot, av, L, dL);
+          }
+          J += L;
+          if (GRAD) {
+#pragma unroll
+            for (int i = 0; i < R / 2; ++i) {
+              g.v[i].x = fma(dL, y[i].x, g.v[i].x);
+              g.v[i].y = fma(dL, y[i].y, g.v[i].y);
+            }
+          }
+          ++nproc;
+        } else {
+          done = true;
+        }
+      }
+      pos += nproc;
+      if (!done) { // the whole batch was consumed: continue with the prefetched one
+        cb = next_ok ? cn : 0x7fffffff;
+        ab = an;
+      } else if (nproc > 0) { // stopped inside the batch: re-anchor the batch at the new position
+        load_entry(pos + j, cb, ab);
+        if (!(pos + j < end)) cb = 0x7fffffff;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// X half-step (and any sweep whose segments are plentiful): whole sweep in one kernel.
+// Workgroup = NW waves, SPB = NW*64/G segments; each pass streams the WHOLE opposing factor through LDS.
+template <int G, int R, int NW, int TILE, int LOSS>
+__global__ void __launch_bounds__(NW * 64, 4) tiled_sweep_kernel(const TiledArgs a) {
+  constexpr int KP = G * R, NGW = 64 / G, SPB = NW * NGW;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % G, gi = lane / G;
+  const int64_t seg = (int64_t)blockIdx.x * SPB + wave * NGW + gi;
+  const bool have = seg < a.nseg;
+  const int64_t beg = have ? a.ptr[seg] : 0, end = have ? a.ptr[seg + 1] : 0;
+  const int64_t gseg = a.own_offset + (have ? seg : 0);
+  double2* ownp = reinterpret_cast<double2*>(a.own + gseg * KP);
+  const int ntiles = (int)((a.n_other + TILE - 1) / TILE);
+
+  Vec<G, R> x, g, xn;
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) x.v[i] = have ? ownp[i * G + j] : make_double2(0.0, 0.0);
+  const RegDesc rd = load_reg(a.regs, (a.reg_single || !have) ? 0 : seg);
+  LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
+  if constexpr (LOSS != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
+
+  double Jold;
+  int64_t pos = beg;
+  tiled_pass<G, R, NW, TILE, LOSS, true>(a, lds, x, g, Jold, have, pos, end, 0, ntiles, segloss, lane, j);
+  Jold += reg_eval<G, R>(rd, x, j, a.k);
+
+  double alpha = have ? a.alpha[seg] : 0.0;
+  const double l = (double)(end - beg) + 1.0;
+  int ntrials = 0;
+  bool accepted = false;
+  bool searching = have && alpha > a.min_stepsize;
+  while (__syncthreads_or(searching ? 1 : 0)) {
+    const double s = alpha / l;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      xn.v[i].x = fma(-s, g.v[i].x, x.v[i].x);
+      xn.v[i].y = fma(-s, g.v[i].y, x.v[i].y);
+    }
+    reg_prox<G, R>(rd, xn, s, j, a.k);
+    double Jn;
+    Vec<G, R> dummy;
+    pos = beg;
+    tiled_pass<G, R, NW, TILE, LOSS, false>(a, lds, xn, dummy, Jn, searching, pos, end, 0, ntiles, segloss, lane, j);
+    Jn += reg_eval<G, R>(rd, xn, j, a.k);
+    if (searching) {
+      ++ntrials;
+      if (Jn < Jold) {
+        x = xn;
+        alpha *= 1.05;
+        Jold = Jn;
+        accepted = true;
+        searching = false;
+      } else {
+        alpha *= .7;
+        if (alpha < a.min_stepsize) {
+          alpha = a.min_stepsize * 1.1;
+          searching = false;
+        }
+      }
+    }
+  }
+  if (have) {
+    if (accepted) {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = x.v[i];
+    }
+    if (j == 0) {
+      a.alpha[seg] = alpha;
+      if (a.obj) a.obj[gseg] = Jold;
+      if (a.trials) {
+        a.trials[seg] += ntrials;
+        a.accepts[seg] += accepted ? 1 : 0;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Y half-step when columns are few and long: rows are split into NSUP super-tiles, one workgroup per
+// (column group, super-tile); partial sums are reduced in super-tile order by col_reduce_kernel /
+// col_decide_kernel, and the line search runs as rounds of (pass, decide) launches.
+
+template <int G>
+__device__ __forceinline__ int64_t lower_bound_idx(const int32_t* idx, int64_t b, int64_t e, int64_t key) {
+  while (b < e) {
+    const int64_t mid = b + ((e - b) >> 1);
+    if ((int64_t)idx[mid] < key) b = mid + 1; else e = mid;
+  }
+  return b;
+}
+
+// GRAD = true: pass 1 (gradient + loss partials at the current point a.own);
+// GRAD = false: trial pass (loss partials at a.trial for the still-active segments).
+template <int G, int R, int NW, int TILE, int LOSS, bool GRAD>
+__global__ void __launch_bounds__(NW * 64, 4) tiled_col_pass_kernel(const TiledArgs a) {
+  constexpr int KP = G * R, NGW = 64 / G, SPB = NW * NGW, PSTRIDE = KP + 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % G, gi = lane / G;
+  const int64_t seg = (int64_t)blockIdx.x * SPB + wave * NGW + gi;
+  const int sup = blockIdx.y;
+  bool have = seg < a.nseg;
+  if (!GRAD && have) have = a.active[seg] != 0;
+  if (!GRAD && !__syncthreads_or(have ? 1 : 0)) return; // nothing left to evaluate in this column group
+  const int64_t beg = have ? a.ptr[seg] : 0, end = have ? a.ptr[seg + 1] : 0;
+  const int64_t gseg = a.own_offset + (have ? seg : 0);
+  const int ntiles = (int)((a.n_other + TILE - 1) / TILE);
+  const int tb = sup * a.tiles_per_sup;
+  const int te = tb + a.tiles_per_sup < ntiles ? tb + a.tiles_per_sup : ntiles;
+  const double2* xp = reinterpret_cast<const double2*>(GRAD ? a.own + gseg * KP : a.trial + (have ? seg : 0) * (int64_t)KP);
+  Vec<G, R> x, g;
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) x.v[i] = have ? xp[i * G + j] : make_double2(0.0, 0.0);
+  LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
+  if constexpr (LOSS != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
+  int64_t pos = have ? lower_bound_idx<G>(a.idx, beg, end, (int64_t)tb * TILE) : 0;
+  double J;
+  tiled_pass<G, R, NW, TILE, LOSS, GRAD>(a, lds, x, g, J, have, pos, end, tb, te, segloss, lane, j);
+  if (have) {
+    double* p = a.part + ((int64_t)seg * a.nsup + sup) * PSTRIDE;
+    if (GRAD) {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) *reinterpret_cast<double2*>(p + i * 2 * G + 2 * j) = g.v[i];
+    }
+    if (j == 0) p[KP] = J;
+  }
+}
+
+// After pass 1: reduce the partials in super-tile order, J_old = loss + r(y), first trial point.
+template <int G, int R>
+__global__ void __launch_bounds__(256) col_reduce_kernel(const TiledArgs a) {
+  constexpr int KP = G * R, NGW = 64 / G, PSTRIDE = KP + 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % G, gi = lane / G;
+  const int64_t seg = ((int64_t)blockIdx.x * 4 + wave) * NGW + gi;
+  if (seg >= a.nseg) return; // group-uniform
+  const int64_t gseg = a.own_offset + seg;
+  Vec<G, R> g, y, yn;
+  double J = 0.0;
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) g.v[i] = make_double2(0.0, 0.0);
+  for (int s = 0; s < a.nsup; ++s) {
+    const double* p = a.part + ((int64_t)seg * a.nsup + s) * PSTRIDE;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      const double2 v = *reinterpret_cast<const double2*>(p + i * 2 * G + 2 * j);
+      g.v[i].x += v.x;
+      g.v[i].y += v.y;
+    }
+    J += p[KP];
+  }
+  if (a.eval_only) {
+    if (j == 0 && a.obj) a.obj[gseg] = J;
+    return;
+  }
+  const double2* yp = reinterpret_cast<const double2*>(a.own + gseg * KP);
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) y.v[i] = yp[i * G + j];
+  const RegDesc rd = load_reg(a.regs, a.reg_single ? 0 : seg);
+  const double Jold = J + reg_eval<G, R>(rd, y, j, a.k);
+  const double alpha = a.alpha[seg];
+  const double l = (double)(a.ptr[seg + 1] - a.ptr[seg]) + 1.0;
+  const bool searching = alpha > a.min_stepsize;
+  const double s = alpha / l;
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) {
+    yn.v[i].x = fma(-s, g.v[i].x, y.v[i].x);
+    yn.v[i].y = fma(-s, g.v[i].y, y.v[i].y);
+  }
+  reg_prox<G, R>(rd, yn, s, j, a.k);
+  double2* gp = reinterpret_cast<double2*>(a.gsum + seg * (int64_t)KP);
+  double2* tp = reinterpret_cast<double2*>(a.trial + seg * (int64_t)KP);
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) {
+    gp[i * G + j] = g.v[i];
+    tp[i * G + j] = yn.v[i];
+  }
+  if (j == 0) {
+    a.jold[seg] = Jold;
+    a.active[seg] = searching ? 1 : 0;
+    a.ntrial[seg] = 0;
+    if (a.obj) a.obj[gseg] = Jold;
+    if (searching) atomicAdd(a.nactive, 1u);
+  }
+}
+
+// After a trial pass: J' = sum of partial losses + r(y'); accept / shrink / give up; next trial point.
+template <int G, int R>
+__global__ void __launch_bounds__(256) col_decide_kernel(const TiledArgs a) {
+  constexpr int KP = G * R, NGW = 64 / G, PSTRIDE = KP + 2;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % G, gi = lane / G;
+  const int64_t seg = ((int64_t)blockIdx.x * 4 + wave) * NGW + gi;
+  if (seg >= a.nseg) return;
+  if (a.active[seg] == 0) return; // group-uniform
+  const int64_t gseg = a.own_offset + seg;
+  double Jn = 0.0;
+  for (int s = 0; s < a.nsup; ++s) Jn += a.part[((int64_t)seg * a.nsup + s) * PSTRIDE + KP];
+  Vec<G, R> y, yn, g;
+  double2* yp = reinterpret_cast<double2*>(a.own + gseg * KP);
+  double2* tp = reinterpret_cast<double2*>(a.trial + seg * (int64_t)KP);
+  const double2* gp = reinterpret_cast<const double2*>(a.gsum + seg * (int64_t)KP);
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) yn.v[i] = tp[i * G + j];
+  const RegDesc rd = load_reg(a.regs, a.reg_single ? 0 : seg);
+  Jn += reg_eval<G, R>(rd, yn, j, a.k);
+  const double Jold = a.jold[seg];
+  double alpha = a.alpha[seg];
+  int still = 0, acc = 0;
+  if (Jn < Jold) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) yp[i * G + j] = yn.v[i];
+    alpha *= 1.05;
+    acc = 1;
+    if (j == 0 && a.obj) a.obj[gseg] = Jn;
+  } else {
+    alpha *= .7;
+    if (alpha < a.min_stepsize) {
+      alpha = a.min_stepsize * 1.1;
+    } else {
+      still = 1;
+      const double l = (double)(a.ptr[seg + 1] - a.ptr[seg]) + 1.0;
+      const double s = alpha / l;
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) {
+        y.v[i] = yp[i * G + j];
+        g.v[i] = gp[i * G + j];
+        yn.v[i].x = fma(-s, g.v[i].x, y.v[i].x);
+        yn.v[i].y = fma(-s, g.v[i].y, y.v[i].y);
+      }
+      reg_prox<G, R>(rd, yn, s, j, a.k);
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) tp[i * G + j] = yn.v[i];
+    }
+  }
+  if (j == 0) {
+    a.alpha[seg] = alpha;
+    a.active[seg] = still;
+    const int nt = a.ntrial[seg] + 1;
+    a.ntrial[seg] = nt;
+    if (still) {
+      atomicAdd(a.nactive, 1u);
+    } else if (a.trials) {
+      a.trials[seg] += nt;
+      a.accepts[seg] += acc;
+    }
+  }
+}
+
+// 1 if idx is non-decreasing inside every segment
+__global__ void check_sorted_kernel(const int64_t* ptr, const int32_t* idx, int64_t nseg, int* unsorted) {
+  const int64_t seg = (int64_t)blockIdx.x;
+  if (seg >= nseg) return;
+  const int64_t b = ptr[seg], e = ptr[seg + 1];
+  int bad = 0;
+  for (int64_t t = b + 1 + threadIdx.x; t < e; t += blockDim.x) bad |= idx[t] < idx[t - 1];
+  if (bad) *unsorted = 1;
+}
+
+} // namespace glrm

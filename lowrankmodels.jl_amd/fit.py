@@ -21,7 +21,7 @@ from .params import AbstractParams, HipProxGradParams, ProxGradParams
 def _engine_opts(params):
     g = lambda k, d: getattr(params, k, d)
     return dict(device_id=g("device_id", -1), profile=1 if g("profile", False) else 0,
-                waves_row=g("waves_row", 0), waves_col=g("waves_col", 0))
+                waves_row=g("waves_row", 0), waves_col=g("waves_col", 0), tiled=g("tiled", 0))
 
 
 def _should_stop(i, prev, obj, scaled_abs_tol, rel_tol):

@@ -45,7 +45,7 @@ def test_c2_full_size_properties(scale):
     ld = api.factor_ld(h)
     assert ld == 32
     st = api.kernel_stats(h)
-    assert st["waves_row"] == 1 and st["waves_col"] == 4
+    assert st["waves_row"] == 1 and st["waves_col"] == 4 and st["tiled"] == 3  # C2 runs on the LDS-tiled sweeps
     dX, dY = w.init_factors(ld)
     dC, dR = torch.zeros(n, dtype=torch.float64, device=dX.device), torch.zeros(m, dtype=torch.float64, device=dX.device)
     api.bind_buffers(h, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())
