@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--waves-row", type=int, default=0)
     ap.add_argument("--waves-col", type=int, default=0)
     ap.add_argument("--tiled", type=int, default=0, help="0 auto, 1 gather sweeps only, 2 LDS-tiled sweeps")
+    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
+                    help="BASELINE.json config family: C2 (default, the bench line), C4 = rank-64 NNMF 0.1 %% observed, "
+                         "C5 = mixed Quad/Logistic/OrdinalHinge columns 2 %% observed (use --rows-per-gpu to scale)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000)
     args = ap.parse_args()
@@ -96,6 +99,15 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=device)
 
+    value_model, loss_mix, reg = 0, 0, (1, 0, 1.0)  # QuadReg(1.0)
+    if args.config == "C4":    # 10M x 100k rank 64, 1e9 observations, NonNegConstraint on X and Y
+        args.cols, args.k, args.obs_per_row, value_model, reg = 100_000, 64, 100, 1, (3, 0, 1.0)
+    elif args.config == "C3":  # 1M x 10k rank 32, fully observed QuadLoss, ZeroReg: the dense MFMA path (single GPU)
+        args.obs_per_row, reg = args.cols, (0, 0, 1.0)
+        if world != 1:
+            raise SystemExit("--config C3 runs on one GPU (the dense hand-over takes the whole matrix)")
+    elif args.config == "C5":  # 5M x 50k rank 32, 2 % observed, Quad/Logistic/OrdinalHinge columns, QuadReg
+        args.cols, args.k, args.obs_per_row, loss_mix = 50_000 - 50_000 % (1000 * 1), 32, 1000, 1
     k, q, n = args.k, args.obs_per_row, args.cols
     m = args.rows_per_gpu * world  # weak scaling in m
     if n % world or n % q:
@@ -105,8 +117,11 @@ def main():
 
     api = _capi.hip_api()
     t_gen = time.time()
-    w = synth.DeviceWorkload(m, n, k, q, rows=(rbs[rank], rbs[rank + 1]), cols=(cbs[rank], cbs[rank + 1]), seed=args.seed,
-                             rx=(1, 0, 1.0), ry=(1, 0, 1.0), device=device)
+    if args.config == "C3":
+        w = synth.DenseDeviceWorkload(m, n, k, seed=args.seed, rx=reg, ry=reg, device=device)
+    else:
+        w = synth.DeviceWorkload(m, n, k, q, rows=(rbs[rank], rbs[rank + 1]), cols=(cbs[rank], cbs[rank + 1]), seed=args.seed,
+                                 value_model=value_model, loss_mix=loss_mix, rx=reg, ry=reg, device=device)
     t_gen = time.time() - t_gen
     t_create = time.time()
     sf = ShardedFit(api, w.problem(), rbs, cbs, device=device, stream=torch.cuda.current_stream().cuda_stream,
@@ -178,8 +193,10 @@ def main():
             "metric": "observed-entry updates/sec", "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1] (C2): {m} x {n}, rank {k}, QuadLoss, {100.0 * q / n:.3g}% observed "
-                                   f"({tot_r} observations), QuadReg(1.0) on X and Y, ProxGradParams defaults, stop rule off",
+            "config": {"workload": (f"BASELINE configs[1] (C2): {m} x {n}, rank {k}, QuadLoss, {100.0 * q / n:.3g}% observed "
+                                    f"({tot_r} observations), QuadReg(1.0) on X and Y, ProxGradParams defaults, stop rule off")
+                       if args.config == "C2" else f"{args.config}-family: {m} x {n}, rank {k}, {tot_r} observations, "
+                       f"{'NonNegConstraint' if reg[0] == 3 else 'QuadReg(1.0)'} on X and Y, {'mixed Quad/Logistic/OrdinalHinge' if loss_mix else 'QuadLoss'}",
                        "m": m, "n": n, "k": k, "observed": tot_r, "parallelism": f"rows/cols sharded over {world} GPU(s), X,Y replicated",
                        "waves_row": st["waves_row"], "waves_col": st["waves_col"],
                        "row_sweep": "lds-tiled" if tiled_row else "gather", "col_sweep": "lds-tiled" if tiled_col else "gather"},
@@ -197,7 +214,7 @@ def main():
             "objective": {"initial": obj0, "after_warmup_and_steps": objs[-1] if objs else None},
             "setup_s": {"generate": t_gen, "create": t_create},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "C2":
             out["cpu_baseline"] = cpu_baseline(args, k, q, n)
         print(json.dumps(out), flush=True)
     sf.close()

@@ -118,6 +118,14 @@ typedef struct glrm_problem {
   int64_t n_rx;               /* 1 (every row alike) or row_end-row_begin */
   const glrm_reg* ry;
   int64_t n_ry;               /* 1 or col_end-col_begin */
+  /* Fully observed QuadLoss case (every (e,f) observed, one QuadLoss descriptor): hand over the whole dense
+   * m x n matrix instead of the two index lists (rowptr..colvals must then be NULL).  The engine keeps a
+   * row-major copy of the shard's rows and a column-major copy of its columns and runs the half-steps on the
+   * fp64 matrix cores.  GLRM_PROBLEM_DEVICE_ARRAYS applies to dense_A as well. */
+  const double* dense_A;      /* NULL = sparse (list) problem */
+  int64_t dense_ld;           /* leading dimension in elements */
+  int32_t dense_colmajor;     /* 1: A(i,j) = dense_A[i + j*dense_ld] (Julia), 0: dense_A[i*dense_ld + j] (C / numpy) */
+  int32_t dense_reserved;     /* must be 0 */
 } glrm_problem;
 
 /* ProxGradParams, src/algorithms/proxgrad.jl:4-12 (inner_iter already merged, :22-23). */
@@ -204,7 +212,8 @@ typedef struct glrm_kernel_stats {
   int64_t accepts_x, accepts_y;
   int64_t nnz_rows, nnz_cols;  /* |Omega| of the local CSR / CSC */
   int32_t waves_row, waves_col, ld;
-  int32_t tiled;               /* bit0: LDS-tiled row sweep in use, bit1: LDS-tiled column sweep in use */
+  int32_t tiled;               /* bit0: LDS-tiled row sweep in use, bit1: LDS-tiled column sweep in use,
+                                  bit2: dense MFMA path in use */
 } glrm_kernel_stats;
 
 int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int reset);

@@ -110,6 +110,9 @@ int glrm_synth_hip_col_counts(const glrm_synth_spec* s, int64_t col_begin, int64
 int glrm_synth_hip_cols(const glrm_synth_spec* s, int64_t col_begin, int64_t col_end, const int64_t* colptr,
                         int32_t* rowidx, double* vals, void* stream);
 int glrm_synth_hip_init(const glrm_synth_spec* s, uint64_t init_seed, int ld, double* X, double* Y, void* stream);
+/* dense block: rows [row_begin,row_end) x n, row-major with leading dimension ld; scratch_xs (rows*k) and scratch_ys (n*k) doubles */
+int glrm_synth_hip_dense(const glrm_synth_spec* s, int64_t row_begin, int64_t row_end, double* A, int64_t ld,
+                         double* scratch_xs, double* scratch_ys, void* stream);
 const char* glrm_synth_hip_last_error(void);
 
 #ifdef __cplusplus

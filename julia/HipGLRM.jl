@@ -26,6 +26,7 @@ struct CProblem
     rowptr::Ptr{Int64}; colidx::Ptr{Int32}; rowvals::Ptr{Float64}
     colptr::Ptr{Int64}; rowidx::Ptr{Int32}; colvals::Ptr{Float64}
     losses::Ptr{CLoss}; n_losses::Int64; rx::Ptr{CReg}; n_rx::Int64; ry::Ptr{CReg}; n_ry::Int64
+    dense_A::Ptr{Float64}; dense_ld::Int64; dense_colmajor::Int32; dense_reserved::Int32
 end
 struct CParams
     stepsize::Float64; max_iter::Int64; inner_iter_X::Int64; inner_iter_Y::Int64
@@ -98,7 +99,7 @@ function fit!(glrm::GLRM, p::HipProxGradParams; ch::ConvergenceHistory=Convergen
     GC.@preserve losses rx ry rowptr colidx rowvals colptr rowidx colvals X Y obj sec begin
         prob = CProblem(m, n, k, 0, 0, m, 0, n, pointer(rowptr), pointer(colidx), pointer(rowvals),
                         pointer(colptr), pointer(rowidx), pointer(colvals), pointer(losses), n,
-                        pointer(rx), m, pointer(ry), n)
+                        pointer(rx), m, pointer(ry), n, C_NULL, 0, 0, 0)
         opt = COptions(p.device_id, 0, 0, 0, C_NULL, 0, 0)
         check(ccall((:glrm_hip_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{CProblem}, Ref{COptions}), h, prob, opt))
         try

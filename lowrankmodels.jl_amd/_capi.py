@@ -49,6 +49,7 @@ class CProblem(C.Structure):
         ("losses", C.c_void_p), ("n_losses", C.c_int64),
         ("rx", C.c_void_p), ("n_rx", C.c_int64),
         ("ry", C.c_void_p), ("n_ry", C.c_int64),
+        ("dense_A", C.c_void_p), ("dense_ld", C.c_int64), ("dense_colmajor", C.c_int32), ("dense_reserved", C.c_int32),
     ]
 
 
@@ -99,6 +100,7 @@ class Api:
 
     def __init__(self, lib: C.CDLL, prefix: str, device_type: str):
         self.lib, self.prefix, self.device_type = lib, prefix, device_type
+        self.dense_ok = prefix == "glrm_hip_"  # the dense (matrix-core) hand-over exists in the HIP engine only
         H = C.c_void_p
         sig = {
             "version": (C.c_int, []),
@@ -153,6 +155,10 @@ class Api:
         p.losses, p.n_losses = _ptr(prob.losses), len(prob.losses)
         p.rx, p.n_rx = _ptr(prob.rx), len(prob.rx)
         p.ry, p.n_ry = _ptr(prob.ry), len(prob.ry)
+        if prob.dense_A is not None:
+            if not self.dense_ok:
+                raise GLRMError(ERR_UNSUPPORTED, "this engine takes observation lists only")
+            p.dense_A, p.dense_ld, p.dense_colmajor, p.dense_reserved = _ptr(prob.dense_A), prob.dense_ld, prob.dense_colmajor, 0
         o = COptions(device_id, profile, waves_row, waves_col, (stream or None), 0 if stream is None else 1, tiled)
         h = C.c_void_p()
         self._ck(self._f["create"](C.byref(h), C.byref(p), C.byref(o)))
@@ -231,13 +237,15 @@ class ProblemArrays:
     """Plain container for one shard in the ABI's layout (0-based, CSR + CSC, descriptors)."""
 
     def __init__(self, m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, losses, rx, ry,
-                 row_begin=0, row_end=None, col_begin=0, col_end=None, flags=0):
+                 row_begin=0, row_end=None, col_begin=0, col_end=None, flags=0, dense_A=None, dense_ld=0, dense_colmajor=0):
         self.m, self.n, self.k, self.flags = int(m), int(n), int(k), int(flags)
         self.row_begin, self.row_end = int(row_begin), int(m if row_end is None else row_end)
         self.col_begin, self.col_end = int(col_begin), int(n if col_end is None else col_end)
         self.rowptr, self.colidx, self.rowvals = rowptr, colidx, rowvals
         self.colptr, self.rowidx, self.colvals = colptr, rowidx, colvals
         self.losses, self.rx, self.ry = losses, rx, ry  # numpy structured arrays (LOSS_DTYPE / REG_DTYPE)
+        # fully observed QuadLoss hand-over: the whole m x n matrix (numpy array or device address) instead of lists
+        self.dense_A, self.dense_ld, self.dense_colmajor = dense_A, int(dense_ld), int(dense_colmajor)
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))

@@ -1,0 +1,173 @@
+// glrm_dense.hip -- host side of the fully observed QuadLoss path on the fp64 matrix cores
+// (kernels in glrm_dense.hpp; line-search bookkeeping kernels shared with glrm_tiled.hpp).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "glrm_engine.hpp"
+#include "glrm_tiled.hpp"
+#include "glrm_dense.hpp"
+
+using namespace glrm;
+
+static int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
+
+// super-tiles over the opposing dimension: a function of that dimension only (never of the shard layout),
+// so the partial-sum order -- and therefore the result bits -- do not depend on the number of GPUs
+static void pick_sup(int64_t n_other, int& nsup, int64_t& vps) {
+  int64_t s = (n_other + 32767) / 32768;
+  if (s < 1) s = 1;
+  if (s > 32) s = 32;
+  vps = round_up((n_other + s - 1) / s, DENSE_TN);
+  nsup = (int)((n_other + vps - 1) / vps);
+}
+
+static int pack_view(glrm_handle* h, const double* dsrc, int64_t ldsrc, int colmajor, int transpose, int64_t seg0,
+                     int64_t nseg, int64_t nother, double** dst, int64_t* lda) {
+  const int64_t nseg_pad = round_up(nseg > 0 ? nseg : 1, 64);
+  *lda = round_up(nother, 64);
+  HIPCK(hipMalloc((void**)dst, (size_t)nseg_pad * (size_t)*lda * 8));
+  const dim3 grid((unsigned)(*lda / 32), (unsigned)(nseg_pad / 32));
+  hipLaunchKernelGGL(dense_pack_kernel, grid, dim3(256), 0, h->stream, dsrc, ldsrc, colmajor, transpose, seg0, nseg, nother, *dst, *lda);
+  HIPCK(hipGetLastError());
+  return GLRM_OK;
+}
+
+template <typename T>
+static int alloc_arr(T** p, int64_t count) {
+  HIPCK(hipMalloc((void**)p, (size_t)(count > 0 ? count : 1) * sizeof(T)));
+  return GLRM_OK;
+}
+
+int glrm_setup_dense(glrm_handle* h, const glrm_problem* p) {
+  if (p->rowptr || p->colidx || p->rowvals || p->colptr || p->rowidx || p->colvals)
+    return fail(GLRM_ERR_INVALID, "dense_A and the observation lists are mutually exclusive");
+  if (p->dense_reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_problem.dense_reserved must be 0");
+  if (!(p->n_losses == 1 && p->losses[0].kind == GLRM_LOSS_QUAD))
+    return fail(GLRM_ERR_UNSUPPORTED, "the dense path needs one QuadLoss descriptor for all columns; pass observation lists otherwise");
+  if (!(h->kp == 16 || h->kp == 32 || h->kp == 64))
+    return fail(GLRM_ERR_UNSUPPORTED, "the dense path supports ranks 9..64; pass observation lists otherwise");
+  const int64_t need_ld = p->dense_colmajor ? p->m : p->n;
+  if (p->dense_ld < need_ld) return fail(GLRM_ERR_INVALID, "dense_ld is smaller than the matrix dimension");
+  h->dense = true;
+  h->dense_scale = p->losses[0].scale;
+  h->nnz_r = h->ml * h->n;
+  h->nnz_c = h->nl * h->m;
+  // bring the caller's matrix to the device if needed
+  const double* dsrc = p->dense_A;
+  double* tmp = nullptr;
+  if (!(p->flags & GLRM_PROBLEM_DEVICE_ARRAYS)) {
+    const size_t rows = p->dense_colmajor ? (size_t)p->n : (size_t)p->m; // number of contiguous runs
+    const size_t run = p->dense_colmajor ? (size_t)p->m : (size_t)p->n;
+    for (size_t r = 0; r < rows; ++r)
+      for (size_t c = 0; c < run; ++c)
+        if (std::isnan(p->dense_A[r * (size_t)p->dense_ld + c])) {
+          const size_t i = p->dense_colmajor ? c : r, j = p->dense_colmajor ? r : c;
+          return fail(GLRM_ERR_NONFINITE, "Observed value in entry (%zu, %zu) is NaN.", i, j);
+        }
+    HIPCK(hipMalloc((void**)&tmp, rows * run * 8));
+    HIPCK(hipMemcpy2DAsync(tmp, run * 8, p->dense_A, (size_t)p->dense_ld * 8, run * 8, rows, hipMemcpyHostToDevice, h->stream));
+    dsrc = tmp;
+  }
+  const int64_t ldsrc = (p->flags & GLRM_PROBLEM_DEVICE_ARRAYS) ? p->dense_ld : (p->dense_colmajor ? p->m : p->n);
+  int rc = pack_view(h, dsrc, ldsrc, p->dense_colmajor, 0, h->rb, h->ml, h->n, &h->Arow, &h->lda_r);
+  if (!rc) rc = pack_view(h, dsrc, ldsrc, p->dense_colmajor, 1, h->cb, h->nl, h->m, &h->Acol, &h->lda_c);
+  if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(GLRM_ERR_HIP, "dense pack failed");
+  if (tmp) (void)hipFree(tmp);
+  if (rc) return rc;
+  pick_sup(h->n, h->nsup_r, h->vps_r);
+  pick_sup(h->m, h->nsup_c, h->vps_c);
+  const int64_t ml1 = h->ml > 0 ? h->ml : 1, nl1 = h->nl > 0 ? h->nl : 1;
+  const int ps = h->kp + 2;
+  if ((rc = alloc_arr(&h->part_r, ml1 * h->nsup_r * ps))) return rc;
+  if ((rc = alloc_arr(&h->gsum_r, ml1 * h->kp))) return rc;
+  if ((rc = alloc_arr(&h->trial_r, ml1 * h->kp))) return rc;
+  if ((rc = alloc_arr(&h->jold_r, ml1))) return rc;
+  if ((rc = alloc_arr(&h->active_r, ml1))) return rc;
+  if ((rc = alloc_arr(&h->ntrial_r, ml1))) return rc;
+  if ((rc = alloc_arr(&h->part, nl1 * h->nsup_c * ps))) return rc;
+  if ((rc = alloc_arr(&h->gsum, nl1 * h->kp))) return rc;
+  if ((rc = alloc_arr(&h->trialbuf, nl1 * h->kp))) return rc;
+  if ((rc = alloc_arr(&h->joldbuf, nl1))) return rc;
+  if ((rc = alloc_arr(&h->activebuf, nl1))) return rc;
+  if ((rc = alloc_arr(&h->ntrialbuf, nl1))) return rc;
+  if ((rc = alloc_arr(&h->nactive, 1))) return rc;
+  return GLRM_OK;
+}
+
+template <int KP>
+static void launch_dense_pass(bool grad, const DenseArgs& a, hipStream_t st) {
+  const dim3 grid((unsigned)((a.nseg + 63) / 64), (unsigned)a.nsup);
+  if (grad) hipLaunchKernelGGL((dense_pass_kernel<KP, true>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((dense_pass_kernel<KP, false>), grid, dim3(256), 0, st, a);
+}
+
+static void launch_dense_any(int kp, bool grad, const DenseArgs& a, hipStream_t st) {
+  switch (kp) {
+    case 16: launch_dense_pass<16>(grad, a, st); break;
+    case 32: launch_dense_pass<32>(grad, a, st); break;
+    default: launch_dense_pass<64>(grad, a, st); break;
+  }
+}
+
+// One half-step on the dense path: pass 1 (residuals, objective, gradient on the matrix cores) -> per-segment
+// reduce + first trial point -> rounds of (trial objective pass, decide) until no segment is still searching.
+int glrm_run_dense(glrm_handle* h, bool rows, double min_stepsize, int eval_only) {
+  const int64_t nseg = rows ? h->ml : h->nl;
+  if (nseg <= 0) return GLRM_OK;
+  DenseArgs d{};
+  d.nseg = nseg;
+  d.xsrc = rows ? h->X : h->Y;
+  d.own_offset = rows ? h->rb : h->cb;
+  d.other = rows ? h->Y : h->X;
+  d.n_other = rows ? h->n : h->m;
+  d.A = rows ? h->Arow : h->Acol;
+  d.lda = rows ? h->lda_r : h->lda_c;
+  d.scale = h->dense_scale;
+  d.nsup = rows ? h->nsup_r : h->nsup_c;
+  d.vec_per_sup = rows ? h->vps_r : h->vps_c;
+  d.part = rows ? h->part_r : h->part;
+  d.active = rows ? h->active_r : h->activebuf;
+  TiledArgs a{};
+  a.nseg = nseg;
+  a.ptr = nullptr;
+  a.dense_len = d.n_other;
+  a.own = rows ? h->X : h->Y;
+  a.own_offset = d.own_offset;
+  a.alpha = rows ? h->alpharow : h->alphacol;
+  a.obj = rows ? nullptr : h->objcol;
+  a.regs = rows ? h->rx : h->ry;
+  a.reg_single = (rows ? h->n_rx : h->n_ry) == 1;
+  a.k = h->k;
+  a.min_stepsize = min_stepsize;
+  a.trials = rows ? h->trials_r : h->trials_c;
+  a.accepts = rows ? h->accepts_r : h->accepts_c;
+  a.nsup = d.nsup;
+  a.part = d.part;
+  a.gsum = rows ? h->gsum_r : h->gsum;
+  a.trial = rows ? h->trial_r : h->trialbuf;
+  a.jold = rows ? h->jold_r : h->joldbuf;
+  a.active = rows ? h->active_r : h->activebuf;
+  a.ntrial = rows ? h->ntrial_r : h->ntrialbuf;
+  a.nactive = h->nactive;
+  a.eval_only = eval_only;
+  HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
+  launch_dense_any(h->kp, true, d, h->stream);
+  glrm_launch_col_small(h->kp, 0, a, h->stream);
+  HIPCK(hipGetLastError());
+  if (eval_only) return GLRM_OK;
+  DenseArgs t = d;
+  t.xsrc = a.trial; // trial points are stored per local segment
+  t.own_offset = 0;
+  for (int round = 0; round < 64; ++round) {
+    unsigned int nact = 0;
+    HIPCK(hipMemcpyAsync(&nact, h->nactive, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    if (nact == 0) break;
+    HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
+    launch_dense_any(h->kp, false, t, h->stream);
+    glrm_launch_col_small(h->kp, 1, a, h->stream);
+    HIPCK(hipGetLastError());
+  }
+  return GLRM_OK;
+}

@@ -1,0 +1,175 @@
+// glrm_dense.hpp -- fully observed QuadLoss case on the fp64 matrix cores (v_mfma_f64_16x16x4_f64).
+//
+// When every entry of A is observed and every column carries QuadLoss(scale), the half-step of a block of
+// segments is two chained GEMMs (src/algorithms/proxgrad.jl:122-135 / :165-178 in matrix form):
+//     R = X_b' Y - A_b            (b x n)      residuals
+//     J_e = s * sum_c R[e,c]^2                 row objective (evaluate_fit.jl:24-38 restricted to Quad)
+//     G_b = 2 s * R Y'            (b x k)      gradient
+// XY is never materialised (the reference allocates it, proxgrad.jl:65-66): a wave owns 16 segments, walks the
+// opposing factor in 16-vector tiles staged through LDS, forms the 16x16 residual tile with k/4 MFMAs, subtracts
+// A (streamed once per pass, 32 contiguous bytes per lane), accumulates J, and feeds the residual tile straight
+// back as the A-operand of the second GEMM (k/16 x 4 MFMAs) -- the D layout of the first product IS the A-operand
+// layout of the second when the first computes R' (tile index <-> opposing vector, j <-> segment).
+//
+// MFMA operand maps (cdna_hip_programming.md section 3): A[i = lane&15][kk = lane>>4], B[kk = lane>>4][j = lane&15],
+// D[i = (lane>>4) + 4*reg][j = lane&15].
+//   GEMM1: i = tile index of the opposing vector, j = segment e:  D1[i][e] = sum_kk Y[kk][col(i)] * X[kk][e]
+//   GEMM2: i = segment e, kk = tile index inside slab r (i1 = kk + 4r), j = component:
+//          D2[e][comp] += sum_kk R[e][col(kk + 4r)] * Y[comp][col(kk + 4r)]
+// col(cq + 4r) = 4*cq + r, so the four residuals a lane holds are four CONTIGUOUS entries of its A row.
+//
+// The line search (trial passes, accept / shrink) reuses col_reduce_kernel / col_decide_kernel of glrm_tiled.hpp.
+#pragma once
+
+#include "glrm_device.hpp"
+
+namespace glrm {
+
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+struct DenseArgs {
+  int64_t nseg;         // local segments (rows of the packed A block)
+  const double* xsrc;   // GRAD: the factor being updated (global array, ld KP, segment s at (own_offset+s)*KP);
+                        // !GRAD: the trial points ([nseg][KP], own_offset = 0)
+  int64_t own_offset;
+  const double* other;  // opposing factor (global array, ld KP)
+  int64_t n_other;      // opposing vectors
+  const double* A;      // packed block: A[s * lda + c], s in [0, nseg_pad), c in [0, lda), zero padded
+  int64_t lda;
+  double scale;         // QuadLoss scale
+  int nsup;             // super-tiles over the opposing dimension
+  int64_t vec_per_sup;  // opposing vectors per super-tile (multiple of TN)
+  double* part;         // [nseg][nsup][KP+2]
+  const int32_t* active; // !GRAD: skip waves without an active segment
+};
+
+constexpr int DENSE_TN = 64; // opposing vectors staged per barrier
+
+template <int KP>
+constexpr int dense_row_bytes() { return KP * 8 + 16; }
+
+template <int KP, bool GRAD>
+__global__ void __launch_bounds__(256) dense_pass_kernel(const DenseArgs a) {
+  constexpr int ROWB = dense_row_bytes<KP>(), PSTRIDE = KP + 2, NQ = KP / 4, NCB = KP / 16;
+  __shared__ __attribute__((aligned(16))) char lds[DENSE_TN * ROWB];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e = lane & 15, cq = lane >> 4;
+  const int64_t seg0 = (int64_t)blockIdx.x * 64 + wave * 16;
+  const int sup = blockIdx.y;
+  const int64_t seg = seg0 + e;
+  const bool have = seg < a.nseg;
+  bool wave_active = true;
+  if constexpr (!GRAD) {
+    const int act = have ? a.active[seg] : 0;
+    wave_active = __any(act != 0);
+  }
+  // B operands of GEMM1: X[kk = 4q + cq][e]
+  double xb[NQ];
+  const double* xp = a.xsrc + (a.own_offset + (have ? seg : 0)) * KP;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) xb[q] = have ? xp[4 * q + cq] : 0.0;
+  f64x4 acc[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb) acc[cb] = f64x4{0.0, 0.0, 0.0, 0.0};
+  double J = 0.0;
+
+  const int64_t v0 = (int64_t)sup * a.vec_per_sup;
+  const int64_t v1 = v0 + a.vec_per_sup < a.n_other ? v0 + a.vec_per_sup : a.n_other;
+  const double* arow = a.A + seg * a.lda; // rows are padded to a multiple of 64: always in bounds
+  const int i1 = lane & 15;               // GEMM1 A-operand: tile index i -> local vector 4*(i&3) + (i>>2)
+  const int vloc1 = 4 * (i1 & 3) + (i1 >> 2);
+
+  for (int64_t t0 = v0; t0 < v1; t0 += DENSE_TN) {
+    __syncthreads();
+    { // stage DENSE_TN opposing vectors (zero beyond n_other), padded rows
+      const char* src = reinterpret_cast<const char*>(a.other) + t0 * (KP * 8);
+      const int64_t valid = (a.n_other - t0) * (KP * 8);
+      for (int off = threadIdx.x * 16; off < DENSE_TN * KP * 8; off += 256 * 16) {
+        double2 v = make_double2(0.0, 0.0);
+        if (off < valid) v = *reinterpret_cast<const double2*>(src + off);
+        const int row = off / (KP * 8), col = off - row * (KP * 8);
+        *reinterpret_cast<double2*>(lds + row * ROWB + col) = v;
+      }
+    }
+    __syncthreads();
+    if (!wave_active) continue;
+#pragma unroll 1
+    for (int ct = 0; ct < DENSE_TN / 16; ++ct) {
+      // the lane's four A entries: A[seg][t0 + ct*16 + 4*cq + (0..3)]
+      const double2* ap = reinterpret_cast<const double2*>(arow + t0 + ct * 16 + 4 * cq);
+      const double2 a01 = ap[0], a23 = ap[1];
+      // GEMM1: residual tile (transposed) = Y_tile' X
+      f64x4 d = f64x4{0.0, 0.0, 0.0, 0.0};
+      const char* y1 = lds + (ct * 16 + vloc1) * ROWB + cq * 8;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const double ya = *reinterpret_cast<const double*>(y1 + q * 32);
+        d = __builtin_amdgcn_mfma_f64_16x16x4f64(ya, xb[q], d, 0, 0, 0);
+      }
+      const double r0 = d[0] - a01.x, r1 = d[1] - a01.y, r2 = d[2] - a23.x, r3 = d[3] - a23.y;
+      J = fma(r0, r0, J);
+      J = fma(r1, r1, J);
+      J = fma(r2, r2, J);
+      J = fma(r3, r3, J);
+      if constexpr (GRAD) {
+        // GEMM2: G += R Y_tile'; slab r uses local vectors 4*cq + r
+        const char* y2 = lds + (ct * 16 + 4 * cq) * ROWB + (lane & 15) * 8;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(r0, *reinterpret_cast<const double*>(y2 + 0 * ROWB + cb * 128), acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(r1, *reinterpret_cast<const double*>(y2 + 1 * ROWB + cb * 128), acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(r2, *reinterpret_cast<const double*>(y2 + 2 * ROWB + cb * 128), acc[cb], 0, 0, 0);
+          acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(r3, *reinterpret_cast<const double*>(y2 + 3 * ROWB + cb * 128), acc[cb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (!wave_active) return;
+  // J of segment e: add the four cq partials (lanes e, e+16, e+32, e+48)
+  J += __shfl_xor(J, 16, 64);
+  J += __shfl_xor(J, 32, 64);
+  if (have && cq == 0) a.part[((int64_t)seg * a.nsup + sup) * PSTRIDE + KP] = a.scale * J;
+  if constexpr (GRAD) {
+    // D2[i = segment (cq + 4r)][j = component 16cb + e]
+    const double two_s = 2 * a.scale;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t s2 = seg0 + cq + 4 * r;
+        if (s2 < a.nseg) a.part[((int64_t)s2 * a.nsup + sup) * PSTRIDE + cb * 16 + e] = two_s * acc[cb][r];
+      }
+    }
+  }
+}
+
+// Pack a block of the caller's dense matrix into the padded row-major layout the pass kernel streams:
+//   dst[s * lda + c] = A(seg0 + s, c)  for the row view   (transpose = 0)
+//   dst[s * lda + c] = A(c, seg0 + s)  for the column view (transpose = 1)
+// A(i,j) = src[i + j*ldsrc] if colmajor else src[i*ldsrc + j].  32x32 tiles through LDS keep both sides coalesced.
+__global__ void __launch_bounds__(256) dense_pack_kernel(const double* src, int64_t ldsrc, int colmajor, int transpose,
+                                                         int64_t seg0, int64_t nseg, int64_t nother, double* dst, int64_t lda) {
+  __shared__ double tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+  const int64_t s0 = (int64_t)blockIdx.y * 32, c0 = (int64_t)blockIdx.x * 32;
+  // element (s, c) of dst comes from A(i, j) with (i, j) = transpose ? (c, seg0+s) : (seg0+s, c)
+  // read side: make the fastest-varying source index follow tx
+  const bool src_fast_is_c = transpose ? (colmajor != 0) : (colmajor == 0); // source contiguous along c?
+  for (int yy = ty; yy < 32; yy += 8) {
+    int64_t s, c;
+    if (src_fast_is_c) { s = s0 + yy; c = c0 + tx; } else { s = s0 + tx; c = c0 + yy; }
+    double v = 0.0;
+    if (s < nseg && c < nother) {
+      const int64_t i = transpose ? c : seg0 + s, j = transpose ? seg0 + s : c;
+      v = colmajor ? src[i + j * ldsrc] : src[i * ldsrc + j];
+    }
+    if (src_fast_is_c) tile[yy][tx] = v; else tile[tx][yy] = v; // tile[s_local][c_local]
+  }
+  __syncthreads();
+  for (int yy = ty; yy < 32; yy += 8) {
+    const int64_t s = s0 + yy, c = c0 + tx;
+    if (c < lda) dst[s * lda + c] = tile[yy][tx]; // dst rows are allocated up to a multiple of 64 >= nseg
+  }
+}
+
+} // namespace glrm

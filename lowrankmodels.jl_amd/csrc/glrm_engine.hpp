@@ -49,6 +49,15 @@ struct glrm_handle {
   int32_t *activebuf = nullptr, *ntrialbuf = nullptr;
   unsigned int* nactive = nullptr;
   int* dflag = nullptr;
+  // dense MFMA path (glrm_dense.hip)
+  bool dense = false;
+  double *Arow = nullptr, *Acol = nullptr; // packed, zero padded: [ml_pad][lda_r], [nl_pad][lda_c]
+  int64_t lda_r = 0, lda_c = 0;
+  double dense_scale = 1.0;
+  int nsup_r = 1, nsup_c = 1;
+  int64_t vps_r = 0, vps_c = 0;           // opposing vectors per super-tile
+  double *part_r = nullptr, *gsum_r = nullptr, *trial_r = nullptr, *jold_r = nullptr;
+  int32_t *active_r = nullptr, *ntrial_r = nullptr;
   int64_t rb = 0, re = 0, cb = 0, ce = 0, ml = 0, nl = 0, nnz_r = 0, nnz_c = 0;
   int64_t *rowptr = nullptr, *colptr = nullptr;
   int32_t *colidx = nullptr, *rowidx = nullptr;
@@ -82,3 +91,11 @@ inline int env_int(const char* name, int dflt) {
 // LDS-tiled sweeps (glrm_tiled.hip)
 int glrm_setup_tiled(glrm_handle* h);
 int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only);
+
+// dense MFMA path (glrm_dense.hip)
+int glrm_setup_dense(glrm_handle* h, const glrm_problem* p);
+int glrm_run_dense(glrm_handle* h, bool rows, double min_stepsize, int eval_only);
+
+// per-segment reduce (which = 0) / decide (which = 1) kernels of glrm_tiled.hpp for a kp-wide factor
+namespace glrm { struct TiledArgs; }
+void glrm_launch_col_small(int kp, int which, const glrm::TiledArgs& a, hipStream_t st);

@@ -465,7 +465,8 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
   void* ptrs[] = {h->rowptr, h->colptr, h->colidx, h->rowidx, h->rowvals, h->colvals, h->losses, h->rx, h->ry,
                   h->alpharow, h->alphacol, h->oX, h->oY, h->oobjcol, h->oobjrow, h->partials, h->dscalar, h->dcount,
                   h->trials_r, h->accepts_r, h->trials_c, h->accepts_c, h->part, h->gsum, h->trialbuf, h->joldbuf,
-                  h->activebuf, h->ntrialbuf, h->nactive, h->dflag};
+                  h->activebuf, h->ntrialbuf, h->nactive, h->dflag, h->Arow, h->Acol, h->part_r, h->gsum_r, h->trial_r,
+                  h->jold_r, h->active_r, h->ntrial_r};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : h->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -493,20 +494,22 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   }
   hipStream_t st = h->stream;
   int rc;
-  if ((rc = dev_copy_in(&h->rowptr, p->rowptr, h->ml + 1, on_dev, st))) return rc;
-  if ((rc = dev_copy_in(&h->colptr, p->colptr, h->nl + 1, on_dev, st))) return rc;
-  if (on_dev) {
-    HIPCK(hipMemcpyAsync(&h->nnz_r, p->rowptr + h->ml, 8, hipMemcpyDeviceToHost, st));
-    HIPCK(hipMemcpyAsync(&h->nnz_c, p->colptr + h->nl, 8, hipMemcpyDeviceToHost, st));
-    HIPCK(hipStreamSynchronize(st));
-  } else {
-    h->nnz_r = p->rowptr[h->ml];
-    h->nnz_c = p->colptr[h->nl];
+  if (!p->dense_A) {
+    if ((rc = dev_copy_in(&h->rowptr, p->rowptr, h->ml + 1, on_dev, st))) return rc;
+    if ((rc = dev_copy_in(&h->colptr, p->colptr, h->nl + 1, on_dev, st))) return rc;
+    if (on_dev) {
+      HIPCK(hipMemcpyAsync(&h->nnz_r, p->rowptr + h->ml, 8, hipMemcpyDeviceToHost, st));
+      HIPCK(hipMemcpyAsync(&h->nnz_c, p->colptr + h->nl, 8, hipMemcpyDeviceToHost, st));
+      HIPCK(hipStreamSynchronize(st));
+    } else {
+      h->nnz_r = p->rowptr[h->ml];
+      h->nnz_c = p->colptr[h->nl];
+    }
+    if ((rc = dev_copy_in(&h->colidx, p->colidx, h->nnz_r, on_dev, st))) return rc;
+    if ((rc = dev_copy_in(&h->rowvals, p->rowvals, h->nnz_r, on_dev, st))) return rc;
+    if ((rc = dev_copy_in(&h->rowidx, p->rowidx, h->nnz_c, on_dev, st))) return rc;
+    if ((rc = dev_copy_in(&h->colvals, p->colvals, h->nnz_c, on_dev, st))) return rc;
   }
-  if ((rc = dev_copy_in(&h->colidx, p->colidx, h->nnz_r, on_dev, st))) return rc;
-  if ((rc = dev_copy_in(&h->rowvals, p->rowvals, h->nnz_r, on_dev, st))) return rc;
-  if ((rc = dev_copy_in(&h->rowidx, p->rowidx, h->nnz_c, on_dev, st))) return rc;
-  if ((rc = dev_copy_in(&h->colvals, p->colvals, h->nnz_c, on_dev, st))) return rc;
   h->n_losses = p->n_losses; h->n_rx = p->n_rx; h->n_ry = p->n_ry;
   if ((rc = dev_copy_in(&h->losses, p->losses, p->n_losses, false, st))) return rc;
   if ((rc = dev_copy_in(&h->rx, p->rx, p->n_rx, false, st))) return rc;
@@ -528,7 +531,7 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   HIPCK(hipMemsetAsync(h->accepts_c, 0, nl1 * 4, st));
   h->waves_row = pick_waves(o ? o->waves_row : 0, h->nnz_r, h->ml);
   h->waves_col = pick_waves(o ? o->waves_col : 0, h->nnz_c, h->nl);
-  int rc2 = glrm_setup_tiled(h);
+  int rc2 = p->dense_A ? glrm_setup_dense(h, p) : glrm_setup_tiled(h);
   if (rc2) return rc2;
   HIPCK(hipStreamSynchronize(st)); // host descriptor / index arrays may be released by the caller now
   return GLRM_OK;
@@ -546,7 +549,9 @@ extern "C" int glrm_hip_create(glrm_handle** out, const glrm_problem* p, const g
     return fail(GLRM_ERR_INVALID, "shard ranges out of bounds");
   int rc = check_desc(p);
   if (rc) return rc;
-  if (!(p->flags & GLRM_PROBLEM_DEVICE_ARRAYS)) {
+  if (p->dense_A) {
+    // validated in glrm_setup_dense
+  } else if (!(p->flags & GLRM_PROBLEM_DEVICE_ARRAYS)) {
     rc = check_view("rowptr", p->row_end - p->row_begin, p->rowptr, p->colidx, p->rowvals, p->n, p, true, p->row_begin);
     if (rc) return rc;
     rc = check_view("colptr", p->col_end - p->col_begin, p->colptr, p->rowidx, p->colvals, p->m, p, false, p->col_begin);
@@ -746,7 +751,10 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
     HIPCK(hipEventRecord(ev.a, h->stream));
   }
   const bool tiled = rows ? (h->tiled_row && !eval_only) : h->tiled_col;
-  if (tiled) {
+  if (h->dense) {
+    rc = glrm_run_dense(h, rows, min_stepsize, eval_only);
+    if (rc) return rc;
+  } else if (tiled) {
     rc = glrm_run_tiled(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
     if (rc) return rc;
   } else {
@@ -842,7 +850,7 @@ extern "C" int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int
   if ((rc = count_sum(h, h->accepts_c, h->nl, &out->accepts_y))) return rc;
   out->nnz_rows = h->nnz_r; out->nnz_cols = h->nnz_c;
   out->waves_row = h->waves_row; out->waves_col = h->waves_col; out->ld = h->kp;
-  out->tiled = (h->tiled_row ? 1 : 0) | (h->tiled_col ? 2 : 0); // bit0: tiled row sweep, bit1: tiled column sweep
+  out->tiled = (h->tiled_row ? 1 : 0) | (h->tiled_col ? 2 : 0) | (h->dense ? 4 : 0); // bit0: tiled row sweep, bit1: tiled column sweep
   if (reset) {
     h->launches_x = h->launches_y = 0;
     h->ms_x = h->ms_y = 0;

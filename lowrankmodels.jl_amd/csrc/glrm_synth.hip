@@ -110,6 +110,46 @@ __global__ void synth_init_kernel(uint64_t seed, uint64_t stream, int64_t count,
   }
 }
 
+// Dense matrix block (rows [row_begin,row_end) x all n columns, row-major, leading dimension ld): same values as
+// glrm_synth_value, computed from tabulated truth factors (xs: rows x k, ys: n x k, filled by synth_factor_kernel).
+__global__ void synth_factor_kernel(glrm_synth_spec s, int which, int64_t first, int64_t count, double* out) {
+  const double isk = 1.0 / sqrt((double)s.k);
+  const int64_t total = count * s.k;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / s.k;
+    const int c = (int)(i - r * s.k);
+    out[i] = which == 0 ? glrm_synth_xstar(&s, first + r, c, isk) : glrm_synth_ystar(&s, first + r, c, isk);
+  }
+}
+
+__global__ void __launch_bounds__(256) synth_dense_kernel(glrm_synth_spec s, int64_t row_begin, int64_t nrows, const double* xs,
+                                                          const double* ys, double* A, int64_t ld) {
+  // one block = 16 rows x 256 columns; thread = one column, loops the 16 rows
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t r0 = (int64_t)blockIdx.y * 16;
+  if (f >= s.n) return;
+  const double* y = ys + f * s.k;
+  for (int rr = 0; rr < 16 && r0 + rr < nrows; ++rr) {
+    const int64_t e = row_begin + r0 + rr;
+    const double* x = xs + (r0 + rr) * s.k;
+    double d = 0.0;
+    for (int c = 0; c < s.k; ++c) d = fma(x[c], y[c], d);
+    A[(r0 + rr) * ld + f] = d + s.noise * glrm_unif_unit(glrm_hash4(s.seed, 4, (uint64_t)e, (uint64_t)f));
+  }
+}
+
+extern "C" int glrm_synth_hip_dense(const glrm_synth_spec* s, int64_t row_begin, int64_t row_end, double* A, int64_t ld,
+                                    double* scratch_xs, double* scratch_ys, void* stream) {
+  if (!spec_ok(s) || row_begin < 0 || row_end > s->m || row_begin > row_end || ld < s->n || s->loss_mix) return -1;
+  const int64_t nrows = row_end - row_begin;
+  hipLaunchKernelGGL(synth_factor_kernel, dim3(4096), dim3(256), 0, (hipStream_t)stream, *s, 0, row_begin, nrows, scratch_xs);
+  hipLaunchKernelGGL(synth_factor_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, *s, 1, (int64_t)0, s->n, scratch_ys);
+  const dim3 grid((unsigned)((s->n + 255) / 256), (unsigned)((nrows + 15) / 16));
+  hipLaunchKernelGGL(synth_dense_kernel, grid, dim3(256), 0, (hipStream_t)stream, *s, row_begin, nrows, scratch_xs, scratch_ys, A, ld);
+  SCK(hipGetLastError());
+  return 0;
+}
+
 extern "C" int glrm_synth_hip_rows(const glrm_synth_spec* s, int64_t row_begin, int64_t row_end, int64_t* rowptr,
                                    int32_t* colidx, double* vals, void* stream) {
   if (!spec_ok(s) || row_begin < 0 || row_end > s->m || row_begin > row_end) return -1;

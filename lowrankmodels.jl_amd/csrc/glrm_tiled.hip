@@ -115,16 +115,17 @@ static void launch_col_small(int which, const TiledArgs& a, hipStream_t st) {
   else hipLaunchKernelGGL((col_decide_kernel<G, R>), dim3(gx), dim3(256), 0, st, a);
 }
 
-static void launch_col_small_any(glrm_handle* h, int which, const TiledArgs& a) {
-  switch (h->tG * 100 + h->tR) {
-
-    case 402: launch_col_small<4, 2>(which, a, h->stream); break;
-    case 404: launch_col_small<4, 4>(which, a, h->stream); break;
-    case 408: launch_col_small<4, 8>(which, a, h->stream); break;
-    case 808: launch_col_small<8, 8>(which, a, h->stream); break;
-    default: launch_col_small<16, 8>(which, a, h->stream); break;
+void glrm_launch_col_small(int kp, int which, const TiledArgs& a, hipStream_t st) {
+  switch (kp) {
+    case 8: launch_col_small<4, 2>(which, a, st); break;
+    case 16: launch_col_small<4, 4>(which, a, st); break;
+    case 32: launch_col_small<4, 8>(which, a, st); break;
+    case 64: launch_col_small<8, 8>(which, a, st); break;
+    default: launch_col_small<16, 8>(which, a, st); break;
   }
 }
+
+static void launch_col_small_any(glrm_handle* h, int which, const TiledArgs& a) { glrm_launch_col_small(h->kp, which, a, h->stream); }
 
 // The tiled variants of run_sweep's launch.  Rows: one kernel.  Columns: pass 1 -> reduce -> rounds of
 // (trial pass, decide) until no column is still searching (the count is read back once per round).

@@ -52,6 +52,7 @@ struct TiledArgs {
   int32_t* ntrial;       // [nseg] trials taken in this sweep
   unsigned int* nactive; // device counter of still-active segments
   int eval_only;         // col_reduce: obj = sum of losses, nothing else
+  int64_t dense_len;     // ptr == nullptr (dense problem): every segment has this many observations
 };
 
 template <int G>
@@ -366,7 +367,7 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const TiledArgs a) {
   const RegDesc rd = load_reg(a.regs, a.reg_single ? 0 : seg);
   const double Jold = J + reg_eval<G, R>(rd, y, j, a.k);
   const double alpha = a.alpha[seg];
-  const double l = (double)(a.ptr[seg + 1] - a.ptr[seg]) + 1.0;
+  const double l = (double)(a.ptr ? a.ptr[seg + 1] - a.ptr[seg] : a.dense_len) + 1.0;
   const bool searching = alpha > a.min_stepsize;
   const double s = alpha / l;
 #pragma unroll
@@ -426,7 +427,7 @@ __global__ void __launch_bounds__(256) col_decide_kernel(const TiledArgs a) {
       alpha = a.min_stepsize * 1.1;
     } else {
       still = 1;
-      const double l = (double)(a.ptr[seg + 1] - a.ptr[seg]) + 1.0;
+      const double l = (double)(a.ptr ? a.ptr[seg + 1] - a.ptr[seg] : a.dense_len) + 1.0;
       const double s = alpha / l;
 #pragma unroll
       for (int i = 0; i < R / 2; ++i) {
@@ -455,7 +456,7 @@ __global__ void __launch_bounds__(256) col_decide_kernel(const TiledArgs a) {
 }
 
 // 1 if idx is non-decreasing inside every segment
-__global__ void check_sorted_kernel(const int64_t* ptr, const int32_t* idx, int64_t nseg, int* unsorted) {
+static __global__ void check_sorted_kernel(const int64_t* ptr, const int32_t* idx, int64_t nseg, int* unsorted) {
   const int64_t seg = (int64_t)blockIdx.x;
   if (seg >= nseg) return;
   const int64_t b = ptr[seg], e = ptr[seg + 1];

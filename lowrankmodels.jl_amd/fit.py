@@ -75,11 +75,12 @@ def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, 
 
     if np.linalg.norm(glrm.Y) == 0:
         raise ValueError("Y is all zeros (the reference cannot start from Y == 0, src/algorithms/proxgrad.jl:45-48)")
-    key = (id(api), _engine_opts(params)["device_id"], glrm._descriptor_key())
+    use_dense = api.dense_ok and glrm.dense_eligible() and getattr(params, "dense", True)
+    key = (id(api), _engine_opts(params)["device_id"], glrm._descriptor_key(), use_dense)
     if glrm._handle_cache is not None and glrm._handle_cache[2] != key:
         glrm.close()
     if glrm._handle_cache is None:
-        h = api.create(glrm.problem_arrays(), **_engine_opts(params))
+        h = api.create(glrm.problem_arrays(dense=use_dense), **_engine_opts(params))
         glrm._handle_cache = (api, h, key)
     h = glrm._handle_cache[1]
     if verbose:
@@ -208,7 +209,8 @@ def _fit_distributed(glrm, params, ch, verbose, api, group):
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     rbs, cbs = partition(glrm._rowptr, world), partition(glrm._colptr, world)
-    prob = glrm.problem_arrays(rows=(rbs[rank], rbs[rank + 1]), cols=(cbs[rank], cbs[rank + 1]))
+    use_dense = api.dense_ok and glrm.dense_eligible() and getattr(params, "dense", True)
+    prob = glrm.problem_arrays(rows=(rbs[rank], rbs[rank + 1]), cols=(cbs[rank], cbs[rank + 1]), dense=use_dense)
     if api.device_type == "cuda":
         device = torch.device("cuda", torch.cuda.current_device())
         stream = torch.cuda.current_stream().cuda_stream

@@ -110,6 +110,8 @@ class GLRM:
         self.Y = np.array(Y, dtype=np.float64, order="F")
         self.m, self.n = m, n
 
+        self._fully_observed = obs is None and observed_features is None and observed_examples is None and \
+            not (sparse_na and _issparse(A))
         # observed entries, src/glrm.jl:45-55
         if obs is None and sparse_na and _issparse(A):
             csc = A.tocsc()
@@ -178,9 +180,27 @@ class GLRM:
         return (self.m, self.n)
 
     # -- lowering to the ABI -----------------------------------------------------------------
-    def problem_arrays(self, rows=None, cols=None) -> ProblemArrays:
+    def dense_eligible(self):
+        """Fully observed, one QuadLoss for every column, rank 9..64, plain numeric matrix: the half-steps can run
+        as fused GEMMs on the matrix cores (the `dense_A` hand-over of include/glrm_hip.h)."""
+        return (self._fully_observed and not _issparse(self.A) and self.A.dtype != object and 8 < self.k <= 64
+                and len(pack_losses(self.losses)) == 1 and self.losses[0].kind == 0)
+
+    def problem_arrays(self, rows=None, cols=None, dense=False) -> ProblemArrays:
         rb, re = (0, self.m) if rows is None else rows
         cb, ce = (0, self.n) if cols is None else cols
+        if dense:
+            if not self.dense_eligible():
+                raise ValueError("this model is not eligible for the dense hand-over")
+            if getattr(self, "_dense_copy", None) is None:
+                self._dense_copy = np.ascontiguousarray(self.A, dtype=np.float64)  # row-major m x n
+                if np.isnan(self._dense_copy).any():
+                    i, j = np.argwhere(np.isnan(self._dense_copy))[0]
+                    raise ValueError(f"Observed value in entry ({i}, {j}) is NaN.")
+            rx = pack_regs(self.rx[rb:re]) if re > rb else pack_regs(self.rx[:1])
+            ry = pack_regs(self.ry[cb:ce]) if ce > cb else pack_regs(self.ry[:1])
+            return ProblemArrays(self.m, self.n, self.k, None, None, None, None, None, None, pack_losses(self.losses), rx, ry,
+                                 rb, re, cb, ce, dense_A=self._dense_copy, dense_ld=self.n, dense_colmajor=0)
         r0, r1 = self._rowptr[rb], self._rowptr[re]
         c0, c1 = self._colptr[cb], self._colptr[ce]
         losses = pack_losses(self.losses)

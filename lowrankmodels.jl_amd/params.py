@@ -30,10 +30,11 @@ class HipProxGradParams(ProxGradParams):
     ``struct HipProxGradParams <: AbstractParams`` (julia/HipGLRM.jl); `fit!(glrm, params=p)`
     dispatches on it exactly like on the built-in solvers (src/fit.jl:8-12)."""
 
-    def __init__(self, stepsize=1.0, *, device_id=-1, profile=False, waves_row=0, waves_col=0, tiled=0, **kw):
+    def __init__(self, stepsize=1.0, *, device_id=-1, profile=False, waves_row=0, waves_col=0, tiled=0, dense=True, **kw):
         super().__init__(stepsize, **kw)
         self.device_id, self.profile = int(device_id), bool(profile)
         self.waves_row, self.waves_col, self.tiled = int(waves_row), int(waves_col), int(tiled)
+        self.dense = bool(dense)  # fully observed QuadLoss models: run the half-steps on the matrix cores
 
 
 def Params(*args, **kwargs):  # src/fit.jl:5

@@ -35,6 +35,7 @@ def synth_lib():
         _lib.glrm_synth_hip_col_counts.argtypes = [C.POINTER(SynthSpec), I64, I64, V, V]
         _lib.glrm_synth_hip_cols.argtypes = [C.POINTER(SynthSpec), I64, I64, V, V, V, V]
         _lib.glrm_synth_hip_init.argtypes = [C.POINTER(SynthSpec), C.c_uint64, C.c_int, V, V, V]
+        _lib.glrm_synth_hip_dense.argtypes = [C.POINTER(SynthSpec), I64, I64, V, I64, V, V, V]
         _lib.glrm_synth_hip_last_error.restype = C.c_char_p
     return _lib
 
@@ -113,4 +114,37 @@ class DeviceWorkload:
     def free_sources(self):
         """Drop the generator's copies once the engine handle has made its own."""
         self.rowptr = self.colidx = self.rowvals = self.colptr = self.rowidx = self.colvals = None
+        self.torch.cuda.empty_cache()
+
+
+class DenseDeviceWorkload:
+    """Fully observed m x n matrix generated in HBM (row-major), for the dense QuadLoss hand-over (BASELINE config 3)."""
+
+    def __init__(self, m, n, k, *, seed=20260926, noise=0.1, rx=(0, 0, 1.0), ry=(0, 0, 1.0), device=None):
+        import torch
+        lib = synth_lib()
+        self.torch = torch
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.spec = SynthSpec(m, n, k, n, seed, 0, 0, noise)
+        self.m, self.n, self.k, self.q = m, n, k, n
+        with torch.cuda.device(self.device):
+            self.A = torch.empty(m * n, dtype=torch.float64, device=self.device)
+            xs = torch.empty(m * k, dtype=torch.float64, device=self.device)
+            ys = torch.empty(n * k, dtype=torch.float64, device=self.device)
+            _ck(lib.glrm_synth_hip_dense(C.byref(self.spec), 0, m, self.A.data_ptr(), n, xs.data_ptr(), ys.data_ptr(),
+                                         torch.cuda.current_stream(self.device).cuda_stream))
+            torch.cuda.synchronize(self.device)
+        self.nnz_rows = self.nnz_cols = m * n
+        self.losses = np.array([QUAD], dtype=_capi.LOSS_DTYPE)
+        self.rx = np.array([rx], dtype=_capi.REG_DTYPE)
+        self.ry = np.array([ry], dtype=_capi.REG_DTYPE)
+
+    def problem(self) -> _capi.ProblemArrays:
+        return _capi.ProblemArrays(self.m, self.n, self.k, None, None, None, None, None, None, self.losses, self.rx, self.ry,
+                                   flags=_capi.PROBLEM_DEVICE_ARRAYS, dense_A=int(self.A.data_ptr()), dense_ld=self.n, dense_colmajor=0)
+
+    init_factors = DeviceWorkload.init_factors
+
+    def free_sources(self):
+        self.A = None
         self.torch.cuda.empty_cache()
