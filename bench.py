@@ -81,6 +81,7 @@ def main():
                     help="BASELINE.json config family: C2 (default, the bench line), C4 = rank-64 NNMF 0.1 %% observed, "
                          "C5 = mixed Quad/Logistic/OrdinalHinge columns 2 %% observed (use --rows-per-gpu to scale)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000)
     args = ap.parse_args()
 
@@ -165,6 +166,29 @@ def main():
         tot_r, tot_c = nnz_r, nnz_c
     st = api.kernel_stats(sf.h)
 
+    # Second leg of the metric (iters-to-ref-objective): the reference's own run -- default ProxGradParams(), stop rule
+    # of src/algorithms/proxgrad.jl:210-213, from the same X0, Y0 -- timed end to end.  Parity makes the iteration count
+    # the reference's iteration count; the objective reached is what the reference would record.
+    conv = None
+    if not args.no_convergence_run:
+        X0, Y0 = w.init_factors(sf.ld)
+        sf.dX.copy_(X0); sf.dY.copy_(Y0)
+        del X0, Y0
+        api.reset_stepsizes(sf.h, 1.0)
+        fence()
+        tc = time.perf_counter()
+        hist = [sf.initial_objective()]
+        scaled_abs_tol = 1e-5 * float(tot_r)
+        for i in range(1, 101):
+            obj = sf.iteration(P)
+            dec = hist[-1] - obj
+            hist.append(obj)
+            if i > 10 and (dec < scaled_abs_tol or dec / obj < 1e-4):
+                break
+        fence()
+        conv = {"iterations": len(hist) - 1, "seconds": time.perf_counter() - tc, "objective_initial": hist[0],
+                "objective_final": hist[-1], "stop_rule": "reference defaults: abs_tol=1e-5*|Omega|, rel_tol=1e-4, max_iter=100"}
+
     if rank == 0:
         updates_per_step = tot_r + tot_c
         value = args.steps * updates_per_step / elapsed
@@ -212,6 +236,7 @@ def main():
                         "mean_trials_per_row": st["trials_x"] / max(st["launches_x"] * nseg_r, 1),
                         "mean_trials_per_col": st["trials_y"] / max(st["launches_y"] * nseg_c, 1)},
             "objective": {"initial": obj0, "after_warmup_and_steps": objs[-1] if objs else None},
+            "to_reference_stop": conv,
             "setup_s": {"generate": t_gen, "create": t_create},
         }
         if world == 1 and not args.no_cpu_baseline and args.config == "C2":

@@ -17,7 +17,7 @@ static int64_t round_up(int64_t v, int64_t q) { return (v + q - 1) / q * q; }
 static void pick_sup(int64_t n_other, int& nsup, int64_t& vps) {
   int64_t s = (n_other + 32767) / 32768;
   if (s < 1) s = 1;
-  if (s > 32) s = 32;
+  if (s > 4096) s = 4096;
   vps = round_up((n_other + s - 1) / s, DENSE_TN);
   nsup = (int)((n_other + vps - 1) / vps);
 }

@@ -41,9 +41,10 @@ int glrm_setup_tiled(glrm_handle* h) {
   want = env_int("GLRM_HIP_TILED", want);
   h->tiled_row = h->rows_sorted && (want < 0 ? (per_tile_r >= 4.0 && h->ml >= 2048) : (want & 1)) ? 1 : 0;
   h->tiled_col = h->cols_sorted && (want < 0 ? (per_tile_c >= 4.0 && h->nl >= 256) : ((want >> 1) & 1)) ? 1 : 0;
+  // super-tiles of ~32k rows: a function of (m, tile) only -- never of the shard layout -- so the partial-sum order
+  // (and the result bits) do not depend on the GPU count, while long columns still spread over enough workgroups
   const int64_t ntiles = (h->m + T - 1) / T;
-  int64_t nsup = ntiles < 32 ? ntiles : 32;
-  h->tiles_per_sup = (int)((ntiles + nsup - 1) / nsup);
+  h->tiles_per_sup = 32768 / T > 1 ? 32768 / T : 1;
   h->nsup = (int)((ntiles + h->tiles_per_sup - 1) / h->tiles_per_sup);
   if (h->tiled_col) {
     const int64_t nl1 = h->nl > 0 ? h->nl : 1;

@@ -79,6 +79,32 @@ __device__ __forceinline__ double group_bcast_f64(double v, int u, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// v from lane (lane ^ X) for X = 4 or 8 (ds_swizzle bit-mask mode: and 0x1F, or 0, xor X; no LDS memory touched)
+template <int X>
+__device__ __forceinline__ double swizzle_xor_f64(double v) {
+  const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), (X << 10) | 0x1F);
+  const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), (X << 10) | 0x1F);
+  return __hiloint2double(hi, lo);
+}
+
+// lane gets v from lane (u0 + (lane & 1)) of its group: the observation "owned" by the lane's parity
+template <int G>
+__device__ __forceinline__ double pair_bcast_f64(double v, int u0, int lane) {
+  if constexpr (G == 4) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (u0 == 0) { // quad_perm:[0,1,0,1]
+      lo = __builtin_amdgcn_update_dpp(lo, lo, 0x44, 0xF, 0xF, false);
+      hi = __builtin_amdgcn_update_dpp(hi, hi, 0x44, 0xF, 0xF, false);
+    } else { // quad_perm:[2,3,2,3]
+      lo = __builtin_amdgcn_update_dpp(lo, lo, 0xEE, 0xF, 0xF, false);
+      hi = __builtin_amdgcn_update_dpp(hi, hi, 0xEE, 0xF, 0xF, false);
+    }
+    return __hiloint2double(hi, lo);
+  } else {
+    return __shfl(v, (lane & ~(G - 1)) + u0 + (lane & 1), 64);
+  }
+}
+
 template <int G, int R>
 constexpr int tile_row_bytes() { return G * R * 8 + 16; } // +16 B pad: consecutive rows start 4 banks apart
 
@@ -152,22 +178,44 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
       load_entry(pos + G + j, cn, an);
       const bool next_ok = pos + G + j < end;
       int nproc = 0;
+      // Two observations of the batch per step.  Every lane forms its partial dot products for BOTH observations;
+      // the first butterfly step is a reduce-scatter (even lanes keep observation u0, odd lanes u0+1), the remaining
+      // steps reduce one value; loss and derivative are then evaluated once per lane for "its" observation and the
+      // derivative of the other one comes back with one DPP move.  ~30 % (gradient pass) / ~45 % (trial pass) fewer
+      // VALU instructions than one observation per step.
+      const bool odd = (j & 1) != 0;
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
-        const int c = group_bcast_i32<G>(cb, u, lane);
-        const double av = group_bcast_f64<G>(ab, u, lane);
-        if (!done && c < (int)hi) { // c == INT_MAX past the end of the segment
-          const char* rowp = lds + (c - (int)lo) * ROWB + j * 16;
-          double2 y[R / 2];
+      for (int u0 = 0; u0 < G; u0 += 2) {
+        const int c0 = group_bcast_i32<G>(cb, u0, lane);
+        const int c1 = group_bcast_i32<G>(cb, u0 + 1, lane);
+        const bool ok0 = !done && c0 < (int)hi; // c == INT_MAX past the end of the segment
+        const bool ok1 = ok0 && c1 < (int)hi;
+        if (ok0) {
+          const char* rp0 = lds + (c0 - (int)lo) * ROWB + j * 16;
+          const char* rp1 = lds + ((ok1 ? c1 : c0) - (int)lo) * ROWB + j * 16;
+          double2 y0[R / 2], y1[R / 2];
 #pragma unroll
-          for (int i = 0; i < R / 2; ++i) y[i] = *reinterpret_cast<const double2*>(rowp + i * (2 * G * 8));
-          double dot = 0.0;
+          for (int i = 0; i < R / 2; ++i) y0[i] = *reinterpret_cast<const double2*>(rp0 + i * (2 * G * 8));
+#pragma unroll
+          for (int i = 0; i < R / 2; ++i) y1[i] = *reinterpret_cast<const double2*>(rp1 + i * (2 * G * 8));
+          double p0 = 0.0, p1 = 0.0;
 #pragma unroll
           for (int i = 0; i < R / 2; ++i) {
-            dot = fma(xv.v[i].x, y[i].x, dot);
-            dot = fma(xv.v[i].y, y[i].y, dot);
+            p0 = fma(xv.v[i].x, y0[i].x, p0);
+            p0 = fma(xv.v[i].y, y0[i].y, p0);
           }
-          dot = group_sum<G>(dot);
+#pragma unroll
+          for (int i = 0; i < R / 2; ++i) {
+            p1 = fma(xv.v[i].x, y1[i].x, p1);
+            p1 = fma(xv.v[i].y, y1[i].y, p1);
+          }
+          const double keep = odd ? p1 : p0, send = odd ? p0 : p1;
+          double dot = keep + dpp_f64<DPP_XOR1>(send); // lane pair sum for observation u0 + odd
+          // remaining butterfly steps must keep the lane parity (mirrors would mix the two observations)
+          if constexpr (G >= 4) dot += dpp_f64<DPP_XOR2>(dot);
+          if constexpr (G >= 8) dot += swizzle_xor_f64<4>(dot);
+          if constexpr (G >= 16) dot += swizzle_xor_f64<8>(dot);
+          const double av = pair_bcast_f64<G>(ab, u0, lane);
           double L, dL;
           if constexpr (LOSS == 0) {
             const double d = dot - av;
@@ -176,18 +224,30 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
           } else if constexpr (LOSS == 1) {
             loss_both<GRAD>(segloss, dot, av, L, dL);
           } else {
-            const LossDesc lo_ = load_loss(a.losses, c);
+            const LossDesc lo_ = load_loss(a.losses, odd ? (ok1 ? c1 : c0) : c0);
             loss_both<GRAD>(lo_, dot, av, L, dL);
           }
-          J += L;
+          if (odd && !ok1) {
+            L = 0.0;
+            dL = 0.0;
+          }
+          J += L; // every observation is accumulated by G/2 lanes; the caller rescales the group sum by 2/G (exact)
           if (GRAD) {
+            const double dLo = dpp_f64<DPP_XOR1>(dL);
+            const double d0 = odd ? dLo : dL, d1 = odd ? dL : dLo; // list order: u0 first, then u0+1
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) {
-              g.v[i].x = fma(dL, y[i].x, g.v[i].x);
-              g.v[i].y = fma(dL, y[i].y, g.v[i].y);
+              g.v[i].x = fma(d0, y0[i].x, g.v[i].x);
+              g.v[i].y = fma(d0, y0[i].y, g.v[i].y);
+            }
+#pragma unroll
+            for (int i = 0; i < R / 2; ++i) {
+              g.v[i].x = fma(d1, y1[i].x, g.v[i].x);
+              g.v[i].y = fma(d1, y1[i].y, g.v[i].y);
             }
           }
-          ++nproc;
+          nproc += ok1 ? 2 : 1;
+          if (!ok1) done = true;
         } else {
           done = true;
         }
@@ -202,6 +262,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
       }
     }
   }
+  J = group_sum<G>(J) * (2.0 / G); // lanes hold parity-partial sums, each observation counted G/2 times
 }
 
 // ------------------------------------------------------------------------------------------------
