@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--waves-row", type=int, default=0)
     ap.add_argument("--waves-col", type=int, default=0)
     ap.add_argument("--tiled", type=int, default=0, help="0 auto, 1 gather sweeps only, 2 LDS-tiled sweeps")
+    ap.add_argument("--x-chunks", type=int, default=4, help="N > 1: row chunks of the X half-step whose all-gather overlaps the next chunk")
     ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
                     help="BASELINE.json config family: C2 (default, the bench line), C4 = rank-64 NNMF 0.1 %% observed, "
                          "C5 = mixed Quad/Logistic/OrdinalHinge columns 2 %% observed (use --rows-per-gpu to scale)")
@@ -126,7 +127,8 @@ def main():
     t_gen = time.time() - t_gen
     t_create = time.time()
     sf = ShardedFit(api, w.problem(), rbs, cbs, device=device, stream=torch.cuda.current_stream().cuda_stream,
-                    opts=dict(profile=1, waves_row=args.waves_row, waves_col=args.waves_col, tiled=args.tiled))
+                    opts=dict(profile=1, waves_row=args.waves_row, waves_col=args.waves_col, tiled=args.tiled),
+                    x_chunks=args.x_chunks if args.config != "C3" else 1)
     nnz_r, nnz_c = w.nnz_rows, w.nnz_cols
     w.free_sources()
     t_create = time.time() - t_create
@@ -193,8 +195,8 @@ def main():
         updates_per_step = tot_r + tot_c
         value = args.steps * updates_per_step / elapsed
         bpu = algorithmic_bytes_per_update(k)
-        ms_x = st["ms_x"] / max(st["launches_x"], 1)
-        ms_y = st["ms_y"] / max(st["launches_y"], 1)
+        ms_x = st["ms_x"] / max(args.steps, 1)  # per outer iteration (the X half-step may run as several chunk launches)
+        ms_y = st["ms_y"] / max(args.steps, 1)
         tiled_row, tiled_col = bool(st["tiled"] & 1), bool(st["tiled"] & 2)
         # dominant kernel = the longest single kernel.  The gather column sweep and both row sweeps are one kernel per
         # half-step; the LDS-tiled column sweep is four launches (pass, reduce, trial pass, decide) of which the two
@@ -233,8 +235,8 @@ def main():
             "kernels": {"row_sweep_ms": ms_x, "col_sweep_ms": ms_y,
                         "row_sweep_GBps_algorithmic": nnz_r * bpu / (ms_x * 1e-3) / 1e9 if ms_x > 0 else None,
                         "col_sweep_GBps_algorithmic": nnz_c * bpu / (ms_y * 1e-3) / 1e9 if ms_y > 0 else None,
-                        "mean_trials_per_row": st["trials_x"] / max(st["launches_x"] * nseg_r, 1),
-                        "mean_trials_per_col": st["trials_y"] / max(st["launches_y"] * nseg_c, 1)},
+                        "mean_trials_per_row": st["trials_x"] / max(args.steps * nseg_r, 1),
+                        "mean_trials_per_col": st["trials_y"] / max(args.steps * nseg_c, 1)},
             "objective": {"initial": obj0, "after_warmup_and_steps": objs[-1] if objs else None},
             "to_reference_stop": conv,
             "setup_s": {"generate": t_gen, "create": t_create},

@@ -196,6 +196,9 @@ int glrm_hip_get_factors(glrm_handle* h, double* X, double* Y);             /* d
 int glrm_hip_reset_stepsizes(glrm_handle* h, double stepsize);              /* alpharow, alphacol (:69-70,:112-115) */
 int glrm_hip_step_x(glrm_handle* h, double min_stepsize);                   /* one inner X sweep (:118-156) */
 int glrm_hip_step_y(glrm_handle* h, double min_stepsize);                   /* one inner Y sweep (:162-201) */
+/* The X sweep restricted to the shard's local rows [seg_begin, seg_end): lets a multi-GPU host pipeline the
+ * all-gather of finished row chunks behind the sweep of the next chunk (rows are independent, :118). */
+int glrm_hip_step_x_range(glrm_handle* h, int64_t seg_begin, int64_t seg_end, double min_stepsize);
 int glrm_hip_col_losses(glrm_handle* h);
 int glrm_hip_row_penalties(glrm_handle* h);
 int glrm_hip_col_penalties(glrm_handle* h);

@@ -81,7 +81,7 @@ class CKernelStats(C.Structure):
 #: that the built library exports all of them.
 ABI_SYMBOLS = (
     "version", "last_error", "create", "destroy", "fit", "objective", "factor_ld", "bind_buffers",
-    "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "col_losses", "row_penalties",
+    "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "col_losses", "row_penalties",
     "col_penalties", "sum", "synchronize", "kernel_stats",
 )
 
@@ -117,6 +117,7 @@ class Api:
             "reset_stepsizes": (C.c_int, [H, C.c_double]),
             "step_x": (C.c_int, [H, C.c_double]),
             "step_y": (C.c_int, [H, C.c_double]),
+            "step_x_range": (C.c_int, [H, C.c_int64, C.c_int64, C.c_double]),
             "col_losses": (C.c_int, [H]),
             "row_penalties": (C.c_int, [H]),
             "col_penalties": (C.c_int, [H]),
@@ -206,6 +207,9 @@ class Api:
 
     def step_x(self, h, min_stepsize):
         self._ck(self._f["step_x"](h, float(min_stepsize)))
+
+    def step_x_range(self, h, seg_begin, seg_end, min_stepsize):
+        self._ck(self._f["step_x_range"](h, int(seg_begin), int(seg_end), float(min_stepsize)))
 
     def step_y(self, h, min_stepsize):
         self._ck(self._f["step_y"](h, float(min_stepsize)))

@@ -737,6 +737,15 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
   a.min_stepsize = min_stepsize;
   a.trials = eval_only ? nullptr : (rows ? h->trials_r : h->trials_c);
   a.accepts = rows ? h->accepts_r : h->accepts_c;
+  if (rows && h->rng_e >= 0) { // glrm_hip_step_x_range: local rows [rng_b, rng_e)
+    const int64_t s0 = h->rng_b;
+    a.nseg = h->rng_e - s0;
+    if (a.nseg <= 0) return GLRM_OK;
+    a.ptr += s0; a.alpha += s0; a.own_offset += s0;
+    if (!a.reg_single) a.regs += s0;
+    if (a.trials) a.trials += s0;
+    a.accepts += s0;
+  }
   int loss;
   if (h->loss_quad_uniform) { loss = LOSS_QUAD_UNIFORM; a.loss_by_segment = 0; }
   else if (h->n_losses == 1) { loss = LOSS_SEGMENT; a.loss_by_segment = 0; }
@@ -774,6 +783,19 @@ extern "C" int glrm_hip_step_x(glrm_handle* h, double min_stepsize) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
   DeviceGuard dg(h->device);
   return run_sweep(h, 0, min_stepsize, 0);
+}
+
+extern "C" int glrm_hip_step_x_range(glrm_handle* h, int64_t seg_begin, int64_t seg_end, double min_stepsize) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (seg_begin < 0 || seg_end > h->ml || seg_begin > seg_end) return fail(GLRM_ERR_INVALID, "row range out of bounds");
+  if (h->dense) return fail(GLRM_ERR_UNSUPPORTED, "step_x_range is not available on the dense path");
+  DeviceGuard dg(h->device);
+  h->rng_b = seg_begin;
+  h->rng_e = seg_end;
+  const int rc = run_sweep(h, 0, min_stepsize, 0);
+  h->rng_b = 0;
+  h->rng_e = -1;
+  return rc;
 }
 
 extern "C" int glrm_hip_step_y(glrm_handle* h, double min_stepsize) {

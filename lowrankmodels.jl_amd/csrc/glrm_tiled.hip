@@ -151,6 +151,14 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
   a.trials = rows ? h->trials_r : h->trials_c;
   a.accepts = rows ? h->accepts_r : h->accepts_c;
   a.eval_only = eval_only;
+  if (rows && h->rng_e >= 0) { // glrm_hip_step_x_range
+    const int64_t s0 = h->rng_b;
+    a.nseg = h->rng_e - s0;
+    if (a.nseg <= 0) return GLRM_OK;
+    a.ptr += s0; a.alpha += s0; a.own_offset += s0;
+    if (!a.reg_single) a.regs += s0;
+    a.trials += s0; a.accepts += s0;
+  }
   if (rows) return launch_tiled(h, loss, 0, a);
   a.nsup = h->nsup;
   a.tiles_per_sup = h->tiles_per_sup;

@@ -133,7 +133,7 @@ class ShardedFit:
     gathered per-column values, so it does not depend on the number of ranks.
     """
 
-    def __init__(self, api, prob, row_bounds, col_bounds, group=None, device=None, stream=None, opts=None):
+    def __init__(self, api, prob, row_bounds, col_bounds, group=None, device=None, stream=None, opts=None, x_chunks=1):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.api, self.group = torch, dist, api, group
@@ -152,6 +152,14 @@ class ShardedFit:
         z = lambda cnt: torch.zeros(cnt, dtype=torch.float64, device=self.device)
         self.dX, self.dY, self.dObjCol, self.dObjRow = z(self.m * self.ld), z(self.n * self.ld), z(self.n), z(self.m)
         api.bind_buffers(self.h, self.dX.data_ptr(), self.dY.data_ptr(), self.dObjCol.data_ptr(), self.dObjRow.data_ptr())
+        # Pipelined X exchange: the X half-step runs in `x_chunks` row chunks; the all-gather of a finished chunk
+        # proceeds on a side stream while the next chunk is swept (rows are independent).  Needs equal row blocks.
+        nrows = [row_bounds[r + 1] - row_bounds[r] for r in range(self.world)]
+        self.x_chunks = int(x_chunks) if (self.world > 1 and x_chunks > 1 and len(set(nrows)) == 1 and nrows[0] % x_chunks == 0) else 1
+        if self.x_chunks > 1:
+            c = nrows[0] // self.x_chunks
+            self._stage = [torch.empty(self.world * c * self.ld, dtype=torch.float64, device=self.device) for _ in range(self.x_chunks)]
+            self._comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
         mode = os.environ.get("GLRM_GATHER", "auto")
         self._inplace_ok = self.world > 1 and mode != "broadcast" and (mode == "allgather" or dist.get_backend(group) == "nccl")
 
@@ -176,6 +184,33 @@ class ShardedFit:
                 src = dist.get_global_rank(self.group, r) if self.group is not None else r
                 dist.broadcast(buf[bounds[r] * unit: bounds[r + 1] * unit], src=src, group=self.group)
 
+    def _step_x_pipelined(self, params):
+        """Last inner X sweep in row chunks; chunk j is all-gathered (into a staging buffer, then copied to each
+        owner's place in the replicated X) while chunk j+1 is being swept."""
+        torch, dist, api, h = self.torch, self.dist, self.api, self.h
+        S, ld, rb = self.x_chunks, self.ld, self.row_bounds
+        c = (rb[self.rank + 1] - rb[self.rank]) // S
+        cuda = self.device.type == "cuda"
+        for j in range(S):
+            api.step_x_range(h, j * c, (j + 1) * c, params.min_stepsize)
+            own = self.dX[(rb[self.rank] + j * c) * ld: (rb[self.rank] + (j + 1) * c) * ld]
+            if cuda:
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(self._comm_stream):
+                    self._comm_stream.wait_event(ev)
+                    dist.all_gather_into_tensor(self._stage[j], own, group=self.group)
+                    for q in range(self.world):
+                        if q != self.rank:
+                            self.dX[(rb[q] + j * c) * ld: (rb[q] + (j + 1) * c) * ld].copy_(self._stage[j][q * c * ld: (q + 1) * c * ld], non_blocking=True)
+            else:
+                dist.all_gather_into_tensor(self._stage[j], own.clone(), group=self.group)
+                for q in range(self.world):
+                    if q != self.rank:
+                        self.dX[(rb[q] + j * c) * ld: (rb[q] + (j + 1) * c) * ld].copy_(self._stage[j][q * c * ld: (q + 1) * c * ld])
+        if cuda:
+            torch.cuda.current_stream().wait_stream(self._comm_stream)
+
     def initial_objective(self):
         api, h = self.api, self.h
         api.col_losses(h)
@@ -194,9 +229,13 @@ class ShardedFit:
         api, h = self.api, self.h
         if params.inner_iter_X > 1 or params.inner_iter_Y > 1:
             api.reset_stepsizes(h, params.stepsize)
-        for _ in range(params.inner_iter_X):
+        for _ in range(params.inner_iter_X - 1):
             api.step_x(h, params.min_stepsize)
-        self._gather(self.dX, self.row_bounds, self.ld)  # inner X sweeps only touch own rows: gather once
+        if self.x_chunks > 1:
+            self._step_x_pipelined(params)
+        else:
+            api.step_x(h, params.min_stepsize)
+            self._gather(self.dX, self.row_bounds, self.ld)  # inner X sweeps only touch own rows: gather once
         for _ in range(params.inner_iter_Y):
             api.step_y(h, params.min_stepsize)
         self._gather(self.dY, self.col_bounds, self.ld)
@@ -217,7 +256,8 @@ def _fit_distributed(glrm, params, ch, verbose, api, group):
     else:
         device, stream = torch.device("cpu"), None
     opts = _engine_opts(params)
-    sf = ShardedFit(api, prob, rbs, cbs, group=group, device=device, stream=stream, opts=opts)
+    sf = ShardedFit(api, prob, rbs, cbs, group=group, device=device, stream=stream, opts=opts,
+                    x_chunks=int(os.environ.get("GLRM_X_CHUNKS", getattr(params, "x_chunks", 1))))
     try:
         if np.linalg.norm(glrm.Y) == 0:
             raise ValueError("Y is all zeros (the reference cannot start from Y == 0)")

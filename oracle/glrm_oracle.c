@@ -527,19 +527,32 @@ static int64_t max_col_len(const glrm_cpu_handle* h) {
 
 /* ------------------------------------------------------------- half-steps */
 
+static int step_x_rows(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_stepsize);
+
 /* One inner X sweep over the local rows, src/algorithms/proxgrad.jl:118-156
  * (threaded exactly like proxgrad_multithread.jl:118: rows are independent). */
 int glrm_cpu_step_x(glrm_cpu_handle* h, double min_stepsize) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  return step_x_rows(h, 0, h->row_end - h->row_begin, min_stepsize);
+}
+
+/* The same sweep restricted to local rows [seg_begin, seg_end) (rows are independent). */
+int glrm_cpu_step_x_range(glrm_cpu_handle* h, int64_t seg_begin, int64_t seg_end, double min_stepsize) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (seg_begin < 0 || seg_end > h->row_end - h->row_begin || seg_begin > seg_end) return fail(GLRM_ERR_INVALID, "row range out of bounds");
+  if (h->dense_faithful) return fail(GLRM_ERR_UNSUPPORTED, "step_x_range is not available in dense-faithful mode");
+  return step_x_rows(h, seg_begin, seg_end, min_stepsize);
+}
+
+static int step_x_rows(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_stepsize) {
   const int k = h->k;
-  const int64_t ml = h->row_end - h->row_begin;
   int64_t trials = 0, accepts = 0;
 #pragma omp parallel num_threads(g_threads) reduction(+ : trials, accepts)
   {
     double g[ORACLE_MAX_K], newx[ORACLE_MAX_K];
     double* scratch = h->dense_faithful ? (double*)malloc((size_t)h->n * 8) : NULL;
 #pragma omp for schedule(dynamic, 16)
-    for (int64_t el = 0; el < ml; ++el) {
+    for (int64_t el = s0; el < s1; ++el) {
       double* x = h->X + (h->row_begin + el) * k;
       const int64_t b = h->rowptr[el], e = h->rowptr[el + 1];
       for (int c = 0; c < k; ++c) g[c] = 0.0; /* fill!(g, 0.) :119 */

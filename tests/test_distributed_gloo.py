@@ -69,3 +69,17 @@ def test_three_ranks_ragged_blocks(tmp_path):
     for z in ranks:
         assert np.array_equal(z["nnmf_X"], X) and np.array_equal(z["nnmf_Y"], Y)
         assert np.array_equal(z["nnmf_obj"][1:], np.array(ch.objective[1:]))
+
+
+def test_pipelined_x_exchange_equals_one_rank(tmp_path):
+    """GLRM_X_CHUNKS=2: the X half-step runs in two row chunks whose all-gather is pipelined behind the next chunk
+    (glrm_*_step_x_range); rows are independent, so the result is still the single-process bits."""
+    ranks = run_world(tmp_path, ["c1", "kmeans"], 2, {"GLRM_X_CHUNKS": "2"})
+    O.set_threads(1)
+    for name in ["c1", "kmeans"]:
+        kwargs, params = cases.build_golden_case(name)
+        g = L.GLRM(**kwargs)
+        X, Y, ch = L.fit_b(g, params, verbose=False, engine=O.oracle_api())
+        for z in ranks:
+            assert np.array_equal(z[name + "_X"], X) and np.array_equal(z[name + "_Y"], Y), name
+            assert np.array_equal(z[name + "_obj"][1:], np.array(ch.objective[1:])), name

@@ -291,3 +291,29 @@ def test_runs_are_bitwise_deterministic():
         a = cases.run_engine(hip(), pa, X0, Y0, params, tiled=mode)
         b = cases.run_engine(hip(), pa, X0, Y0, params, tiled=mode)
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_step_x_range_chunks_equal_full_sweep(mode):
+    """glrm_hip_step_x_range over consecutive row chunks == one glrm_hip_step_x (what the pipelined multi-GPU host relies on)."""
+    rng = np.random.default_rng(90 + mode)
+    pa, X0, Y0 = random_problem(rng, 700, 150, 32, 0.3, rx=L.NonNegConstraint())
+    api = hip()
+    res = []
+    for chunks in (None, [(0, 100), (100, 101), (101, 512), (512, 700)]):
+        h = api.create(pa, tiled=mode)
+        api.set_factors(h, X0, Y0)
+        api.reset_stepsizes(h, 1.0)
+        for _ in range(3):
+            if chunks is None:
+                api.step_x(h, 0.01)
+            else:
+                for b, e in chunks:
+                    api.step_x_range(h, b, e, 0.01)
+            api.step_y(h, 0.01)
+        X, Y = np.zeros_like(X0), np.zeros_like(Y0)
+        api.get_factors(h, X, Y)
+        st = api.kernel_stats(h)
+        api.destroy(h)
+        res.append((X, Y, st["trials_x"], st["accepts_x"]))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
