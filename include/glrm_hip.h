@@ -202,6 +202,10 @@ int glrm_hip_step_x_range(glrm_handle* h, int64_t seg_begin, int64_t seg_end, do
 int glrm_hip_col_losses(glrm_handle* h);
 int glrm_hip_row_penalties(glrm_handle* h);
 int glrm_hip_col_penalties(glrm_handle* h);
+/* Replace the regularizer descriptors of an existing handle (same counts as at create: 1 or one per local row /
+ * column).  Omega, A and the losses stay on the device: this is what `regularization_path` / `scale_regularizer!`
+ * (src/cross_validate.jl:228-231, src/glrm.jl:85-89) need between warm-started fits. */
+int glrm_hip_set_regularizers(glrm_handle* h, const glrm_reg* rx, int64_t n_rx, const glrm_reg* ry, int64_t n_ry);
 /* Fixed-order sum of n device doubles (independent of the number of shards); synchronises. */
 int glrm_hip_sum(glrm_handle* h, const void* dvec, int64_t n, double* out);
 int glrm_hip_synchronize(glrm_handle* h);

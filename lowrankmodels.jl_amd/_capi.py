@@ -82,7 +82,7 @@ class CKernelStats(C.Structure):
 ABI_SYMBOLS = (
     "version", "last_error", "create", "destroy", "fit", "objective", "factor_ld", "bind_buffers",
     "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "col_losses", "row_penalties",
-    "col_penalties", "sum", "synchronize", "kernel_stats",
+    "col_penalties", "set_regularizers", "sum", "synchronize", "kernel_stats",
 )
 
 
@@ -121,6 +121,7 @@ class Api:
             "col_losses": (C.c_int, [H]),
             "row_penalties": (C.c_int, [H]),
             "col_penalties": (C.c_int, [H]),
+            "set_regularizers": (C.c_int, [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
             "sum": (C.c_int, [H, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
             "synchronize": (C.c_int, [H]),
             "kernel_stats": (C.c_int, [H, C.POINTER(CKernelStats), C.c_int]),
@@ -222,6 +223,10 @@ class Api:
 
     def col_penalties(self, h):
         self._ck(self._f["col_penalties"](h))
+
+    def set_regularizers(self, h, rx, ry):
+        """rx, ry: REG_DTYPE arrays with the same lengths as at create."""
+        self._ck(self._f["set_regularizers"](h, _ptr(rx), len(rx), _ptr(ry), len(ry)))
 
     def sum(self, h, vec, n) -> float:
         out = C.c_double(0.0)

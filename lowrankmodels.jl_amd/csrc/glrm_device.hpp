@@ -20,13 +20,13 @@ namespace glrm {
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
   return __hiloint2double(hi, lo);
 }
 template <int CTRL>
 __device__ __forceinline__ int dpp_i32(int v) {
-  return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false);
+  return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, false);
 }
 
 constexpr int DPP_XOR1 = 0xB1;         // quad_perm:[1,0,3,2]

@@ -649,6 +649,21 @@ extern "C" int glrm_hip_reset_stepsizes(glrm_handle* h, double stepsize) {
   return GLRM_OK;
 }
 
+extern "C" int glrm_hip_set_regularizers(glrm_handle* h, const glrm_reg* rx, int64_t n_rx, const glrm_reg* ry, int64_t n_ry) {
+  if (!h || !rx || !ry) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (n_rx != h->n_rx || n_ry != h->n_ry)
+    return fail(GLRM_ERR_INVALID, "regularizer counts must match the handle (rx %lld, ry %lld)", (long long)h->n_rx, (long long)h->n_ry);
+  for (int64_t i = 0; i < n_rx; ++i)
+    if (rx[i].kind < 0 || rx[i].kind >= GLRM_REG_KIND_COUNT || rx[i].reserved != 0) return fail(GLRM_ERR_UNSUPPORTED, "rx regularizer kind %d is not supported", rx[i].kind);
+  for (int64_t i = 0; i < n_ry; ++i)
+    if (ry[i].kind < 0 || ry[i].kind >= GLRM_REG_KIND_COUNT || ry[i].reserved != 0) return fail(GLRM_ERR_UNSUPPORTED, "ry regularizer kind %d is not supported", ry[i].kind);
+  DeviceGuard dg(h->device);
+  HIPCK(hipMemcpyAsync(h->rx, rx, (size_t)n_rx * sizeof(glrm_reg), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpyAsync(h->ry, ry, (size_t)n_ry * sizeof(glrm_reg), hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  return GLRM_OK;
+}
+
 extern "C" int glrm_hip_synchronize(glrm_handle* h) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
   DeviceGuard dg(h->device);

@@ -60,14 +60,14 @@ __device__ __forceinline__ int group_bcast_i32(int v, int u, int lane) {
   if constexpr (G == 1) {
     return v;
   } else if constexpr (G == 2) {
-    return u == 0 ? __builtin_amdgcn_update_dpp(v, v, 0xA0, 0xF, 0xF, false)  // quad_perm:[0,0,2,2]
-                  : __builtin_amdgcn_update_dpp(v, v, 0xF5, 0xF, 0xF, false); // quad_perm:[1,1,3,3]
+    return u == 0 ? __builtin_amdgcn_mov_dpp(v, 0xA0, 0xF, 0xF, false)  // quad_perm:[0,0,2,2]
+                  : __builtin_amdgcn_mov_dpp(v, 0xF5, 0xF, 0xF, false); // quad_perm:[1,1,3,3]
   } else if constexpr (G == 4) {
     switch (u) { // compile-time after unrolling
-      case 0: return __builtin_amdgcn_update_dpp(v, v, 0x00, 0xF, 0xF, false);
-      case 1: return __builtin_amdgcn_update_dpp(v, v, 0x55, 0xF, 0xF, false);
-      case 2: return __builtin_amdgcn_update_dpp(v, v, 0xAA, 0xF, 0xF, false);
-      default: return __builtin_amdgcn_update_dpp(v, v, 0xFF, 0xF, 0xF, false);
+      case 0: return __builtin_amdgcn_mov_dpp(v, 0x00, 0xF, 0xF, false);
+      case 1: return __builtin_amdgcn_mov_dpp(v, 0x55, 0xF, 0xF, false);
+      case 2: return __builtin_amdgcn_mov_dpp(v, 0xAA, 0xF, 0xF, false);
+      default: return __builtin_amdgcn_mov_dpp(v, 0xFF, 0xF, 0xF, false);
     }
   } else {
     return __shfl(v, (lane & ~(G - 1)) + u, 64);
@@ -93,11 +93,11 @@ __device__ __forceinline__ double pair_bcast_f64(double v, int u0, int lane) {
   if constexpr (G == 4) {
     int lo = __double2loint(v), hi = __double2hiint(v);
     if (u0 == 0) { // quad_perm:[0,1,0,1]
-      lo = __builtin_amdgcn_update_dpp(lo, lo, 0x44, 0xF, 0xF, false);
-      hi = __builtin_amdgcn_update_dpp(hi, hi, 0x44, 0xF, 0xF, false);
+      lo = __builtin_amdgcn_mov_dpp(lo, 0x44, 0xF, 0xF, false);
+      hi = __builtin_amdgcn_mov_dpp(hi, 0x44, 0xF, 0xF, false);
     } else { // quad_perm:[2,3,2,3]
-      lo = __builtin_amdgcn_update_dpp(lo, lo, 0xEE, 0xF, 0xF, false);
-      hi = __builtin_amdgcn_update_dpp(hi, hi, 0xEE, 0xF, 0xF, false);
+      lo = __builtin_amdgcn_mov_dpp(lo, 0xEE, 0xF, 0xF, false);
+      hi = __builtin_amdgcn_mov_dpp(hi, 0xEE, 0xF, 0xF, false);
     }
     return __hiloint2double(hi, lo);
   } else {
@@ -215,7 +215,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
           if constexpr (G >= 4) dot += dpp_f64<DPP_XOR2>(dot);
           if constexpr (G >= 8) dot += swizzle_xor_f64<4>(dot);
           if constexpr (G >= 16) dot += swizzle_xor_f64<8>(dot);
-          const double av = pair_bcast_f64<G>(ab, u0, lane);
+          double av = pair_bcast_f64<G>(ab, u0, lane);
           double L, dL;
           if constexpr (LOSS == 0) {
             const double d = dot - av;

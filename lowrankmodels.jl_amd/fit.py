@@ -76,12 +76,18 @@ def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, 
     if np.linalg.norm(glrm.Y) == 0:
         raise ValueError("Y is all zeros (the reference cannot start from Y == 0, src/algorithms/proxgrad.jl:45-48)")
     use_dense = api.dense_ok and glrm.dense_eligible() and getattr(params, "dense", True)
-    key = (id(api), _engine_opts(params)["device_id"], glrm._descriptor_key(), use_dense)
+    hard, soft = glrm._descriptor_key()
+    key = (id(api), _engine_opts(params)["device_id"], hard, use_dense)
     if glrm._handle_cache is not None and glrm._handle_cache[2] != key:
         glrm.close()
     if glrm._handle_cache is None:
         h = api.create(glrm.problem_arrays(dense=use_dense), **_engine_opts(params))
-        glrm._handle_cache = (api, h, key)
+        glrm._handle_cache = (api, h, key, soft)
+    elif glrm._handle_cache[3] != soft:
+        # only the regularizers changed (scale_regularizer!, regularization_path): keep Omega / A on the device
+        from .regularizers import pack_regs
+        api.set_regularizers(glrm._handle_cache[1], pack_regs(glrm.rx), pack_regs(glrm.ry))
+        glrm._handle_cache = glrm._handle_cache[:3] + (soft,)
     h = glrm._handle_cache[1]
     if verbose:
         print("Fitting GLRM")

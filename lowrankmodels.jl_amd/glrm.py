@@ -215,12 +215,15 @@ class GLRM:
             losses, rx, ry, rb, re, cb, ce)
 
     def _descriptor_key(self):
-        return (pack_losses(self.losses).tobytes(), pack_regs(self.rx).tobytes(), pack_regs(self.ry).tobytes())
+        """(what forces a new engine handle, what can be updated in place): losses are baked into the handle's
+        validation and kernel choice; regularizer descriptors can be replaced as long as their counts stay."""
+        rx, ry = pack_regs(self.rx), pack_regs(self.ry)
+        return (pack_losses(self.losses).tobytes(), len(rx), len(ry)), (rx.tobytes(), ry.tobytes())
 
     def close(self):
         """Release the cached engine handle (device copies of Omega)."""
         if self._handle_cache is not None:
-            api, h, _ = self._handle_cache
+            api, h = self._handle_cache[:2]
             api.destroy(h)
             self._handle_cache = None
 

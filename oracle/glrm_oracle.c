@@ -705,6 +705,14 @@ int glrm_cpu_sum(glrm_cpu_handle* h, const void* vec, int64_t n, double* out) { 
   return GLRM_OK;
 }
 
+int glrm_cpu_set_regularizers(glrm_cpu_handle* h, const glrm_reg* rx, int64_t n_rx, const glrm_reg* ry, int64_t n_ry) {
+  if (!h || !rx || !ry) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (n_rx != h->n_rx || n_ry != h->n_ry) return fail(GLRM_ERR_INVALID, "regularizer counts must match the handle");
+  memcpy(h->rx, rx, (size_t)n_rx * sizeof(glrm_reg));
+  memcpy(h->ry, ry, (size_t)n_ry * sizeof(glrm_reg));
+  return GLRM_OK;
+}
+
 int glrm_cpu_synchronize(glrm_cpu_handle* h) { (void)h; return GLRM_OK; }
 int glrm_cpu_factor_ld(glrm_cpu_handle* h) { return h ? h->k : GLRM_ERR_INVALID; }
 

@@ -317,3 +317,31 @@ def test_step_x_range_chunks_equal_full_sweep(mode):
         api.destroy(h)
         res.append((X, Y, st["trials_x"], st["accepts_x"]))
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
+
+
+def test_set_regularizers_keeps_the_handle_and_matches_a_fresh_one():
+    rng = np.random.default_rng(95)
+    pa, X0, Y0 = random_problem(rng, 200, 90, 12, 0.4, rx=L.QuadReg(1.0), ry=L.QuadReg(1.0))
+    api, params = hip(), L.ProxGradParams(max_iter=8)
+    h = api.create(pa)
+    X, Y = X0.copy(order="F"), Y0.copy(order="F")
+    api.fit(h, params, X, Y)
+    new = np.array([(1, 0, 0.2)], dtype=_capi.REG_DTYPE)
+    api.set_regularizers(h, new, new)
+    o2, _ = api.fit(h, params, X, Y)
+    api.destroy(h)
+    pb = _capi.ProblemArrays(pa.m, pa.n, pa.k, pa.rowptr, pa.colidx, pa.rowvals, pa.colptr, pa.rowidx, pa.colvals, pa.losses, new, new)
+    h = api.create(pa)
+    Xr, Yr = X0.copy(order="F"), Y0.copy(order="F")
+    api.fit(h, params, Xr, Yr)
+    api.destroy(h)
+    h = api.create(pb)
+    o3, _ = api.fit(h, params, Xr, Yr)
+    api.destroy(h)
+    assert np.array_equal(o2, o3) and np.array_equal(X, Xr) and np.array_equal(Y, Yr)
+    with pytest.raises(_capi.GLRMError):
+        h = api.create(pa)
+        try:
+            api.set_regularizers(h, np.repeat(new, 3), new)
+        finally:
+            api.destroy(h)
