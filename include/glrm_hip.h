@@ -139,6 +139,15 @@ typedef struct glrm_params {
   double min_stepsize;
 } glrm_params;
 
+/* SparseProxGradParams, src/algorithms/sparse_proxgrad.jl:4-19: the solver `fit!(glrm)` picks for SparseMatrixCSC input. */
+typedef struct glrm_sparse_params {
+  double stepsize;
+  int64_t max_iter;
+  int64_t inner_iter;
+  double abs_tol;
+  double min_stepsize;
+} glrm_sparse_params;
+
 typedef struct glrm_options {
   int32_t device_id; /* HIP device ordinal; -1 = current device */
   int32_t profile;   /* 1 = bracket every sweep launch with HIP events (glrm_hip_kernel_stats) */
@@ -173,6 +182,15 @@ void glrm_hip_destroy(glrm_handle* h); /* NULL is a no-op */
 int glrm_hip_fit(glrm_handle* h, const glrm_params* prm, double* X, double* Y,
                  double* objective, double* seconds, int64_t cap, int64_t* n_recorded);
 
+/*
+ * fit!(glrm, SparseProxGradParams) (src/algorithms/sparse_proxgrad.jl:22-134): one global step size, one gradient + prox
+ * step per factor and iteration (no per-row line search), the whole iteration is accepted or reverted on the full
+ * objective(glrm, X, Y; sparse=true).  objective[] holds the initial objective, one entry per ACCEPTED iteration and the
+ * last value once more (:126-127); cap must be >= max_iter+2.  X, Y return the best model found.
+ */
+int glrm_hip_fit_sparse(glrm_handle* h, const glrm_sparse_params* prm, double* X, double* Y, double* objective,
+                        double* seconds, int64_t cap, int64_t* n_recorded);
+
 /* objective(glrm, X, Y; include_regularization) over observed_examples (src/evaluate_fit.jl:57-81). */
 int glrm_hip_objective(glrm_handle* h, const double* X, const double* Y, int include_reg, double* out);
 
@@ -196,6 +214,10 @@ int glrm_hip_get_factors(glrm_handle* h, double* X, double* Y);             /* d
 int glrm_hip_reset_stepsizes(glrm_handle* h, double stepsize);              /* alpharow, alphacol (:69-70,:112-115) */
 int glrm_hip_step_x(glrm_handle* h, double min_stepsize);                   /* one inner X sweep (:118-156) */
 int glrm_hip_step_y(glrm_handle* h, double min_stepsize);                   /* one inner Y sweep (:162-201) */
+/* One prox-gradient step of the shard's rows / columns with a global step size and no line search
+ * (src/algorithms/sparse_proxgrad.jl:59-77 / :81-99). */
+int glrm_hip_gradstep_x(glrm_handle* h, double alpha);
+int glrm_hip_gradstep_y(glrm_handle* h, double alpha);
 /* The X sweep restricted to the shard's local rows [seg_begin, seg_end): lets a multi-GPU host pipeline the
  * all-gather of finished row chunks behind the sweep of the next chunk (rows are independent, :118). */
 int glrm_hip_step_x_range(glrm_handle* h, int64_t seg_begin, int64_t seg_end, double min_stepsize);

@@ -11,7 +11,7 @@ from .fit import ShardedFit, fit, fit_b, objective, partition
 from .glrm import GLRM, copy_estimate, parameter_estimate, scale_regularizer_, sort_observations
 from .losses import (HingeLoss, HuberLoss, L1Loss, LogisticLoss, Loss, OrdinalHingeLoss, PeriodicLoss,
                      PoissonLoss, QuadLoss, QuantileLoss, WeightedHingeLoss, embedding_dim, evaluate, grad)
-from .params import AbstractParams, HipProxGradParams, Params, ProxGradParams
+from .params import AbstractParams, HipProxGradParams, Params, ProxGradParams, SparseProxGradParams
 from .regularizers import (NonNegConstraint, OneReg, QuadReg, Regularizer, UnitOneSparseConstraint, ZeroReg, prox)
 
 fit_inplace = fit_b  # Julia's `fit!`

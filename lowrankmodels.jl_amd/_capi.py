@@ -60,6 +60,11 @@ class CParams(C.Structure):
     ]
 
 
+class CSparseParams(C.Structure):
+    _fields_ = [("stepsize", C.c_double), ("max_iter", C.c_int64), ("inner_iter", C.c_int64), ("abs_tol", C.c_double),
+                ("min_stepsize", C.c_double)]
+
+
 class COptions(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("profile", C.c_int32), ("waves_row", C.c_int32), ("waves_col", C.c_int32),
                 ("stream", C.c_void_p), ("caller_stream", C.c_int32), ("tiled", C.c_int32)]
@@ -80,8 +85,8 @@ class CKernelStats(C.Structure):
 #: every symbol include/glrm_hip.h declares (suffix after the prefix); the CPU test-suite checks
 #: that the built library exports all of them.
 ABI_SYMBOLS = (
-    "version", "last_error", "create", "destroy", "fit", "objective", "factor_ld", "bind_buffers",
-    "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "col_losses", "row_penalties",
+    "version", "last_error", "create", "destroy", "fit", "fit_sparse", "objective", "factor_ld", "bind_buffers",
+    "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "gradstep_x", "gradstep_y", "col_losses", "row_penalties",
     "col_penalties", "set_regularizers", "sum", "synchronize", "kernel_stats",
 )
 
@@ -109,6 +114,10 @@ class Api:
             "destroy": (None, [H]),
             "fit": (C.c_int, [H, C.POINTER(CParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                               C.POINTER(C.c_int64)]),
+            "fit_sparse": (C.c_int, [H, C.POINTER(CSparseParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.POINTER(C.c_int64)]),
+            "gradstep_x": (C.c_int, [H, C.c_double]),
+            "gradstep_y": (C.c_int, [H, C.c_double]),
             "objective": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_double)]),
             "factor_ld": (C.c_int, [H]),
             "bind_buffers": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -181,6 +190,20 @@ class Api:
                      params.rel_tol, params.min_stepsize)
         self._ck(self._f["fit"](h, C.byref(cp), _ptr(X), _ptr(Y), _ptr(obj), _ptr(sec), cap, C.byref(nrec)))
         return obj[: nrec.value].copy(), sec[: nrec.value].copy()
+
+    def fit_sparse(self, h, params, X, Y):
+        cap = int(params.max_iter) + 2
+        obj, sec = np.zeros(cap), np.zeros(cap)
+        nrec = C.c_int64(0)
+        cp = CSparseParams(params.stepsize, params.max_iter, params.inner_iter, params.abs_tol, params.min_stepsize)
+        self._ck(self._f["fit_sparse"](h, C.byref(cp), _ptr(X), _ptr(Y), _ptr(obj), _ptr(sec), cap, C.byref(nrec)))
+        return obj[: nrec.value].copy(), sec[: nrec.value].copy()
+
+    def gradstep_x(self, h, alpha):
+        self._ck(self._f["gradstep_x"](h, float(alpha)))
+
+    def gradstep_y(self, h, alpha):
+        self._ck(self._f["gradstep_y"](h, float(alpha)))
 
     def objective(self, h, X, Y, include_reg=True) -> float:
         out = C.c_double(0.0)

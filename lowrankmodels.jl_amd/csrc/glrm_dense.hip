@@ -151,11 +151,12 @@ int glrm_run_dense(glrm_handle* h, bool rows, double min_stepsize, int eval_only
   a.ntrial = rows ? h->ntrial_r : h->ntrialbuf;
   a.nactive = h->nactive;
   a.eval_only = eval_only;
+  a.fixed_alpha = eval_only ? 0.0 : h->fixed_alpha;
   HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
   launch_dense_any(h->kp, true, d, h->stream);
   glrm_launch_col_small(h->kp, 0, a, h->stream);
   HIPCK(hipGetLastError());
-  if (eval_only) return GLRM_OK;
+  if (eval_only || a.fixed_alpha > 0.0) return GLRM_OK;
   DenseArgs t = d;
   t.xsrc = a.trial; // trial points are stored per local segment
   t.own_offset = 0;

@@ -40,6 +40,7 @@ struct glrm_handle {
   int unroll_row = 1, unroll_col = 1;
   // LDS-tiled sweeps (glrm_tiled.hpp)
   bool rows_sorted = false, cols_sorted = false;
+  double fixed_alpha = 0.0;           // > 0 while a SparseProxGradParams step (no line search) is being launched
   int64_t rng_b = 0, rng_e = -1;      // row sub-range of the next X sweep (glrm_hip_step_x_range); rng_e < 0 = all
   int tiled_opt = 0;                  // glrm_options.tiled
   int tiled_row = 0, tiled_col = 0;   // 0 = gather sweep, 1 = tiled

@@ -49,6 +49,7 @@ struct SweepArgs {
   int reg_single;        // 1 -> regs[0], 0 -> regs[seg]
   int k;
   int eval_only;         // 1: obj[seg] = sum of losses (no regularizer), nothing else is written
+  double fixed_alpha;    // > 0: one prox-gradient step with this global step size, no line search (SparseProxGradParams)
   double min_stepsize;
   int32_t* trials;       // per local segment accumulators (nullable)
   int32_t* accepts;
@@ -218,6 +219,21 @@ __global__ void __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64) sweep_kernel(co
   Jold = block_combine<G, R, WAVES, true>(Jold, g, red, wave, lane);
   if constexpr (EVAL) {
     if (threadIdx.x == (WAVES == 1 ? wave * 64 : 0) && a.obj) a.obj[gseg] = Jold;
+    return;
+  }
+  if (a.fixed_alpha > 0.0) { // src/algorithms/sparse_proxgrad.jl:72-77 / :94-99: g *= -alpha/l; x += g; prox!(r, x, alpha/l)
+    const double s = a.fixed_alpha / ((double)len + 1.0);
+    Vec<G, R> xn;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      xn.v[i].x = x.v[i].x + g.v[i].x * (-s);
+      xn.v[i].y = x.v[i].y + g.v[i].y * (-s);
+    }
+    reg_prox<G, R>(rd, xn, s, j, a.k);
+    if (wave == (WAVES == 1 ? wave : 0) && gi == 0) {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = xn.v[i];
+    }
     return;
   }
   Jold += reg_eval<G, R>(rd, x, j, a.k);
@@ -749,6 +765,7 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
   a.reg_single = (rows ? h->n_rx : h->n_ry) == 1;
   a.k = h->k;
   a.eval_only = eval_only;
+  a.fixed_alpha = eval_only ? 0.0 : h->fixed_alpha;
   a.min_stepsize = min_stepsize;
   a.trials = eval_only ? nullptr : (rows ? h->trials_r : h->trials_c);
   a.accepts = rows ? h->accepts_r : h->accepts_c;
@@ -818,6 +835,19 @@ extern "C" int glrm_hip_step_y(glrm_handle* h, double min_stepsize) {
   DeviceGuard dg(h->device);
   return run_sweep(h, 1, min_stepsize, 0);
 }
+
+// One prox-gradient step with a global step size and no line search (src/algorithms/sparse_proxgrad.jl:59-77, :81-99).
+static int gradstep(glrm_handle* h, int which, double alpha) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (!(alpha > 0.0)) return fail(GLRM_ERR_INVALID, "the step size must be positive");
+  DeviceGuard dg(h->device);
+  h->fixed_alpha = alpha;
+  const int rc = run_sweep(h, which, 0.0, 0);
+  h->fixed_alpha = 0.0;
+  return rc;
+}
+extern "C" int glrm_hip_gradstep_x(glrm_handle* h, double alpha) { return gradstep(h, 0, alpha); }
+extern "C" int glrm_hip_gradstep_y(glrm_handle* h, double alpha) { return gradstep(h, 1, alpha); }
 
 extern "C" int glrm_hip_col_losses(glrm_handle* h) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
@@ -972,4 +1002,74 @@ extern "C" int glrm_hip_fit(glrm_handle* h, const glrm_params* prm, double* X, d
   if ((rc = glrm_hip_get_factors(h, X, Y))) return rc;
   *n_recorded = nrec;
   return GLRM_OK;
+}
+
+// fit!(glrm::GLRM, params::SparseProxGradParams), src/algorithms/sparse_proxgrad.jl:22-134: global step size, one
+// gradient + prox step per factor and iteration, whole-iteration accept / revert on the full objective.
+extern "C" int glrm_hip_fit_sparse(glrm_handle* h, const glrm_sparse_params* prm, double* X, double* Y, double* objective,
+                                   double* seconds, int64_t cap, int64_t* n_recorded) {
+  if (!h || !prm || !X || !Y || !objective || !seconds || !n_recorded) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (!single_shard(h)) return fail(GLRM_ERR_INVALID, "glrm_hip_fit_sparse needs a single-shard handle");
+  if (prm->max_iter < 0 || cap < prm->max_iter + 2) return fail(GLRM_ERR_INVALID, "objective/seconds capacity must be >= max_iter+2");
+  if (prm->inner_iter < 1) return fail(GLRM_ERR_INVALID, "inner_iter must be >= 1");
+  double ynorm = 0.0; // norm(Y)==0 would be re-randomised by the reference (:41-43); not reproducible -> error
+  for (int64_t i = 0; i < (int64_t)h->k * h->n; ++i) ynorm += Y[i] * Y[i];
+  if (ynorm == 0.0) return fail(GLRM_ERR_INVALID, "Y is all zeros");
+  DeviceGuard dg(h->device);
+  int rc;
+  if ((rc = glrm_hip_set_factors(h, X, Y))) return rc; // working copies X, Y (:33); glrm.X / glrm.Y = best so far
+  const size_t xb = (size_t)h->kp * h->m * 8, yb = (size_t)h->kp * h->n * 8;
+  double *bestX = nullptr, *bestY = nullptr;
+  HIPCK(hipMalloc((void**)&bestX, xb));
+  if (hipMalloc((void**)&bestY, yb) != hipSuccess) { (void)hipFree(bestX); return fail(GLRM_ERR_OOM, "out of device memory"); }
+  auto cleanup = [&](int code) { (void)hipFree(bestX); (void)hipFree(bestY); return code; };
+  if (hipMemcpyAsync(bestX, h->X, xb, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+      hipMemcpyAsync(bestY, h->Y, yb, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+    return cleanup(fail(GLRM_ERR_HIP, "device copy failed"));
+  double alpha = prm->stepsize;                              // :46
+  const double tol = prm->abs_tol * (double)h->nnz_r;        // :48
+  int64_t nrec = 0;
+  if ((rc = device_objective(h, 1, &objective[0]))) return cleanup(rc); // update_ch!(ch, 0, objective(glrm; sparse=true)) :52
+  seconds[0] = 0.0;
+  nrec = 1;
+  double t = now_s();
+  int64_t steps_in_a_row = 0;
+  for (int64_t i = 1; i <= prm->max_iter; ++i) {
+    for (int64_t in = 0; in < prm->inner_iter; ++in) { h->fixed_alpha = alpha; rc = run_sweep(h, 0, 0.0, 0); h->fixed_alpha = 0.0; if (rc) return cleanup(rc); }
+    for (int64_t in = 0; in < prm->inner_iter; ++in) { h->fixed_alpha = alpha; rc = run_sweep(h, 1, 0.0, 0); h->fixed_alpha = 0.0; if (rc) return cleanup(rc); }
+    double obj = 0.0;
+    if ((rc = device_objective(h, 1, &obj))) return cleanup(rc); // :102
+    if (obj < objective[nrec - 1]) {                              // :104-110
+      const double dt = now_s() - t;
+      objective[nrec] = obj;
+      seconds[nrec] = seconds[nrec - 1] + dt;
+      ++nrec;
+      if (hipMemcpyAsync(bestX, h->X, xb, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+          hipMemcpyAsync(bestY, h->Y, yb, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+        return cleanup(fail(GLRM_ERR_HIP, "device copy failed"));
+      alpha = alpha * 1.05;
+      steps_in_a_row = steps_in_a_row + 1 > 1 ? steps_in_a_row + 1 : 1;
+      t = now_s();
+    } else {                                                      // :111-117
+      const double div = -(double)steps_in_a_row > 1.5 ? -(double)steps_in_a_row : 1.5;
+      alpha = alpha / div;
+      if (hipMemcpyAsync(h->X, bestX, xb, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+          hipMemcpyAsync(h->Y, bestY, yb, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+        return cleanup(fail(GLRM_ERR_HIP, "device copy failed"));
+      steps_in_a_row = steps_in_a_row - 1 < 0 ? steps_in_a_row - 1 : 0;
+    }
+    // :119  i>10 && (steps_in_a_row > 3 && ch.objective[end-1] - obj < tol) || alpha <= params.min_stepsize
+    if ((i > 10 && (steps_in_a_row > 3 && nrec >= 2 && objective[nrec - 2] - obj < tol)) || alpha <= prm->min_stepsize) break;
+  }
+  // :126-127 the last objective is recorded once more with the remaining time
+  objective[nrec] = objective[nrec - 1];
+  seconds[nrec] = seconds[nrec - 1] + (now_s() - t);
+  ++nrec;
+  // glrm.X, glrm.Y are the best model found
+  if (hipMemcpyAsync(h->X, bestX, xb, hipMemcpyDeviceToDevice, h->stream) != hipSuccess ||
+      hipMemcpyAsync(h->Y, bestY, yb, hipMemcpyDeviceToDevice, h->stream) != hipSuccess)
+    return cleanup(fail(GLRM_ERR_HIP, "device copy failed"));
+  rc = glrm_hip_get_factors(h, X, Y);
+  *n_recorded = nrec;
+  return cleanup(rc);
 }

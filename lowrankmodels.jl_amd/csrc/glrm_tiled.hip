@@ -72,9 +72,12 @@ static int launch_tiled_inst(int kind, const TiledArgs& a, hipStream_t st) {
   const int lds = TILE * tile_row_bytes<G, R>();
   const unsigned gx = (unsigned)((a.nseg + SPB - 1) / SPB);
   int rc = GLRM_OK;
-  if (kind == 0) {
-    if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS>, lds))) return rc;
-    hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS>), dim3(gx), dim3(NW * 64), lds, st, a);
+  if (kind == 0 && a.fixed_alpha > 0.0) {
+    if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS, true>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS, true>), dim3(gx), dim3(NW * 64), lds, st, a);
+  } else if (kind == 0) {
+    if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS, false>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS, false>), dim3(gx), dim3(NW * 64), lds, st, a);
   } else if (kind == 1) {
     if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true>, lds))) return rc;
     hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
@@ -151,6 +154,7 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
   a.trials = rows ? h->trials_r : h->trials_c;
   a.accepts = rows ? h->accepts_r : h->accepts_c;
   a.eval_only = eval_only;
+  a.fixed_alpha = eval_only ? 0.0 : h->fixed_alpha;
   if (rows && h->rng_e >= 0) { // glrm_hip_step_x_range
     const int64_t s0 = h->rng_b;
     a.nseg = h->rng_e - s0;
@@ -169,7 +173,7 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
   if ((rc = launch_tiled(h, loss, 1, a))) return rc;
   launch_col_small_any(h, 0, a);
   HIPCK(hipGetLastError());
-  if (eval_only) return GLRM_OK;
+  if (eval_only || a.fixed_alpha > 0.0) return GLRM_OK;
   for (int round = 0; round < 64; ++round) {
     unsigned int nact = 0;
     HIPCK(hipMemcpyAsync(&nact, h->nactive, 4, hipMemcpyDeviceToHost, h->stream));

@@ -53,6 +53,7 @@ struct TiledArgs {
   unsigned int* nactive; // device counter of still-active segments
   int eval_only;         // col_reduce: obj = sum of losses, nothing else
   int64_t dense_len;     // ptr == nullptr (dense problem): every segment has this many observations
+  double fixed_alpha;    // > 0: one prox-gradient step with this global step size, no line search
 };
 
 template <int G>
@@ -268,7 +269,9 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
 // ------------------------------------------------------------------------------------------------
 // X half-step (and any sweep whose segments are plentiful): whole sweep in one kernel.
 // Workgroup = NW waves, SPB = NW*64/G segments; each pass streams the WHOLE opposing factor through LDS.
-template <int G, int R, int NW, int TILE, int LOSS>
+// FIXED = true is the SparseProxGradParams step (one gradient pass, x <- prox(x - (alpha/l) g), no line search); it is a
+// separate instantiation so that the line-search kernel keeps its register budget.
+template <int G, int R, int NW, int TILE, int LOSS, bool FIXED>
 __global__ void __launch_bounds__(NW * 64, 4) tiled_sweep_kernel(const TiledArgs a) {
   constexpr int KP = G * R, NGW = 64 / G, SPB = NW * NGW;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -281,20 +284,40 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_sweep_kernel(const TiledArgs
   double2* ownp = reinterpret_cast<double2*>(a.own + gseg * KP);
   const int ntiles = (int)((a.n_other + TILE - 1) / TILE);
 
-  Vec<G, R> x, g, xn;
-#pragma unroll
-  for (int i = 0; i < R / 2; ++i) x.v[i] = have ? ownp[i * G + j] : make_double2(0.0, 0.0);
+  Vec<G, R> g, xn;
   const RegDesc rd = load_reg(a.regs, (a.reg_single || !have) ? 0 : seg);
   LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
   if constexpr (LOSS != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
+  const double l = (double)(end - beg) + 1.0;
 
   double Jold;
   int64_t pos = beg;
-  tiled_pass<G, R, NW, TILE, LOSS, true>(a, lds, x, g, Jold, have, pos, end, 0, ntiles, segloss, lane, j);
-  Jold += reg_eval<G, R>(rd, x, j, a.k);
+  {
+    Vec<G, R> x;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) x.v[i] = have ? ownp[i * G + j] : make_double2(0.0, 0.0);
+    tiled_pass<G, R, NW, TILE, LOSS, true>(a, lds, x, g, Jold, have, pos, end, 0, ntiles, segloss, lane, j);
+    if constexpr (FIXED) { // src/algorithms/sparse_proxgrad.jl:72-78: g *= -alpha/l; x += g; prox!(r, x, alpha/l)
+      const double s = a.fixed_alpha / l;
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) {
+        xn.v[i].x = x.v[i].x + g.v[i].x * (-s);
+        xn.v[i].y = x.v[i].y + g.v[i].y * (-s);
+      }
+      reg_prox<G, R>(rd, xn, s, j, a.k);
+      if (have) {
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = xn.v[i];
+      }
+      return;
+    }
+    Jold += reg_eval<G, R>(rd, x, j, a.k);
+  }
 
+  // Backtracking line search.  The current point is NOT kept in registers across the trial passes: it is re-read
+  // from the factor array when the next trial point is formed (32 B per lane per trial) and the accepted point is
+  // written back at once, which frees R VGPRs per lane inside the pass.
   double alpha = have ? a.alpha[seg] : 0.0;
-  const double l = (double)(end - beg) + 1.0;
   int ntrials = 0;
   bool accepted = false;
   bool searching = have && alpha > a.min_stepsize;
@@ -302,8 +325,9 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_sweep_kernel(const TiledArgs
     const double s = alpha / l;
 #pragma unroll
     for (int i = 0; i < R / 2; ++i) {
-      xn.v[i].x = fma(-s, g.v[i].x, x.v[i].x);
-      xn.v[i].y = fma(-s, g.v[i].y, x.v[i].y);
+      const double2 xi = have ? ownp[i * G + j] : make_double2(0.0, 0.0);
+      xn.v[i].x = fma(-s, g.v[i].x, xi.x);
+      xn.v[i].y = fma(-s, g.v[i].y, xi.y);
     }
     reg_prox<G, R>(rd, xn, s, j, a.k);
     double Jn;
@@ -314,7 +338,8 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_sweep_kernel(const TiledArgs
     if (searching) {
       ++ntrials;
       if (Jn < Jold) {
-        x = xn;
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = xn.v[i];
         alpha *= 1.05;
         Jold = Jn;
         accepted = true;
@@ -328,18 +353,12 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_sweep_kernel(const TiledArgs
       }
     }
   }
-  if (have) {
-    if (accepted) {
-#pragma unroll
-      for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = x.v[i];
-    }
-    if (j == 0) {
-      a.alpha[seg] = alpha;
-      if (a.obj) a.obj[gseg] = Jold;
-      if (a.trials) {
-        a.trials[seg] += ntrials;
-        a.accepts[seg] += accepted ? 1 : 0;
-      }
+  if (have && j == 0) {
+    a.alpha[seg] = alpha;
+    if (a.obj) a.obj[gseg] = Jold;
+    if (a.trials) {
+      a.trials[seg] += ntrials;
+      a.accepts[seg] += accepted ? 1 : 0;
     }
   }
 }
@@ -426,6 +445,21 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const TiledArgs a) {
 #pragma unroll
   for (int i = 0; i < R / 2; ++i) y.v[i] = yp[i * G + j];
   const RegDesc rd = load_reg(a.regs, a.reg_single ? 0 : seg);
+  if (a.fixed_alpha > 0.0) { // SparseProxGradParams step on this segment, no trial rounds
+    const double l0 = (double)(a.ptr ? a.ptr[seg + 1] - a.ptr[seg] : a.dense_len) + 1.0;
+    const double s0 = a.fixed_alpha / l0;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      yn.v[i].x = y.v[i].x + g.v[i].x * (-s0);
+      yn.v[i].y = y.v[i].y + g.v[i].y * (-s0);
+    }
+    reg_prox<G, R>(rd, yn, s0, j, a.k);
+    double2* yw = reinterpret_cast<double2*>(a.own + gseg * KP);
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) yw[i * G + j] = yn.v[i];
+    if (j == 0) a.active[seg] = 0;
+    return;
+  }
   const double Jold = J + reg_eval<G, R>(rd, y, j, a.k);
   const double alpha = a.alpha[seg];
   const double l = (double)(a.ptr ? a.ptr[seg + 1] - a.ptr[seg] : a.dense_len) + 1.0;

@@ -15,7 +15,7 @@ import numpy as np
 
 from . import _capi
 from .convergence import ConvergenceHistory, update_ch
-from .params import AbstractParams, HipProxGradParams, ProxGradParams
+from .params import AbstractParams, HipProxGradParams, ProxGradParams, SparseProxGradParams
 
 
 def _engine_opts(params):
@@ -62,8 +62,9 @@ def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, 
         params = HipProxGradParams()
     if not isinstance(params, AbstractParams):
         raise TypeError("params must be an AbstractParams (ProxGradParams / HipProxGradParams)")
+    sparse = isinstance(params, SparseProxGradParams)
     if ch is None:
-        ch = ConvergenceHistory("ProxGradGLRM")
+        ch = ConvergenceHistory("SparseProxGradGLRM" if sparse else "ProxGradGLRM")
     api = engine if engine is not None else _capi.hip_api()
     world = 1
     if group is not None or os.environ.get("WORLD_SIZE", "1") != "1":
@@ -71,6 +72,8 @@ def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, 
         if dist.is_available() and dist.is_initialized():
             world = dist.get_world_size(group)
     if world > 1:
+        if sparse:
+            raise NotImplementedError("SparseProxGradParams runs on a single shard (step-level gradstep_x / gradstep_y exist for hosts)")
         return _fit_distributed(glrm, params, ch, verbose, api, group)
 
     if np.linalg.norm(glrm.Y) == 0:
@@ -89,10 +92,20 @@ def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, 
         api.set_regularizers(glrm._handle_cache[1], pack_regs(glrm.rx), pack_regs(glrm.ry))
         glrm._handle_cache = glrm._handle_cache[:3] + (soft,)
     h = glrm._handle_cache[1]
-    if verbose:
-        print("Fitting GLRM")
     X = np.asfortranarray(glrm.X, dtype=np.float64)
     Y = np.asfortranarray(glrm.Y, dtype=np.float64)
+    if sparse:  # src/algorithms/sparse_proxgrad.jl:22-134
+        if verbose:
+            print(params)
+            print("Fitting GLRM")
+        obj, sec = api.fit_sparse(h, params, X, Y)
+        glrm.X[...] = X
+        glrm.Y[...] = Y
+        for i in range(len(obj)):
+            update_ch(ch, sec[i] - (sec[i - 1] if i else 0.0), float(obj[i]))
+        return glrm.X, glrm.Y, ch
+    if verbose:
+        print("Fitting GLRM")
     obj, sec = api.fit(h, params, X, Y)
     if X is not glrm.X:
         glrm.X[...] = X

@@ -39,3 +39,19 @@ class HipProxGradParams(ProxGradParams):
 
 def Params(*args, **kwargs):  # src/fit.jl:5
     return ProxGradParams(*args, **kwargs)
+
+
+class SparseProxGradParams(AbstractParams):
+    """SparseProxGradParams(stepsize=1.0; max_iter=100, inner_iter=1, abs_tol=1e-5, min_stepsize=0.01*stepsize)
+    (src/algorithms/sparse_proxgrad.jl:4-19): one global step size, whole-iteration accept / revert.  The reference's
+    `fit!(glrm)` picks it for SparseMatrixCSC input (src/fit.jl:13-15)."""
+
+    def __init__(self, stepsize=1.0, *, max_iter=100, inner_iter=1, abs_tol=0.00001, min_stepsize=None, device_id=-1, tiled=0):
+        self.stepsize = float(stepsize)
+        self.max_iter, self.inner_iter = int(max_iter), int(inner_iter)
+        self.abs_tol = float(abs_tol)
+        self.min_stepsize = float(0.01 * self.stepsize if min_stepsize is None else min_stepsize)
+        self.device_id, self.tiled = int(device_id), int(tiled)
+
+    def __repr__(self):  # Julia prints the struct positionally (println(params), sparse_proxgrad.jl:26)
+        return f"SparseProxGradParams({self.stepsize}, {self.max_iter}, {self.inner_iter}, {self.abs_tol}, {self.min_stepsize})"

@@ -845,3 +845,117 @@ int glrm_cpu_fit(glrm_cpu_handle* h, const glrm_params* prm, double* X, double* 
   *n_recorded = nrec;
   return GLRM_OK;
 }
+
+/* ------------------------------------------------------------------ SparseProxGradParams
+ * fit!(glrm::GLRM, params::SparseProxGradParams), src/algorithms/sparse_proxgrad.jl:22-134. */
+
+/* One X step: for every local row, g = sum grad * y_f (:66-70), g *= -alpha/l (:74), x += g (:76), prox! (:78). */
+int glrm_cpu_gradstep_x(glrm_cpu_handle* h, double alpha) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (!(alpha > 0.0)) return fail(GLRM_ERR_INVALID, "the step size must be positive");
+  const int k = h->k;
+  const int64_t ml = h->row_end - h->row_begin;
+#pragma omp parallel num_threads(g_threads)
+  {
+    double g[ORACLE_MAX_K];
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t el = 0; el < ml; ++el) {
+      double* x = h->X + (h->row_begin + el) * k;
+      const int64_t b = h->rowptr[el], e = h->rowptr[el + 1];
+      for (int c = 0; c < k; ++c) g[c] = 0.0;
+      for (int64_t t = b; t < e; ++t) {
+        const int64_t f = h->colidx[t];
+        const double* y = h->Y + f * k;
+        const double cg = glrm_cpu_loss_grad(loss_of(h, f), dotk(x, y, k), h->rowvals[t]);
+        for (int c = 0; c < k; ++c) g[c] = fma(cg, y[c], g[c]);
+      }
+      const double l = (double)(e - b) + 1;
+      const double s = alpha / l;
+      for (int c = 0; c < k; ++c) g[c] = g[c] * (-s); /* rmul!(g, -alpha/l) */
+      for (int c = 0; c < k; ++c) x[c] = x[c] + g[c];  /* axpy!(1, g, ve[e]) */
+      glrm_cpu_reg_prox(rx_of(h, el), x, k, s);
+    }
+  }
+  return GLRM_OK;
+}
+
+/* One Y step, :81-99. */
+int glrm_cpu_gradstep_y(glrm_cpu_handle* h, double alpha) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (!(alpha > 0.0)) return fail(GLRM_ERR_INVALID, "the step size must be positive");
+  const int k = h->k;
+  const int64_t nl = h->col_end - h->col_begin;
+#pragma omp parallel num_threads(g_threads)
+  {
+    double g[ORACLE_MAX_K];
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t fl = 0; fl < nl; ++fl) {
+      const int64_t fg = h->col_begin + fl;
+      double* y = h->Y + fg * k;
+      const int64_t b = h->colptr[fl], e = h->colptr[fl + 1];
+      const glrm_loss* lo = loss_of(h, fg);
+      for (int c = 0; c < k; ++c) g[c] = 0.0;
+      for (int64_t t = b; t < e; ++t) {
+        const double* x = h->X + (int64_t)h->rowidx[t] * k;
+        const double cg = glrm_cpu_loss_grad(lo, dotk(x, y, k), h->colvals[t]);
+        for (int c = 0; c < k; ++c) g[c] = fma(cg, x[c], g[c]);
+      }
+      const double l = (double)(e - b) + 1;
+      const double s = alpha / l;
+      for (int c = 0; c < k; ++c) g[c] = g[c] * (-s);
+      for (int c = 0; c < k; ++c) y[c] = y[c] + g[c];
+      glrm_cpu_reg_prox(ry_of(h, fl), y, k, s);
+    }
+  }
+  return GLRM_OK;
+}
+
+int glrm_cpu_fit_sparse(glrm_cpu_handle* h, const glrm_sparse_params* prm, double* X, double* Y, double* objective,
+                        double* seconds, int64_t cap, int64_t* n_recorded) {
+  if (!h || !prm || !X || !Y || !objective || !seconds || !n_recorded) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (!single_shard(h)) return fail(GLRM_ERR_INVALID, "glrm_cpu_fit_sparse needs a single-shard handle");
+  if (h->dense_faithful) return fail(GLRM_ERR_UNSUPPORTED, "not available in dense-faithful mode");
+  if (prm->max_iter < 0 || cap < prm->max_iter + 2) return fail(GLRM_ERR_INVALID, "objective/seconds capacity must be >= max_iter+2");
+  if (prm->inner_iter < 1) return fail(GLRM_ERR_INVALID, "inner_iter must be >= 1");
+  const int k = h->k;
+  double ynorm = 0.0;
+  for (int64_t i = 0; i < (int64_t)k * h->n; ++i) ynorm += Y[i] * Y[i];
+  if (ynorm == 0.0) return fail(GLRM_ERR_INVALID, "Y is all zeros");
+  const size_t xb = (size_t)k * h->m * 8, yb = (size_t)k * h->n * 8;
+  glrm_cpu_bind_buffers(h, NULL, NULL, NULL, NULL);
+  glrm_cpu_set_factors(h, X, Y); /* working copies X, Y (:33); X, Y arguments hold the best model (glrm.X, glrm.Y) */
+  double alpha = prm->stepsize;                                 /* :46 */
+  const double tol = prm->abs_tol * (double)h->rowptr[h->m];    /* :48 */
+  int64_t nrec = 0;
+  objective[nrec] = full_objective(h, h->X, h->Y, 1);           /* objective(glrm; sparse=true) :52 */
+  seconds[nrec] = 0.0;
+  ++nrec;
+  double t = now_s();
+  int64_t steps_in_a_row = 0;
+  for (int64_t i = 1; i <= prm->max_iter; ++i) {
+    for (int64_t in = 0; in < prm->inner_iter; ++in) glrm_cpu_gradstep_x(h, alpha);
+    for (int64_t in = 0; in < prm->inner_iter; ++in) glrm_cpu_gradstep_y(h, alpha);
+    const double obj = full_objective(h, h->X, h->Y, 1);        /* :102 */
+    if (obj < objective[nrec - 1]) {                            /* :104-110 */
+      const double dt = now_s() - t;
+      objective[nrec] = obj;
+      seconds[nrec] = seconds[nrec - 1] + dt;
+      ++nrec;
+      memcpy(X, h->X, xb); memcpy(Y, h->Y, yb);
+      alpha = alpha * 1.05;
+      steps_in_a_row = steps_in_a_row + 1 > 1 ? steps_in_a_row + 1 : 1;
+      t = now_s();
+    } else {                                                    /* :111-117 */
+      const double div = -(double)steps_in_a_row > 1.5 ? -(double)steps_in_a_row : 1.5;
+      alpha = alpha / div;
+      memcpy(h->X, X, xb); memcpy(h->Y, Y, yb);
+      steps_in_a_row = steps_in_a_row - 1 < 0 ? steps_in_a_row - 1 : 0;
+    }
+    if ((i > 10 && (steps_in_a_row > 3 && nrec >= 2 && objective[nrec - 2] - obj < tol)) || alpha <= prm->min_stepsize) break; /* :119 */
+  }
+  objective[nrec] = objective[nrec - 1];                        /* :126-127 */
+  seconds[nrec] = seconds[nrec - 1] + (now_s() - t);
+  ++nrec;
+  *n_recorded = nrec;
+  return GLRM_OK;
+}
