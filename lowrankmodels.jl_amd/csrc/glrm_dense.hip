@@ -24,7 +24,7 @@ static void pick_sup(int64_t n_other, int& nsup, int64_t& vps) {
 
 static int pack_view(glrm_handle* h, const double* dsrc, int64_t ldsrc, int colmajor, int transpose, int64_t seg0,
                      int64_t nseg, int64_t nother, double** dst, int64_t* lda) {
-  const int64_t nseg_pad = round_up(nseg > 0 ? nseg : 1, 64);
+  const int64_t nseg_pad = round_up(nseg > 0 ? nseg : 1, 256); // whole 16-wave workgroups stay in bounds
   *lda = round_up(nother, 64);
   HIPCK(hipMalloc((void**)dst, (size_t)nseg_pad * (size_t)*lda * 8));
   const dim3 grid((unsigned)(*lda / 32), (unsigned)(nseg_pad / 32));
@@ -95,11 +95,20 @@ int glrm_setup_dense(glrm_handle* h, const glrm_problem* p) {
   return GLRM_OK;
 }
 
+template <int KP, int NWD>
+static void launch_dense_inst(bool grad, const DenseArgs& a, hipStream_t st) {
+  const dim3 grid((unsigned)((a.nseg + NWD * 16 - 1) / (NWD * 16)), (unsigned)a.nsup);
+  if (grad) hipLaunchKernelGGL((dense_pass_kernel<KP, true, NWD>), grid, dim3(NWD * 64), 0, st, a);
+  else hipLaunchKernelGGL((dense_pass_kernel<KP, false, NWD>), grid, dim3(NWD * 64), 0, st, a);
+}
+
 template <int KP>
 static void launch_dense_pass(bool grad, const DenseArgs& a, hipStream_t st) {
-  const dim3 grid((unsigned)((a.nseg + 63) / 64), (unsigned)a.nsup);
-  if (grad) hipLaunchKernelGGL((dense_pass_kernel<KP, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((dense_pass_kernel<KP, false>), grid, dim3(256), 0, st, a);
+  // 16-wave workgroups (256 segments share one staged tile) unless the problem is too small to fill the chip with them
+  int nw = a.nseg * (int64_t)a.nsup >= 256 * 256 ? 16 : 4;
+  nw = env_int("GLRM_HIP_DENSE_NW", nw) == 16 ? 16 : 4; // tuning override
+  if (nw == 16) launch_dense_inst<KP, 16>(grad, a, st);
+  else launch_dense_inst<KP, 4>(grad, a, st);
 }
 
 static void launch_dense_any(int kp, bool grad, const DenseArgs& a, hipStream_t st) {

@@ -48,13 +48,16 @@ constexpr int DENSE_TN = 64; // opposing vectors staged per barrier
 template <int KP>
 constexpr int dense_row_bytes() { return KP * 8 + 16; }
 
-template <int KP, bool GRAD>
-__global__ void __launch_bounds__(256) dense_pass_kernel(const DenseArgs a) {
+// NWD waves per workgroup (4 or 16; all share the staged tile: larger workgroups re-stage the opposing factor less
+// often).  The lane's A entries are loaded per 16-vector tile right before use; requesting the whole staged tile's
+// entries ahead of the barrier measured 4-7 % slower (profiles/r01_dense_c3_pmc_summary.md).
+template <int KP, bool GRAD, int NWD>
+__global__ void __launch_bounds__(NWD * 64) dense_pass_kernel(const DenseArgs a) {
   constexpr int ROWB = dense_row_bytes<KP>(), PSTRIDE = KP + 2, NQ = KP / 4, NCB = KP / 16;
   __shared__ __attribute__((aligned(16))) char lds[DENSE_TN * ROWB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = lane & 15, cq = lane >> 4;
-  const int64_t seg0 = (int64_t)blockIdx.x * 64 + wave * 16;
+  const int64_t seg0 = (int64_t)blockIdx.x * (NWD * 16) + wave * 16;
   const int sup = blockIdx.y;
   const int64_t seg = seg0 + e;
   const bool have = seg < a.nseg;
@@ -84,7 +87,7 @@ __global__ void __launch_bounds__(256) dense_pass_kernel(const DenseArgs a) {
     { // stage DENSE_TN opposing vectors (zero beyond n_other), padded rows
       const char* src = reinterpret_cast<const char*>(a.other) + t0 * (KP * 8);
       const int64_t valid = (a.n_other - t0) * (KP * 8);
-      for (int off = threadIdx.x * 16; off < DENSE_TN * KP * 8; off += 256 * 16) {
+      for (int off = threadIdx.x * 16; off < DENSE_TN * KP * 8; off += NWD * 64 * 16) {
         double2 v = make_double2(0.0, 0.0);
         if (off < valid) v = *reinterpret_cast<const double2*>(src + off);
         const int row = off / (KP * 8), col = off - row * (KP * 8);
@@ -93,7 +96,7 @@ __global__ void __launch_bounds__(256) dense_pass_kernel(const DenseArgs a) {
     }
     __syncthreads();
     if (!wave_active) continue;
-#pragma unroll 1
+#pragma unroll
     for (int ct = 0; ct < DENSE_TN / 16; ++ct) {
       // the lane's four A entries: A[seg][t0 + ct*16 + 4*cq + (0..3)]
       const double2* ap = reinterpret_cast<const double2*>(arow + t0 + ct * 16 + 4 * cq);
@@ -168,7 +171,7 @@ __global__ void __launch_bounds__(256) dense_pack_kernel(const double* src, int6
   __syncthreads();
   for (int yy = ty; yy < 32; yy += 8) {
     const int64_t s = s0 + yy, c = c0 + tx;
-    if (c < lda) dst[s * lda + c] = tile[yy][tx]; // dst rows are allocated up to a multiple of 64 >= nseg
+    if (c < lda) dst[s * lda + c] = tile[yy][tx]; // dst rows are allocated up to a multiple of 256 >= nseg
   }
 }
 
