@@ -10,8 +10,10 @@
  * no `julia` binary exists in the build container or on the GPU box, so the reference
  * itself can be neither run nor compiled here.  The oracle is pinned against every
  * closed-form known answer the reference's tests/notebook hold for this path
- * (tests/test_oracle_kat.py), but the reference has no golden *trajectory* that is
- * reproducible without Julia's RNG.
+ * (tests/test_oracle_kat.py) and cross-checked against an independent dense numpy
+ * transcription of proxgrad.jl (tests/test_oracle_vs_numpy.py), but the reference has
+ * no golden *trajectory* that is reproducible without Julia's RNG (SURVEY.md section
+ * 8(c)): for trajectories this oracle is "parity unpinned".
  *
  * Every function cites the reference file:line (relative to the LowRankModels.jl
  * tree) it follows.  Arithmetic is Float64 throughout, indices 0-based here
