@@ -17,9 +17,11 @@
  *   objective/seconds arrays <- ConvergenceHistory  src/convergence.jl:3-27
  *
  * Conventions
- *   - X is k x m, Y is k x n, both COLUMN-major with leading dimension k, i.e.
- *     X[:,e] and Y[:,f] are k contiguous doubles (same as the Julia arrays,
- *     src/algorithms/proxgrad.jl:90-91).
+ *   - X is k x m, Y is k x d, both COLUMN-major with leading dimension k, i.e.
+ *     X[:,e] and Y[:,c] are k contiguous doubles (same as the Julia arrays,
+ *     src/algorithms/proxgrad.jl:90-91).  d = sum of the losses' embedding dimensions
+ *     (= n when every loss is scalar); column f owns Y columns [ys_f, ys_f + dim_f)
+ *     in column order (get_yidxs, src/losses.jl:76-93).
  *   - All indices are 0-based across this ABI (the Julia shim shifts by one).
  *   - Omega is handed over twice and the two views are NEVER derived from each
  *     other: CSR-by-row = observed_features, CSC-by-column = observed_examples,
@@ -62,7 +64,13 @@ typedef enum glrm_loss_kind {
   GLRM_LOSS_ORDINAL_HINGE = 6,  /* OrdinalHingeLoss  :247-294  scale, p0=min, p1=max */
   GLRM_LOSS_LOGISTIC = 7,       /* LogisticLoss      :298-311  scale; a in {1.0 (true), 0.0 (false)} */
   GLRM_LOSS_WEIGHTED_HINGE = 8, /* WeightedHingeLoss :317-352  scale, p0=case_weight_ratio; a in {1.0,0.0} */
-  GLRM_LOSS_KIND_COUNT = 9
+  /* multi-dimensional losses: the column owns `dim` consecutive columns of Y (embedding_dim, :72-93); a is the level 1..max */
+  GLRM_LOSS_MULTINOMIAL = 9,          /* MultinomialLoss(max)        :360-409  dim = max                              */
+  GLRM_LOSS_OVA = 10,                 /* OvALoss(max; bin_loss)      :413-446  dim = max,   p0 = bin_loss.scale, p1 = bin kind (7|8) */
+  GLRM_LOSS_BVS = 11,                 /* BvSLoss(max; bin_loss)      :450-483  dim = max-1, p0 = bin_loss.scale, p1 = bin kind (7|8) */
+  GLRM_LOSS_ORDISTIC = 12,            /* OrdisticLoss(max)           :490-530  dim = max                              */
+  GLRM_LOSS_MULTINOMIAL_ORDINAL = 13, /* MultinomialOrdinalLoss(max) :562-620  dim = max-1                            */
+  GLRM_LOSS_KIND_COUNT = 14
 } glrm_loss_kind;
 
 /* Regularizers named by the north star, src/regularizers.jl. */
@@ -75,17 +83,25 @@ typedef enum glrm_reg_kind {
   GLRM_REG_KIND_COUNT = 5
 } glrm_reg_kind;
 
+#define GLRM_MAX_EMBEDDING_DIM 32
+
 typedef struct glrm_loss {
   int32_t kind;     /* glrm_loss_kind */
-  int32_t reserved; /* must be 0 */
+  int32_t dim;      /* embedding dimension: 0 or 1 for the scalar losses, 2..GLRM_MAX_EMBEDDING_DIM for kinds >= 9 */
   double scale;
   double p0;
   double p1;
 } glrm_loss; /* 32 bytes */
 
+/* wrappers around the base regularizer (bit set in glrm_reg.wrap) */
+#define GLRM_WRAP_LASTENTRY1 1            /* lastentry1(r)            :163-175: last entry pinned to 1 (offset, on X)      */
+#define GLRM_WRAP_LASTENTRY_UNPENALIZED 2 /* lastentry_unpenalized(r) :177-189: last row exempt from r (offset, on Y)      */
+#define GLRM_WRAP_ORDINAL 4               /* OrdinalReg(r)            :356-383: block regularizer of ordinal multi-dim losses */
+#define GLRM_WRAP_MNL_ORDINAL 8           /* MNLOrdinalReg(r)         :388-409                                               */
+
 typedef struct glrm_reg {
-  int32_t kind;     /* glrm_reg_kind */
-  int32_t reserved; /* must be 0 */
+  int32_t kind;     /* glrm_reg_kind of the base regularizer */
+  int32_t wrap;     /* 0 or one GLRM_WRAP_* flag */
   double scale;
 } glrm_reg; /* 16 bytes */
 

@@ -8,11 +8,13 @@ from . import _capi
 from ._capi import GLRMError
 from .convergence import ConvergenceHistory, update_ch
 from .fit import ShardedFit, fit, fit_b, objective, partition
-from .glrm import GLRM, copy_estimate, parameter_estimate, scale_regularizer_, sort_observations
-from .losses import (HingeLoss, HuberLoss, L1Loss, LogisticLoss, Loss, OrdinalHingeLoss, PeriodicLoss,
-                     PoissonLoss, QuadLoss, QuantileLoss, WeightedHingeLoss, embedding_dim, evaluate, grad)
+from .glrm import GLRM, add_offset_, copy_estimate, parameter_estimate, scale_regularizer_, sort_observations
+from .losses import (BvSLoss, HingeLoss, HuberLoss, L1Loss, LogisticLoss, Loss, MultinomialLoss, MultinomialOrdinalLoss,
+                     OrdinalHingeLoss, OrdisticLoss, OvALoss, PeriodicLoss, PoissonLoss, QuadLoss, QuantileLoss,
+                     WeightedHingeLoss, embedding_dim, evaluate, get_yidxs, grad)
 from .params import AbstractParams, HipProxGradParams, Params, ProxGradParams, SparseProxGradParams
-from .regularizers import (NonNegConstraint, OneReg, QuadReg, Regularizer, UnitOneSparseConstraint, ZeroReg, prox)
+from .regularizers import (MNLOrdinalReg, NonNegConstraint, OneReg, OrdinalReg, QuadReg, Regularizer, UnitOneSparseConstraint,
+                           ZeroReg, lastentry1, lastentry_unpenalized, prox)
 
 fit_inplace = fit_b  # Julia's `fit!`
 

@@ -28,15 +28,15 @@ class GLRMError(RuntimeError):
 
 
 class CLoss(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("scale", C.c_double), ("p0", C.c_double), ("p1", C.c_double)]
+    _fields_ = [("kind", C.c_int32), ("dim", C.c_int32), ("scale", C.c_double), ("p0", C.c_double), ("p1", C.c_double)]
 
 
 class CReg(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("scale", C.c_double)]
+    _fields_ = [("kind", C.c_int32), ("wrap", C.c_int32), ("scale", C.c_double)]
 
 
-LOSS_DTYPE = np.dtype([("kind", "<i4"), ("reserved", "<i4"), ("scale", "<f8"), ("p0", "<f8"), ("p1", "<f8")])
-REG_DTYPE = np.dtype([("kind", "<i4"), ("reserved", "<i4"), ("scale", "<f8")])
+LOSS_DTYPE = np.dtype([("kind", "<i4"), ("dim", "<i4"), ("scale", "<f8"), ("p0", "<f8"), ("p1", "<f8")])
+REG_DTYPE = np.dtype([("kind", "<i4"), ("wrap", "<i4"), ("scale", "<f8")])
 assert LOSS_DTYPE.itemsize == C.sizeof(CLoss) == 32 and REG_DTYPE.itemsize == C.sizeof(CReg) == 16
 
 
@@ -79,7 +79,7 @@ class CKernelStats(C.Structure):
     ]
 
     def asdict(self):
-        return {f: getattr(self, f) for f, _ in self._fields_ if f != "reserved"}
+        return {f: getattr(self, f) for f, _ in self._fields_}
 
 
 #: every symbol include/glrm_hip.h declares (suffix after the prefix); the CPU test-suite checks
@@ -278,6 +278,19 @@ class ProblemArrays:
         self.losses, self.rx, self.ry = losses, rx, ry  # numpy structured arrays (LOSS_DTYPE / REG_DTYPE)
         # fully observed QuadLoss hand-over: the whole m x n matrix (numpy array or device address) instead of lists
         self.dense_A, self.dense_ld, self.dense_colmajor = dense_A, int(dense_ld), int(dense_colmajor)
+
+    @property
+    def ystart(self):
+        """Column f owns vectors [ystart[f], ystart[f+1]) of Y (get_yidxs, src/losses.jl:76-93)."""
+        dims = np.maximum(np.asarray(self.losses["dim"], dtype=np.int64), 1)
+        if len(dims) == 1:
+            return np.arange(self.n + 1, dtype=np.int64) * int(dims[0])
+        return np.concatenate([[0], np.cumsum(dims)]).astype(np.int64)
+
+    @property
+    def d(self):
+        """Vectors of Y = sum of the embedding dimensions (= n for scalar losses)."""
+        return int(self.ystart[-1])
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))

@@ -1,5 +1,6 @@
-// glrm_engine.hpp -- host-side declarations shared by the two translation units of libglrm_hip.so
-// (glrm_hip.hip: C ABI + gather sweeps; glrm_tiled.hip: LDS-tiled sweeps).
+// glrm_engine.hpp -- host-side declarations shared by the translation units of libglrm_hip.so
+// (glrm_hip.hip: C ABI + gather sweeps; glrm_tiled.hip: LDS-tiled sweeps; glrm_dense.hip: MFMA path;
+// glrm_multi.hip: multi-dimensional losses / block regularizers).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -51,6 +52,11 @@ struct glrm_handle {
   int32_t *activebuf = nullptr, *ntrialbuf = nullptr;
   unsigned int* nactive = nullptr;
   int* dflag = nullptr;
+  // general sweeps: multi-dimensional losses / wrapped regularizers (glrm_multi.hip)
+  bool multi = false;
+  int64_t d = 0;                      // vectors of Y = sum of embedding dimensions (= n for scalar losses)
+  int dmax = 1;
+  int64_t* ystart = nullptr;          // device, n+1
   // dense MFMA path (glrm_dense.hip)
   bool dense = false;
   double *Arow = nullptr, *Acol = nullptr; // packed, zero padded: [ml_pad][lda_r], [nl_pad][lda_c]
@@ -97,6 +103,11 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
 // dense MFMA path (glrm_dense.hip)
 int glrm_setup_dense(glrm_handle* h, const glrm_problem* p);
 int glrm_run_dense(glrm_handle* h, bool rows, double min_stepsize, int eval_only);
+
+// general sweeps (glrm_multi.hip)
+int glrm_setup_multi(glrm_handle* h, const glrm_problem* p);
+int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only);
+int glrm_run_multi_penalty(glrm_handle* h, bool rows);
 
 // per-segment reduce (which = 0) / decide (which = 1) kernels of glrm_tiled.hpp for a kp-wide factor
 namespace glrm { struct TiledArgs; }

@@ -444,9 +444,19 @@ static int check_view(const char* name, int64_t nseg, const int64_t* ptr, const 
       if (is_classification(l.kind) && !(vals[t] == 1.0 || vals[t] == 0.0))
         return fail(GLRM_ERR_NONFINITE, "entry in column %lld has label %g; a ClassificationLoss needs true(1)/false(0)",
                     (long long)f, vals[t]);
+      if (l.kind >= GLRM_LOSS_MULTINOMIAL) { // levels 1..max index into u (BoundsError / InexactError in the reference)
+        const int mx = (l.kind == GLRM_LOSS_BVS || l.kind == GLRM_LOSS_MULTINOMIAL_ORDINAL) ? l.dim + 1 : l.dim;
+        if (!(vals[t] >= 1.0 && vals[t] <= (double)mx && vals[t] == std::floor(vals[t])))
+          return fail(GLRM_ERR_NONFINITE, "entry (%lld, %lld) = %g is not a level in 1..%d of its categorical / ordinal loss",
+                      (long long)e, (long long)f, vals[t], mx);
+      }
     }
   }
   return GLRM_OK;
+}
+
+static bool wrap_ok(int w) {
+  return w == 0 || w == GLRM_WRAP_LASTENTRY1 || w == GLRM_WRAP_LASTENTRY_UNPENALIZED || w == GLRM_WRAP_ORDINAL || w == GLRM_WRAP_MNL_ORDINAL;
 }
 
 static int check_desc(const glrm_problem* p) {
@@ -460,16 +470,21 @@ static int check_desc(const glrm_problem* p) {
     return fail(GLRM_ERR_INVALID, "There must be either one Y regularizer or as many Y regularizers as there are columns in the data matrix");
   for (int64_t i = 0; i < p->n_losses; ++i) {
     if (p->losses[i].kind < 0 || p->losses[i].kind >= GLRM_LOSS_KIND_COUNT)
-      return fail(GLRM_ERR_UNSUPPORTED, "loss kind %d (column %lld) is not a supported scalar loss", p->losses[i].kind, (long long)i);
-    if (p->losses[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_loss.reserved must be 0");
+      return fail(GLRM_ERR_UNSUPPORTED, "loss kind %d (column %lld) is not a supported loss", p->losses[i].kind, (long long)i);
+    if (p->losses[i].kind < GLRM_LOSS_MULTINOMIAL ? !(p->losses[i].dim == 0 || p->losses[i].dim == 1)
+                                                  : !(p->losses[i].dim >= 2 && p->losses[i].dim <= GLRM_MAX_EMBEDDING_DIM))
+      return fail(GLRM_ERR_INVALID, "glrm_loss.dim = %d is not a valid embedding dimension for loss kind %d", p->losses[i].dim, p->losses[i].kind);
+    if ((p->losses[i].kind == GLRM_LOSS_OVA || p->losses[i].kind == GLRM_LOSS_BVS) &&
+        !(p->losses[i].p1 == GLRM_LOSS_LOGISTIC || p->losses[i].p1 == GLRM_LOSS_WEIGHTED_HINGE))
+      return fail(GLRM_ERR_UNSUPPORTED, "bin_loss of OvALoss / BvSLoss must be LogisticLoss or HingeLoss");
   }
   for (int64_t i = 0; i < p->n_rx; ++i) {
     if (p->rx[i].kind < 0 || p->rx[i].kind >= GLRM_REG_KIND_COUNT) return fail(GLRM_ERR_UNSUPPORTED, "rx regularizer kind %d is not supported", p->rx[i].kind);
-    if (p->rx[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_reg.reserved must be 0");
+    if (!wrap_ok(p->rx[i].wrap)) return fail(GLRM_ERR_INVALID, "glrm_reg.wrap must be 0 or one GLRM_WRAP_* flag");
   }
   for (int64_t i = 0; i < p->n_ry; ++i) {
     if (p->ry[i].kind < 0 || p->ry[i].kind >= GLRM_REG_KIND_COUNT) return fail(GLRM_ERR_UNSUPPORTED, "ry regularizer kind %d is not supported", p->ry[i].kind);
-    if (p->ry[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_reg.reserved must be 0");
+    if (!wrap_ok(p->ry[i].wrap)) return fail(GLRM_ERR_INVALID, "glrm_reg.wrap must be 0 or one GLRM_WRAP_* flag");
   }
   return GLRM_OK;
 }
@@ -482,7 +497,7 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
                   h->alpharow, h->alphacol, h->oX, h->oY, h->oobjcol, h->oobjrow, h->partials, h->dscalar, h->dcount,
                   h->trials_r, h->accepts_r, h->trials_c, h->accepts_c, h->part, h->gsum, h->trialbuf, h->joldbuf,
                   h->activebuf, h->ntrialbuf, h->nactive, h->dflag, h->Arow, h->Acol, h->part_r, h->gsum_r, h->trial_r,
-                  h->jold_r, h->active_r, h->ntrial_r};
+                  h->jold_r, h->active_r, h->ntrial_r, h->ystart};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   for (auto& e : h->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -547,7 +562,9 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   HIPCK(hipMemsetAsync(h->accepts_c, 0, nl1 * 4, st));
   h->waves_row = pick_waves(o ? o->waves_row : 0, h->nnz_r, h->ml);
   h->waves_col = pick_waves(o ? o->waves_col : 0, h->nnz_c, h->nl);
-  int rc2 = p->dense_A ? glrm_setup_dense(h, p) : glrm_setup_tiled(h);
+  int rc2 = glrm_setup_multi(h, p);
+  if (rc2) return rc2;
+  if (!h->multi) rc2 = p->dense_A ? glrm_setup_dense(h, p) : glrm_setup_tiled(h);
   if (rc2) return rc2;
   HIPCK(hipStreamSynchronize(st)); // host descriptor / index arrays may be released by the caller now
   return GLRM_OK;
@@ -606,7 +623,7 @@ static int ensure_owned(glrm_handle* h) {
     h->X = h->oX;
   }
   if (!h->Y) {
-    if (!h->oY) { HIPCK(hipMalloc((void**)&h->oY, (size_t)h->kp * h->n * 8)); HIPCK(hipMemsetAsync(h->oY, 0, (size_t)h->kp * h->n * 8, h->stream)); }
+    if (!h->oY) { HIPCK(hipMalloc((void**)&h->oY, (size_t)h->kp * h->d * 8)); HIPCK(hipMemsetAsync(h->oY, 0, (size_t)h->kp * h->d * 8, h->stream)); }
     h->Y = h->oY;
   }
   if (!h->objcol) {
@@ -637,10 +654,10 @@ extern "C" int glrm_hip_set_factors(glrm_handle* h, const double* X, const doubl
   const size_t kb = (size_t)h->k * 8, pb = (size_t)h->kp * 8;
   if (h->kp != h->k) {
     HIPCK(hipMemsetAsync(h->X, 0, pb * h->m, h->stream));
-    HIPCK(hipMemsetAsync(h->Y, 0, pb * h->n, h->stream));
+    HIPCK(hipMemsetAsync(h->Y, 0, pb * h->d, h->stream));
   }
   HIPCK(hipMemcpy2DAsync(h->X, pb, X, kb, kb, (size_t)h->m, hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipMemcpy2DAsync(h->Y, pb, Y, kb, kb, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMemcpy2DAsync(h->Y, pb, Y, kb, kb, (size_t)h->d, hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
   return GLRM_OK;
 }
@@ -651,7 +668,7 @@ extern "C" int glrm_hip_get_factors(glrm_handle* h, double* X, double* Y) {
   DeviceGuard dg(h->device);
   const size_t kb = (size_t)h->k * 8, pb = (size_t)h->kp * 8;
   HIPCK(hipMemcpy2DAsync(X, kb, h->X, pb, kb, (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
-  HIPCK(hipMemcpy2DAsync(Y, kb, h->Y, pb, kb, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipMemcpy2DAsync(Y, kb, h->Y, pb, kb, (size_t)h->d, hipMemcpyDeviceToHost, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
   return GLRM_OK;
 }
@@ -670,9 +687,18 @@ extern "C" int glrm_hip_set_regularizers(glrm_handle* h, const glrm_reg* rx, int
   if (n_rx != h->n_rx || n_ry != h->n_ry)
     return fail(GLRM_ERR_INVALID, "regularizer counts must match the handle (rx %lld, ry %lld)", (long long)h->n_rx, (long long)h->n_ry);
   for (int64_t i = 0; i < n_rx; ++i)
-    if (rx[i].kind < 0 || rx[i].kind >= GLRM_REG_KIND_COUNT || rx[i].reserved != 0) return fail(GLRM_ERR_UNSUPPORTED, "rx regularizer kind %d is not supported", rx[i].kind);
+    if (rx[i].kind < 0 || rx[i].kind >= GLRM_REG_KIND_COUNT || !wrap_ok(rx[i].wrap)) return fail(GLRM_ERR_UNSUPPORTED, "rx regularizer kind %d is not supported", rx[i].kind);
   for (int64_t i = 0; i < n_ry; ++i)
-    if (ry[i].kind < 0 || ry[i].kind >= GLRM_REG_KIND_COUNT || ry[i].reserved != 0) return fail(GLRM_ERR_UNSUPPORTED, "ry regularizer kind %d is not supported", ry[i].kind);
+    if (ry[i].kind < 0 || ry[i].kind >= GLRM_REG_KIND_COUNT || !wrap_ok(ry[i].wrap)) return fail(GLRM_ERR_UNSUPPORTED, "ry regularizer kind %d is not supported", ry[i].kind);
+  if (!h->multi) { // a handle created on the scalar fast paths moves to the general sweeps when a wrapper appears
+    bool wrapped = false;
+    for (int64_t i = 0; i < n_rx; ++i) wrapped |= rx[i].wrap != 0;
+    for (int64_t i = 0; i < n_ry; ++i) wrapped |= ry[i].wrap != 0;
+    if (wrapped) {
+      if (h->dense || h->kp > 64) return fail(GLRM_ERR_UNSUPPORTED, "wrapped regularizers need a sparse-view handle with k <= 64");
+      h->multi = true;
+    }
+  }
   DeviceGuard dg(h->device);
   HIPCK(hipMemcpyAsync(h->rx, rx, (size_t)n_rx * sizeof(glrm_reg), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->ry, ry, (size_t)n_ry * sizeof(glrm_reg), hipMemcpyHostToDevice, h->stream));
@@ -792,7 +818,10 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
     HIPCK(hipEventRecord(ev.a, h->stream));
   }
   const bool tiled = rows ? (h->tiled_row && !eval_only) : h->tiled_col;
-  if (h->dense) {
+  if (h->multi) {
+    rc = glrm_run_multi(h, rows, min_stepsize, eval_only);
+    if (rc) return rc;
+  } else if (h->dense) {
     rc = glrm_run_dense(h, rows, min_stepsize, eval_only);
     if (rc) return rc;
   } else if (tiled) {
@@ -860,6 +889,7 @@ static int run_penalty(glrm_handle* h, bool rows) {
   if (rc) return rc;
   const int64_t nseg = rows ? h->ml : h->nl;
   if (nseg <= 0) return GLRM_OK;
+  if (h->multi) return glrm_run_multi_penalty(h, rows);
   hipLaunchKernelGGL(penalty_kernel, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, h->stream, rows ? h->X : h->Y, h->kp,
                      h->k, rows ? h->rb : h->cb, nseg, rows ? h->rx : h->ry, (rows ? h->n_rx : h->n_ry) == 1 ? 1 : 0,
                      rows ? h->objrow : h->objcol);
@@ -917,7 +947,7 @@ extern "C" int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int
   if ((rc = count_sum(h, h->accepts_c, h->nl, &out->accepts_y))) return rc;
   out->nnz_rows = h->nnz_r; out->nnz_cols = h->nnz_c;
   out->waves_row = h->waves_row; out->waves_col = h->waves_col; out->ld = h->kp;
-  out->tiled = (h->tiled_row ? 1 : 0) | (h->tiled_col ? 2 : 0) | (h->dense ? 4 : 0); // bit0: tiled row sweep, bit1: tiled column sweep
+  out->tiled = h->multi ? 8 : (h->tiled_row ? 1 : 0) | (h->tiled_col ? 2 : 0) | (h->dense ? 4 : 0); // bit0: tiled row sweep, bit1: tiled column sweep
   if (reset) {
     h->launches_x = h->launches_y = 0;
     h->ms_x = h->ms_y = 0;
@@ -970,7 +1000,7 @@ extern "C" int glrm_hip_fit(glrm_handle* h, const glrm_params* prm, double* X, d
   if (prm->max_iter < 0 || cap < prm->max_iter + 1) return fail(GLRM_ERR_INVALID, "objective/seconds capacity must be >= max_iter+1");
   if (prm->inner_iter_X < 1 || prm->inner_iter_Y < 1) return fail(GLRM_ERR_INVALID, "inner iteration counts must be >= 1");
   double ynorm = 0.0; // norm(Y)==0 guard, proxgrad.jl:45-48 (the reference would hit an UndefVarError)
-  for (int64_t i = 0; i < (int64_t)h->k * h->n; ++i) ynorm += Y[i] * Y[i];
+  for (int64_t i = 0; i < (int64_t)h->k * h->d; ++i) ynorm += Y[i] * Y[i];
   if (ynorm == 0.0) return fail(GLRM_ERR_INVALID, "Y is all zeros (the reference cannot start from Y == 0)");
   DeviceGuard dg(h->device);
   int rc;
@@ -1013,12 +1043,12 @@ extern "C" int glrm_hip_fit_sparse(glrm_handle* h, const glrm_sparse_params* prm
   if (prm->max_iter < 0 || cap < prm->max_iter + 2) return fail(GLRM_ERR_INVALID, "objective/seconds capacity must be >= max_iter+2");
   if (prm->inner_iter < 1) return fail(GLRM_ERR_INVALID, "inner_iter must be >= 1");
   double ynorm = 0.0; // norm(Y)==0 would be re-randomised by the reference (:41-43); not reproducible -> error
-  for (int64_t i = 0; i < (int64_t)h->k * h->n; ++i) ynorm += Y[i] * Y[i];
+  for (int64_t i = 0; i < (int64_t)h->k * h->d; ++i) ynorm += Y[i] * Y[i];
   if (ynorm == 0.0) return fail(GLRM_ERR_INVALID, "Y is all zeros");
   DeviceGuard dg(h->device);
   int rc;
   if ((rc = glrm_hip_set_factors(h, X, Y))) return rc; // working copies X, Y (:33); glrm.X / glrm.Y = best so far
-  const size_t xb = (size_t)h->kp * h->m * 8, yb = (size_t)h->kp * h->n * 8;
+  const size_t xb = (size_t)h->kp * h->m * 8, yb = (size_t)h->kp * h->d * 8;
   double *bestX = nullptr, *bestY = nullptr;
   HIPCK(hipMalloc((void**)&bestX, xb));
   if (hipMalloc((void**)&bestY, yb) != hipSuccess) { (void)hipFree(bestX); return fail(GLRM_ERR_OOM, "out of device memory"); }

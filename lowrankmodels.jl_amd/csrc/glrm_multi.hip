@@ -1,0 +1,94 @@
+// glrm_multi.hip -- host side of the general sweeps (glrm_multi.hpp): multi-dimensional losses, block
+// regularizers and offsets.  Part of libglrm_hip.so.
+#include "glrm_multi.hpp"
+
+#include "glrm_engine.hpp"
+
+using namespace glrm;
+
+// Column spans of Y (get_yidxs, src/losses.jl:76-93) and the routing decision.  Called for every handle: the spans
+// are also what a scalar problem uses (ystart[f] = f) if its regularizers are later replaced by wrapped ones.
+int glrm_setup_multi(glrm_handle* h, const glrm_problem* p) {
+  std::vector<int64_t> ys((size_t)p->n + 1);
+  ys[0] = 0;
+  h->dmax = 1;
+  bool multi = false;
+  for (int64_t f = 0; f < p->n; ++f) {
+    const glrm_loss& l = p->n_losses == 1 ? p->losses[0] : p->losses[f];
+    const int d = l.dim > 1 ? l.dim : 1;
+    if (d > 1) multi = true;
+    if (d > h->dmax) h->dmax = d;
+    ys[f + 1] = ys[f] + d;
+  }
+  h->d = ys[p->n];
+  for (int64_t i = 0; i < p->n_rx; ++i) if (p->rx[i].wrap) multi = true;
+  for (int64_t i = 0; i < p->n_ry; ++i) if (p->ry[i].wrap) multi = true;
+  h->multi = multi;
+  if (multi && h->kp > 64)
+    return fail(GLRM_ERR_UNSUPPORTED, "multi-dimensional losses / wrapped regularizers need k <= 64 (got %d)", h->k);
+  if (multi && p->dense_A)
+    return fail(GLRM_ERR_UNSUPPORTED, "the dense hand-over covers scalar QuadLoss with unwrapped regularizers only");
+  HIPCK(hipMalloc((void**)&h->ystart, ((size_t)p->n + 1) * 8));
+  HIPCK(hipMemcpyAsync(h->ystart, ys.data(), ((size_t)p->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream)); // ys is a local
+  return GLRM_OK;
+}
+
+int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only) {
+  MultiArgs a{};
+  a.nseg = rows ? h->ml : h->nl;
+  a.ptr = rows ? h->rowptr : h->colptr;
+  a.idx = rows ? h->colidx : h->rowidx;
+  a.vals = rows ? h->rowvals : h->colvals;
+  a.own = rows ? h->X : h->Y;
+  a.own_offset = rows ? h->rb : h->cb;
+  a.other = rows ? h->Y : h->X;
+  a.ystart = h->ystart;
+  a.losses = h->losses;
+  a.loss_single = h->n_losses == 1;
+  a.regs = rows ? h->rx : h->ry;
+  a.reg_single = (rows ? h->n_rx : h->n_ry) == 1;
+  a.alpha = rows ? h->alpharow : h->alphacol;
+  a.obj = rows ? nullptr : h->objcol;
+  a.k = h->k; a.kp = h->kp; a.dmax = h->dmax;
+  a.mode = eval_only ? 1 : (h->fixed_alpha > 0.0 ? 2 : 0);
+  a.fixed_alpha = h->fixed_alpha;
+  a.min_stepsize = min_stepsize;
+  a.trials = (eval_only || a.mode == 2) ? nullptr : (rows ? h->trials_r : h->trials_c);
+  a.accepts = (eval_only || a.mode == 2) ? nullptr : (rows ? h->accepts_r : h->accepts_c);
+  if (rows && h->rng_e >= 0) {
+    const int64_t s0 = h->rng_b;
+    a.nseg = h->rng_e - s0;
+    a.ptr += s0; a.alpha += s0; a.own_offset += s0;
+    if (!a.reg_single) a.regs += s0;
+    if (a.trials) a.trials += s0;
+    if (a.accepts) a.accepts += s0;
+  }
+  if (a.nseg <= 0) return GLRM_OK;
+  if (rows) {
+    const size_t lds = multi_lds_doubles(true, 1, h->kp, h->dmax) * 8;
+    hipLaunchKernelGGL((multi_sweep_kernel<true, 1>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+  } else {
+    const size_t lds = multi_lds_doubles(false, 8, h->kp, h->dmax) * 8;
+    hipLaunchKernelGGL((multi_sweep_kernel<false, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+  }
+  HIPCK(hipGetLastError());
+  return GLRM_OK;
+}
+
+int glrm_run_multi_penalty(glrm_handle* h, bool rows) {
+  PenaltyArgs a{};
+  a.nseg = rows ? h->ml : h->nl;
+  if (a.nseg <= 0) return GLRM_OK;
+  a.own = rows ? h->X : h->Y;
+  a.own_offset = rows ? h->rb : h->cb;
+  a.ystart = rows ? nullptr : h->ystart;
+  a.regs = rows ? h->rx : h->ry;
+  a.reg_single = (rows ? h->n_rx : h->n_ry) == 1;
+  a.k = h->k; a.kp = h->kp;
+  a.out = rows ? h->objrow : h->objcol;
+  const size_t lds = ((size_t)(rows ? 1 : h->dmax) * (h->kp + 1) + 16) * 8;
+  hipLaunchKernelGGL(multi_penalty_kernel, dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+  HIPCK(hipGetLastError());
+  return GLRM_OK;
+}

@@ -162,6 +162,9 @@ class ShardedFit:
             self.rank, self.world = 0, 1
         self.row_bounds, self.col_bounds = list(row_bounds), list(col_bounds)
         self.m, self.n, self.k = prob.m, prob.n, prob.k
+        ys = prob.ystart
+        self.d = int(ys[-1])                                       # vectors of Y (> n with multi-dimensional losses)
+        self.y_bounds = [int(ys[c]) for c in self.col_bounds]      # the rank's block of Y in vector units
         self.device = device if device is not None else torch.device("cpu")
         o = dict(opts or {})
         if self.device.type == "cuda":
@@ -169,7 +172,7 @@ class ShardedFit:
         self.h = api.create(prob, stream=stream, **o)
         self.ld = api.factor_ld(self.h)
         z = lambda cnt: torch.zeros(cnt, dtype=torch.float64, device=self.device)
-        self.dX, self.dY, self.dObjCol, self.dObjRow = z(self.m * self.ld), z(self.n * self.ld), z(self.n), z(self.m)
+        self.dX, self.dY, self.dObjCol, self.dObjRow = z(self.m * self.ld), z(self.d * self.ld), z(self.n), z(self.m)
         api.bind_buffers(self.h, self.dX.data_ptr(), self.dY.data_ptr(), self.dObjCol.data_ptr(), self.dObjRow.data_ptr())
         # Pipelined X exchange: the X half-step runs in `x_chunks` row chunks; the all-gather of a finished chunk
         # proceeds on a side stream while the next chunk is swept (rows are independent).  Needs equal row blocks.
@@ -257,7 +260,7 @@ class ShardedFit:
             self._gather(self.dX, self.row_bounds, self.ld)  # inner X sweeps only touch own rows: gather once
         for _ in range(params.inner_iter_Y):
             api.step_y(h, params.min_stepsize)
-        self._gather(self.dY, self.col_bounds, self.ld)
+        self._gather(self.dY, self.y_bounds, self.ld)
         self._gather(self.dObjCol, self.col_bounds, 1)
         return api.sum(h, self.dObjCol.data_ptr(), self.n)
 

@@ -14,8 +14,8 @@ import copy as _copy
 import numpy as np
 
 from ._capi import ProblemArrays
-from .losses import Loss, pack_losses
-from .regularizers import Regularizer, pack_regs
+from .losses import Loss, embedding_dim, get_yidxs, pack_losses
+from .regularizers import OrdinalReg, Regularizer, lastentry1, lastentry_unpenalized, pack_regs
 
 try:  # scipy is optional: only needed for SparseMatrixCSC-like inputs
     import scipy.sparse as _sp
@@ -92,23 +92,24 @@ class GLRM:
         rng = np.random.default_rng() if rng is None else rng
         if X is None:
             X = rng.standard_normal((k, m))  # randn(k, size(A,1)), src/glrm.jl:31
+        d = embedding_dim(losses)  # Y has one column per embedding dimension (src/glrm.jl:31, src/losses.jl:72-93)
         if Y is None:
-            Y = rng.standard_normal((k, n))
+            Y = rng.standard_normal((k, d))
         X = np.asarray(X, dtype=np.float64)
         if X.shape != (k, m) and X.shape == (m, k):
             X = X.T  # "transposing X", src/glrm.jl:57-60
         if X.shape != (k, m):
             raise ValueError(f"X must be of size (k,m) where m is the number of rows in the data matrix. size(X) = {X.shape}, size(A) = {(m, n)}, k = {k}")
         Y = np.asarray(Y, dtype=np.float64)
-        if Y.shape != (k, n):
+        if Y.shape != (k, d):
             raise ValueError("Y must be of size (k,d) where d is the sum of the embedding dimensions of all the losses.")
-        if offset or scale:
-            raise NotImplementedError("offset/scale wrap regularizers outside the accelerated path (src/modify_glrm.jl:21-82)")
+        if scale:
+            raise NotImplementedError("scale=true needs the M-estimators (src/modify_glrm.jl:34-58), outside the accelerated path")
 
         self.A, self.losses, self.rx, self.ry, self.k = A, losses, rx, ry, k
         self.X = np.array(X, dtype=np.float64, order="F")
         self.Y = np.array(Y, dtype=np.float64, order="F")
-        self.m, self.n = m, n
+        self.m, self.n, self.d = m, n, d
 
         self._fully_observed = obs is None and observed_features is None and observed_examples is None and \
             not (sparse_na and _issparse(A))
@@ -140,6 +141,8 @@ class GLRM:
         self._rowvals = self._gather(np.repeat(np.arange(m, dtype=np.int64), np.diff(rowptr)), colidx.astype(np.int64), checknan)
         self._colvals = self._gather(rowidx.astype(np.int64), np.repeat(np.arange(n, dtype=np.int64), np.diff(colptr)), False)
         self._handle_cache = None
+        if offset:  # add_offset!(glrm), src/glrm.jl:76-78, src/modify_glrm.jl:21-24
+            add_offset_(self)
 
     # -- values --------------------------------------------------------------------------
     def _gather(self, I, J, checknan):
@@ -184,7 +187,8 @@ class GLRM:
         """Fully observed, one QuadLoss for every column, rank 9..64, plain numeric matrix: the half-steps can run
         as fused GEMMs on the matrix cores (the `dense_A` hand-over of include/glrm_hip.h)."""
         return (self._fully_observed and not _issparse(self.A) and self.A.dtype != object and 8 < self.k <= 64
-                and len(pack_losses(self.losses)) == 1 and self.losses[0].kind == 0)
+                and len(pack_losses(self.losses)) == 1 and self.losses[0].kind == 0
+                and all(r.wrap == 0 for r in list(self.rx) + list(self.ry)))
 
     def problem_arrays(self, rows=None, cols=None, dense=False) -> ProblemArrays:
         rb, re = (0, self.m) if rows is None else rows
@@ -232,6 +236,14 @@ class GLRM:
             self.close()
         except Exception:
             pass
+
+
+def add_offset_(glrm):
+    """add_offset!(glrm) (src/modify_glrm.jl:21-24): the last latent feature of every row is pinned to 1 and the last row
+    of Y is not penalised -- an unpenalised per-column offset.  OrdinalReg / MNLOrdinalReg already exempt their last row."""
+    glrm.rx = [lastentry1(r) for r in glrm.rx]
+    glrm.ry = [lastentry_unpenalized(r) for r in glrm.ry]
+    return glrm
 
 
 def parameter_estimate(glrm):  # src/glrm.jl:82

@@ -29,8 +29,10 @@ class Regularizer:
         r.mul_(self.scale * newscale)
         return r
 
+    wrap = 0
+
     def descriptor(self):
-        return (self.kind, 0, self.scale)
+        return (self.kind, self.wrap, self.scale)
 
     def __repr__(self):
         return f"{type(self).__name__}({self.scale})"
@@ -119,6 +121,93 @@ class UnitOneSparseConstraint(_Unscaled):  # :295-318
         v = np.zeros_like(u)
         v[int(np.argmax(u))] = 1
         return v
+
+
+# ------------------------------------------------------------------------- wrappers / block regularizers
+WRAP_LASTENTRY1, WRAP_LASTENTRY_UNPENALIZED, WRAP_ORDINAL, WRAP_MNL_ORDINAL = 1, 2, 4, 8
+
+
+class _Wrapper(Regularizer):
+    """A regularizer around a base regularizer r (one of the five above).  Arrays are k-vectors or k x d blocks
+    (first axis = latent component), like the views the reference passes."""
+    wrap = 0
+
+    def __init__(self, r=None):
+        r = ZeroReg() if r is None else r
+        if isinstance(r, _Wrapper) or r.kind < 0:
+            raise NotImplementedError("nested wrappers are outside the accelerated path")
+        self.r = r
+
+    kind = property(lambda self: self.r.kind)
+    scale = property(lambda self: self.r.scale)
+
+    def mul_(self, newscale):
+        self.r.mul_(newscale)
+        return self
+
+    def descriptor(self):
+        return (self.r.kind, self.wrap, self.r.descriptor()[2])
+
+    def __repr__(self):
+        return f"{type(self).__name__}({self.r!r})"
+
+
+class lastentry1(_Wrapper):  # src/regularizers.jl:163-175
+    wrap = WRAP_LASTENTRY1
+
+    def evaluate(self, a):
+        a = np.asarray(a, dtype=float)
+        return self.r.evaluate(a[:-1]) if np.all(a[-1] == 1) else float("inf")
+
+    def prox(self, u, alpha=1):
+        u = np.array(u, dtype=float)
+        u[:-1] = self.r.prox(u[:-1], alpha)
+        u[-1] = 1
+        return u
+
+
+class lastentry_unpenalized(_Wrapper):  # src/regularizers.jl:177-189
+    wrap = WRAP_LASTENTRY_UNPENALIZED
+
+    def __new__(cls, r=None):
+        if isinstance(r, (OrdinalReg, MNLOrdinalReg)):  # "make sure we don't add two offsets", :386,:411
+            return r
+        return super().__new__(cls)
+
+    def evaluate(self, a):
+        return self.r.evaluate(np.asarray(a, dtype=float)[:-1])
+
+    def prox(self, u, alpha=1):
+        u = np.array(u, dtype=float)
+        u[:-1] = self.r.prox(u[:-1], alpha)
+        return u
+
+
+class OrdinalReg(_Wrapper):  # src/regularizers.jl:356-386
+    wrap = WRAP_ORDINAL
+
+    def evaluate(self, a):
+        a = np.asarray(a, dtype=float).reshape(len(a), -1)
+        return self.r.evaluate(a[:-1, 0])
+
+    def prox(self, u, alpha):
+        u = np.array(u, dtype=float)
+        u2 = u.reshape(len(u), -1)
+        um = np.asarray(self.r.prox(np.mean(u2[:-1, :], axis=1), alpha), dtype=float)
+        u2[:-1, :] = um[:, None]
+        return u
+
+
+class MNLOrdinalReg(OrdinalReg):  # src/regularizers.jl:388-411
+    wrap = WRAP_MNL_ORDINAL
+
+    def prox(self, u, alpha, TOL=1e-3):
+        u = OrdinalReg.prox(self, u, alpha)
+        u2 = u.reshape(len(u), -1)
+        u2[-1, 0] = min(-TOL, u2[-1, 0])
+        for j in range(1, u2.shape[1]):
+            u2[-1, j] = min(u2[-1, j], u2[-1, j - 1] - TOL)
+        return u
 
 
 def prox(r, u, alpha):

@@ -300,6 +300,9 @@ typedef struct glrm_cpu_handle {
   double *X, *Y, *objcol, *objrow;
   double *ownX, *ownY, *ownobjcol, *ownobjrow;
   double *alpharow, *alphacol;
+  int multi;          /* 1 = some loss is multi-dimensional or some regularizer is wrapped: general code path */
+  int64_t d;          /* columns of Y = sum of embedding dimensions (= n for scalar losses) */
+  int64_t* ystart;    /* n+1: column f owns Y[:, ystart[f] .. ystart[f+1]) (get_yidxs, src/losses.jl:76-93) */
   int dense_faithful; /* 1 = reproduce the reference's Theta(mnk) cost model */
   double* XY;         /* m x n, only in dense_faithful mode */
   glrm_kernel_stats st;
@@ -326,7 +329,7 @@ void glrm_cpu_destroy(glrm_cpu_handle* h) {
   free(h->rowptr); free(h->colptr); free(h->colidx); free(h->rowidx);
   free(h->rowvals); free(h->colvals); free(h->losses); free(h->rx); free(h->ry);
   free(h->ownX); free(h->ownY); free(h->ownobjcol); free(h->ownobjrow);
-  free(h->alpharow); free(h->alphacol); free(h->XY);
+  free(h->alpharow); free(h->alphacol); free(h->XY); free(h->ystart);
   free(h);
 }
 
@@ -342,17 +345,24 @@ static int check_desc(const glrm_problem* p) {
   for (int64_t i = 0; i < p->n_losses; ++i) {
     if (p->losses[i].kind < 0 || p->losses[i].kind >= GLRM_LOSS_KIND_COUNT)
       return fail(GLRM_ERR_UNSUPPORTED, "loss kind %d (column %lld) is not a supported scalar loss", p->losses[i].kind, (long long)i);
-    if (p->losses[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_loss.reserved must be 0");
+    if (p->losses[i].kind < GLRM_LOSS_MULTINOMIAL ? !(p->losses[i].dim == 0 || p->losses[i].dim == 1)
+                                                  : !(p->losses[i].dim >= 2 && p->losses[i].dim <= GLRM_MAX_EMBEDDING_DIM))
+      return fail(GLRM_ERR_INVALID, "glrm_loss.dim = %d is not a valid embedding dimension for loss kind %d", p->losses[i].dim, p->losses[i].kind);
+    if ((p->losses[i].kind == GLRM_LOSS_OVA || p->losses[i].kind == GLRM_LOSS_BVS) &&
+        !(p->losses[i].p1 == GLRM_LOSS_LOGISTIC || p->losses[i].p1 == GLRM_LOSS_WEIGHTED_HINGE))
+      return fail(GLRM_ERR_UNSUPPORTED, "bin_loss of OvALoss / BvSLoss must be LogisticLoss or HingeLoss");
   }
   for (int64_t i = 0; i < p->n_rx; ++i) {
     if (p->rx[i].kind < 0 || p->rx[i].kind >= GLRM_REG_KIND_COUNT)
       return fail(GLRM_ERR_UNSUPPORTED, "rx regularizer kind %d is not supported", p->rx[i].kind);
-    if (p->rx[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_reg.reserved must be 0");
+    if (!(p->rx[i].wrap == 0 || p->rx[i].wrap == 1 || p->rx[i].wrap == 2 || p->rx[i].wrap == 4 || p->rx[i].wrap == 8))
+      return fail(GLRM_ERR_INVALID, "glrm_reg.wrap must be 0 or one GLRM_WRAP_* flag");
   }
   for (int64_t i = 0; i < p->n_ry; ++i) {
     if (p->ry[i].kind < 0 || p->ry[i].kind >= GLRM_REG_KIND_COUNT)
       return fail(GLRM_ERR_UNSUPPORTED, "ry regularizer kind %d is not supported", p->ry[i].kind);
-    if (p->ry[i].reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_reg.reserved must be 0");
+    if (!(p->ry[i].wrap == 0 || p->ry[i].wrap == 1 || p->ry[i].wrap == 2 || p->ry[i].wrap == 4 || p->ry[i].wrap == 8))
+      return fail(GLRM_ERR_INVALID, "glrm_reg.wrap must be 0 or one GLRM_WRAP_* flag");
   }
   return GLRM_OK;
 }
@@ -381,6 +391,12 @@ static int check_view(const char* name, int64_t nseg, const int64_t* ptr, const 
       if (loss_is_classification(l->kind) && !(vals[t] == 1.0 || vals[t] == 0.0))
         return fail(GLRM_ERR_NONFINITE, "entry in column %lld has label %g; a ClassificationLoss needs true(1)/false(0)",
                     (long long)f, vals[t]);
+      if (l->kind >= GLRM_LOSS_MULTINOMIAL) { /* levels 1..max index into u (BoundsError / InexactError in the reference) */
+        const int mx = (l->kind == GLRM_LOSS_BVS || l->kind == GLRM_LOSS_MULTINOMIAL_ORDINAL) ? l->dim + 1 : l->dim;
+        if (!(vals[t] >= 1.0 && vals[t] <= (double)mx && vals[t] == floor(vals[t])))
+          return fail(GLRM_ERR_NONFINITE, "entry (%lld, %lld) = %g is not a level in 1..%d of its categorical / ordinal loss",
+                      (long long)(by_idx ? seg_offset + s : idx[t]), (long long)f, vals[t], mx);
+      }
     }
   }
   return GLRM_OK;
@@ -424,11 +440,23 @@ int glrm_cpu_create(glrm_cpu_handle** out, const glrm_problem* p, const glrm_opt
   h->alpharow = (double*)malloc((size_t)(ml ? ml : 1) * 8);
   h->alphacol = (double*)malloc((size_t)(nl ? nl : 1) * 8);
   h->ownX = (double*)calloc((size_t)p->k * p->m, 8);
-  h->ownY = (double*)calloc((size_t)p->k * p->n, 8);
+  h->ystart = (int64_t*)malloc((size_t)(p->n + 1) * 8);
+  if (h->ystart) {
+    h->ystart[0] = 0;
+    for (int64_t f = 0; f < p->n; ++f) {
+      const glrm_loss* l = p->n_losses == 1 ? &p->losses[0] : &p->losses[f];
+      h->ystart[f + 1] = h->ystart[f] + (l->dim > 1 ? l->dim : 1);
+      if (l->dim > 1) h->multi = 1;
+    }
+    h->d = h->ystart[p->n];
+  }
+  for (int64_t i = 0; i < p->n_rx; ++i) if (p->rx[i].wrap) h->multi = 1;
+  for (int64_t i = 0; i < p->n_ry; ++i) if (p->ry[i].wrap) h->multi = 1;
+  h->ownY = (double*)calloc((size_t)p->k * (h->ystart ? h->d : p->n), 8);
   h->ownobjcol = (double*)calloc((size_t)p->n, 8);
   h->ownobjrow = (double*)calloc((size_t)p->m, 8);
   if (!h->rowptr || !h->colptr || !h->colidx || !h->rowidx || !h->rowvals || !h->colvals || !h->losses ||
-      !h->rx || !h->ry || !h->alpharow || !h->alphacol || !h->ownX || !h->ownY || !h->ownobjcol || !h->ownobjrow) {
+      !h->rx || !h->ry || !h->alpharow || !h->alphacol || !h->ownX || !h->ownY || !h->ownobjcol || !h->ownobjrow || !h->ystart) {
     glrm_cpu_destroy(h);
     return fail(GLRM_ERR_OOM, "out of memory");
   }
@@ -445,6 +473,7 @@ int glrm_cpu_create(glrm_cpu_handle** out, const glrm_problem* p, const glrm_opt
  * src/evaluate_fit.jl:29,45).  The numbers produced are identical to the sparse mode. */
 int glrm_cpu_set_dense_faithful(glrm_cpu_handle* h, int on) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (on && h->multi) return fail(GLRM_ERR_UNSUPPORTED, "dense-faithful mode covers scalar losses only");
   if (on && !(h->row_begin == 0 && h->row_end == h->m && h->col_begin == 0 && h->col_end == h->n))
     return fail(GLRM_ERR_INVALID, "dense-faithful mode needs a single-shard handle");
   h->dense_faithful = on ? 1 : 0;
@@ -546,7 +575,14 @@ int glrm_cpu_step_x_range(glrm_cpu_handle* h, int64_t seg_begin, int64_t seg_end
   return step_x_rows(h, seg_begin, seg_end, min_stepsize);
 }
 
+static int gen_step_x(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_stepsize, double fixed_alpha);
+static int gen_step_y(glrm_cpu_handle* h, double min_stepsize, double fixed_alpha);
+static double gen_full_objective(const glrm_cpu_handle* h, const double* X, const double* Y, int include_reg);
+static int gen_col_losses(glrm_cpu_handle* h);
+static int gen_penalties(glrm_cpu_handle* h, int rows);
+
 static int step_x_rows(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_stepsize) {
+  if (h->multi) return gen_step_x(h, s0, s1, min_stepsize, 0.0);
   const int k = h->k;
   int64_t trials = 0, accepts = 0;
 #pragma omp parallel num_threads(g_threads) reduction(+ : trials, accepts)
@@ -599,6 +635,7 @@ static int step_x_rows(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_st
 /* One inner Y sweep over the local columns, src/algorithms/proxgrad.jl:162-201. */
 int glrm_cpu_step_y(glrm_cpu_handle* h, double min_stepsize) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (h->multi) return gen_step_y(h, min_stepsize, 0.0);
   const int k = h->k;
   const int64_t nl = h->col_end - h->col_begin;
   const int64_t mlen = max_col_len(h) + (h->dense_faithful ? h->m : 0);
@@ -666,6 +703,7 @@ int glrm_cpu_step_y(glrm_cpu_handle* h, double min_stepsize) {
 /* Per-column loss sums (no regularizer) -> objcol[col_begin:col_end]. */
 int glrm_cpu_col_losses(glrm_cpu_handle* h) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (h->multi) return gen_col_losses(h);
   const int64_t nl = h->col_end - h->col_begin;
   const int64_t mlen = max_col_len(h) + (h->dense_faithful ? h->m : 0);
   double* mapped = (double*)malloc((size_t)(mlen ? mlen : 1) * 8);
@@ -688,6 +726,7 @@ int glrm_cpu_col_losses(glrm_cpu_handle* h) {
 
 int glrm_cpu_row_penalties(glrm_cpu_handle* h) { /* calc_penalty, src/evaluate_fit.jl:97-99 */
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (h->multi) return gen_penalties(h, 1);
   for (int64_t el = 0; el < h->row_end - h->row_begin; ++el)
     h->objrow[h->row_begin + el] = glrm_cpu_reg_evaluate(rx_of(h, el), h->X + (h->row_begin + el) * h->k, h->k);
   return GLRM_OK;
@@ -695,6 +734,7 @@ int glrm_cpu_row_penalties(glrm_cpu_handle* h) { /* calc_penalty, src/evaluate_f
 
 int glrm_cpu_col_penalties(glrm_cpu_handle* h) { /* calc_penalty, src/evaluate_fit.jl:100-102 */
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (h->multi) return gen_penalties(h, 0);
   for (int64_t fl = 0; fl < h->col_end - h->col_begin; ++fl)
     h->objcol[h->col_begin + fl] = glrm_cpu_reg_evaluate(ry_of(h, fl), h->Y + (h->col_begin + fl) * h->k, h->k);
   return GLRM_OK;
@@ -730,7 +770,7 @@ int glrm_cpu_bind_buffers(glrm_cpu_handle* h, void* X, void* Y, void* objcol, vo
 int glrm_cpu_set_factors(glrm_cpu_handle* h, const double* X, const double* Y) {
   if (!h || !X || !Y) return fail(GLRM_ERR_INVALID, "NULL argument");
   memcpy(h->X, X, (size_t)h->k * h->m * 8);
-  memcpy(h->Y, Y, (size_t)h->k * h->n * 8);
+  memcpy(h->Y, Y, (size_t)h->k * h->d * 8);
   recompute_XY(h);
   return GLRM_OK;
 }
@@ -738,7 +778,7 @@ int glrm_cpu_set_factors(glrm_cpu_handle* h, const double* X, const double* Y) {
 int glrm_cpu_get_factors(glrm_cpu_handle* h, double* X, double* Y) {
   if (!h || !X || !Y) return fail(GLRM_ERR_INVALID, "NULL argument");
   memcpy(X, h->X, (size_t)h->k * h->m * 8);
-  memcpy(Y, h->Y, (size_t)h->k * h->n * 8);
+  memcpy(Y, h->Y, (size_t)h->k * h->d * 8);
   return GLRM_OK;
 }
 
@@ -777,6 +817,7 @@ static int single_shard(const glrm_cpu_handle* h) {
 /* objective(glrm, X, Y, XY; include_regularization), src/evaluate_fit.jl:4-23 with
  * calc_penalty :91-104: ONE accumulator across all columns, columns outer, list order inner. */
 static double full_objective(const glrm_cpu_handle* h, const double* X, const double* Y, int include_reg) {
+  if (h->multi) return gen_full_objective(h, X, Y, include_reg);
   const int k = h->k;
   double err = 0.0;
   for (int64_t j = 0; j < h->n; ++j) {
@@ -811,7 +852,7 @@ int glrm_cpu_fit(glrm_cpu_handle* h, const glrm_params* prm, double* X, double* 
   if (prm->inner_iter_X < 1 || prm->inner_iter_Y < 1) return fail(GLRM_ERR_INVALID, "inner iteration counts must be >= 1");
   const int k = h->k;
   double ynorm = 0.0; /* norm(Y)==0 guard, :45-48 (the reference would hit an UndefVarError) */
-  for (int64_t i = 0; i < (int64_t)k * h->n; ++i) ynorm += Y[i] * Y[i];
+  for (int64_t i = 0; i < (int64_t)k * h->d; ++i) ynorm += Y[i] * Y[i];
   if (ynorm == 0.0) return fail(GLRM_ERR_INVALID, "Y is all zeros (the reference cannot start from Y == 0)");
 
   glrm_cpu_bind_buffers(h, NULL, NULL, NULL, NULL);
@@ -843,7 +884,7 @@ int glrm_cpu_fit(glrm_cpu_handle* h, const glrm_params* prm, double* X, double* 
     if (i > 10 && (obj_decrease < scaled_abs_tol || obj_decrease / obj < prm->rel_tol)) break; /* :211-213 */
   }
   memcpy(X, h->X, (size_t)k * h->m * 8);
-  memcpy(Y, h->Y, (size_t)k * h->n * 8);
+  memcpy(Y, h->Y, (size_t)k * h->d * 8);
   *n_recorded = nrec;
   return GLRM_OK;
 }
@@ -855,6 +896,7 @@ int glrm_cpu_fit(glrm_cpu_handle* h, const glrm_params* prm, double* X, double* 
 int glrm_cpu_gradstep_x(glrm_cpu_handle* h, double alpha) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
   if (!(alpha > 0.0)) return fail(GLRM_ERR_INVALID, "the step size must be positive");
+  if (h->multi) return gen_step_x(h, 0, h->row_end - h->row_begin, 0.0, alpha);
   const int k = h->k;
   const int64_t ml = h->row_end - h->row_begin;
 #pragma omp parallel num_threads(g_threads)
@@ -885,6 +927,7 @@ int glrm_cpu_gradstep_x(glrm_cpu_handle* h, double alpha) {
 int glrm_cpu_gradstep_y(glrm_cpu_handle* h, double alpha) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
   if (!(alpha > 0.0)) return fail(GLRM_ERR_INVALID, "the step size must be positive");
+  if (h->multi) return gen_step_y(h, 0.0, alpha);
   const int k = h->k;
   const int64_t nl = h->col_end - h->col_begin;
 #pragma omp parallel num_threads(g_threads)
@@ -921,9 +964,9 @@ int glrm_cpu_fit_sparse(glrm_cpu_handle* h, const glrm_sparse_params* prm, doubl
   if (prm->inner_iter < 1) return fail(GLRM_ERR_INVALID, "inner_iter must be >= 1");
   const int k = h->k;
   double ynorm = 0.0;
-  for (int64_t i = 0; i < (int64_t)k * h->n; ++i) ynorm += Y[i] * Y[i];
+  for (int64_t i = 0; i < (int64_t)k * h->d; ++i) ynorm += Y[i] * Y[i];
   if (ynorm == 0.0) return fail(GLRM_ERR_INVALID, "Y is all zeros");
-  const size_t xb = (size_t)k * h->m * 8, yb = (size_t)k * h->n * 8;
+  const size_t xb = (size_t)k * h->m * 8, yb = (size_t)k * h->d * 8;
   glrm_cpu_bind_buffers(h, NULL, NULL, NULL, NULL);
   glrm_cpu_set_factors(h, X, Y); /* working copies X, Y (:33); X, Y arguments hold the best model (glrm.X, glrm.Y) */
   double alpha = prm->stepsize;                                 /* :46 */
@@ -959,5 +1002,421 @@ int glrm_cpu_fit_sparse(glrm_cpu_handle* h, const glrm_sparse_params* prm, doubl
   seconds[nrec] = seconds[nrec - 1] + (now_s() - t);
   ++nrec;
   *n_recorded = nrec;
+  return GLRM_OK;
+}
+
+/* =====================================================================================================
+ * General code path: multi-dimensional losses (the column owns dim_f columns of Y), block regularizers and
+ * the offset wrappers.  Restates the non-scalar branches of src/algorithms/proxgrad.jl:126-131,169-174
+ * (gemm! with the gradient vector), src/evaluate_fit.jl:24-55, src/losses.jl:360-620,640-650 and
+ * src/regularizers.jl:163-189,356-411.  Scalar columns inside such a model use the same formulas as above.
+ * ===================================================================================================== */
+
+static int loss_dim(const glrm_loss* l) { return l->dim > 1 ? l->dim : 1; }
+
+static double bin_evaluate(const glrm_loss* l, double u, int truth) { /* bin_loss of OvA / BvS */
+  glrm_loss b = {(int32_t)l->p1, 0, l->p0, 1.0, 0.0}; /* LogisticLoss(scale) or HingeLoss(scale) (ratio 1) */
+  return glrm_cpu_loss_evaluate(&b, u, truth ? 1.0 : 0.0);
+}
+static double bin_grad(const glrm_loss* l, double u, int truth) {
+  glrm_loss b = {(int32_t)l->p1, 0, l->p0, 1.0, 0.0};
+  return glrm_cpu_loss_grad(&b, u, truth ? 1.0 : 0.0);
+}
+
+static void enforce_mnl_ord_rules(double* u, int d) { /* src/losses.jl:572-578, TOL = 1e-3 */
+  const double TOL = 1e-3;
+  u[0] = u[0] < -TOL ? u[0] : -TOL;
+  for (int j = 1; j < d; ++j) u[j] = u[j] < u[j - 1] - TOL ? u[j] : u[j - 1] - TOL;
+}
+
+/* evaluate(l, u::Vector, a::Integer); a is the level 1..max stored as a double.  u may be modified (the
+ * reference works on a copy of the row of XY). */
+double glrm_cpu_vloss_evaluate(const glrm_loss* l, double* u, double a_level) {
+  const int d = loss_dim(l), a = (int)a_level - 1;
+  const double s = l->scale;
+  switch (l->kind) {
+    case GLRM_LOSS_MULTINOMIAL: { /* :377-388 */
+      double mx = u[0];
+      for (int j = 1; j < d; ++j) if (u[j] > mx) mx = u[j];
+      const double M = mx - u[a];
+      double sumexp = 0;
+      for (int j = 0; j < d; ++j) sumexp += exp(u[j] - u[a] - M);
+      return s * (log(sumexp) + M);
+    }
+    case GLRM_LOSS_OVA: { /* :424-430 */
+      double loss = 0;
+      for (int j = 0; j < d; ++j) loss += bin_evaluate(l, u[j], a == j);
+      return s * loss;
+    }
+    case GLRM_LOSS_BVS: { /* :461-467: a > j with 1-based j */
+      double loss = 0;
+      for (int j = 0; j < d; ++j) loss += bin_evaluate(l, u[j], a + 1 > j + 1);
+      return s * loss;
+    }
+    case GLRM_LOSS_ORDISTIC: { /* :499-505 */
+      double M = -INFINITY, invlik = 0;
+      for (int j = 0; j < d; ++j) { const double q = u[a] * u[a] - u[j] * u[j]; if (q > M) M = q; }
+      for (int j = 0; j < d; ++j) invlik += exp((u[a] * u[a] - u[j] * u[j]) - M);
+      return s * (M + log(invlik));
+    }
+    case GLRM_LOSS_MULTINOMIAL_ORDINAL: { /* :581-590; max = d + 1 */
+      enforce_mnl_ord_rules(u, d);
+      if (a == 0) return -s * log(exp(0) - exp(u[0]));
+      if (a == d) return -s * u[a - 1];
+      return -s * log(exp(u[a - 1]) - exp(u[a]));
+    }
+    default:
+      return glrm_cpu_loss_evaluate(l, u[0], a_level);
+  }
+}
+
+/* grad(l, u::Vector, a::Integer) -> g[0..d) */
+void glrm_cpu_vloss_grad(const glrm_loss* l, double* u, double a_level, double* g) {
+  const int d = loss_dim(l), a = (int)a_level - 1;
+  const double s = l->scale;
+  switch (l->kind) {
+    case GLRM_LOSS_MULTINOMIAL: { /* :390-406 */
+      double mx = u[0];
+      for (int j = 1; j < d; ++j) if (u[j] > mx) mx = u[j];
+      for (int j = 0; j < d; ++j) g[j] = 0;
+      g[a] = -1;
+      for (int j = 0; j < d; ++j) {
+        const double M = mx - u[j];
+        double sumexp = 0;
+        for (int jp = 0; jp < d; ++jp) sumexp += exp(u[jp] - u[j] - M);
+        g[j] += exp(-M) / sumexp;
+      }
+      for (int j = 0; j < d; ++j) g[j] = s * g[j];
+      return;
+    }
+    case GLRM_LOSS_OVA:
+      for (int j = 0; j < d; ++j) g[j] = s * bin_grad(l, u[j], a == j);
+      return;
+    case GLRM_LOSS_BVS:
+      for (int j = 0; j < d; ++j) g[j] = s * bin_grad(l, u[j], a + 1 > j + 1);
+      return;
+    case GLRM_LOSS_ORDISTIC: { /* :507-519 */
+      for (int j = 0; j < d; ++j) g[j] = 0;
+      g[a] = 2 * u[a];
+      for (int j = 0; j < d; ++j) {
+        double M = -INFINITY, invlik = 0;
+        for (int jp = 0; jp < d; ++jp) { const double q = u[j] * u[j] - u[jp] * u[jp]; if (q > M) M = q; }
+        for (int jp = 0; jp < d; ++jp) invlik += exp((u[j] * u[j] - u[jp] * u[jp]) - M);
+        g[j] -= 2 * u[j] * exp(-M) / invlik;
+      }
+      for (int j = 0; j < d; ++j) g[j] = s * g[j];
+      return;
+    }
+    case GLRM_LOSS_MULTINOMIAL_ORDINAL: { /* :592-609 */
+      enforce_mnl_ord_rules(u, d);
+      for (int j = 0; j < d; ++j) g[j] = 0;
+      if (a == 0) {
+        g[0] = -exp(u[0]) / (exp(0) - exp(u[0]));
+      } else if (a == d) {
+        g[a - 1] = 1;
+      } else {
+        g[a] = -exp(u[a]) / (exp(u[a - 1]) - exp(u[a]));
+        g[a - 1] = exp(u[a - 1]) / (exp(u[a - 1]) - exp(u[a]));
+      }
+      for (int j = 0; j < d; ++j) g[j] = -s * g[j];
+      return;
+    }
+    default:
+      g[0] = glrm_cpu_loss_grad(l, u[0], a_level);
+  }
+}
+
+/* evaluate(r, a) for a k x d block (column-major, ld = k) with the wrappers of src/regularizers.jl:163-189,356-411. */
+double glrm_cpu_reg_evaluate_block(const glrm_reg* r, const double* a, int k, int d) {
+  glrm_reg base = {r->kind, 0, r->scale};
+  double tmp[ORACLE_MAX_K];
+  switch (r->wrap) {
+    case 0: { /* elementwise regularizers see the block as one array */
+      if (d == 1) return glrm_cpu_reg_evaluate(&base, a, k);
+      if (r->kind == GLRM_REG_QUAD || r->kind == GLRM_REG_ONE) { /* scale * sum over all entries (sequential, column-major) */
+        double acc = 0.0;
+        for (int i = 0; i < k * d; ++i) acc += r->kind == GLRM_REG_QUAD ? a[i] * a[i] : fabs(a[i]);
+        return r->scale * acc;
+      }
+      if (r->kind == GLRM_REG_ZERO) return 0.0;
+      if (r->kind == GLRM_REG_NONNEG) { for (int i = 0; i < k * d; ++i) if (a[i] < 0) return INFINITY; return 0.0; }
+      { int one = 0; /* UnitOneSparse over the whole block */
+        for (int i = 0; i < k * d; ++i) { if (a[i] == 0) continue; if (a[i] == 1) { if (one) return INFINITY; one = 1; } else return INFINITY; }
+        return 0.0; }
+    }
+    case GLRM_WRAP_LASTENTRY1: /* a[end]==1 ? evaluate(r.r, a[1:end-1]) : Inf  (vectors; every column's last entry for blocks) */
+      for (int j = 0; j < d; ++j) if (a[j * k + k - 1] != 1) return INFINITY;
+      __attribute__((fallthrough)); /* then evaluate(r.r, all rows but the last) */
+    case GLRM_WRAP_LASTENTRY_UNPENALIZED: { /* evaluate(r.r, a[1:end-1, :]) */
+      if (d == 1) return glrm_cpu_reg_evaluate(&base, a, k - 1);
+      double acc = 0.0;
+      if (r->kind == GLRM_REG_QUAD || r->kind == GLRM_REG_ONE) {
+        for (int j = 0; j < d; ++j) for (int i = 0; i < k - 1; ++i) { const double v = a[j * k + i]; acc += r->kind == GLRM_REG_QUAD ? v * v : fabs(v); }
+        return r->scale * acc;
+      }
+      if (r->kind == GLRM_REG_ZERO) return 0.0;
+      if (r->kind == GLRM_REG_NONNEG) { for (int j = 0; j < d; ++j) for (int i = 0; i < k - 1; ++i) if (a[j * k + i] < 0) return INFINITY; return 0.0; }
+      { int one = 0;
+        for (int j = 0; j < d; ++j) for (int i = 0; i < k - 1; ++i) { const double v = a[j * k + i]; if (v == 0) continue; if (v == 1) { if (one) return INFINITY; one = 1; } else return INFINITY; }
+        return 0.0; }
+    }
+    default: /* OrdinalReg / MNLOrdinalReg: evaluate(r.r, a[1:end-1, 1]) */
+      for (int i = 0; i < k - 1; ++i) tmp[i] = a[i];
+      return glrm_cpu_reg_evaluate(&base, tmp, k - 1);
+  }
+}
+
+/* prox!(r, u, alpha) on a k x d block. */
+void glrm_cpu_reg_prox_block(const glrm_reg* r, double* u, int k, int d, double alpha) {
+  glrm_reg base = {r->kind, 0, r->scale};
+  switch (r->wrap) {
+    case 0:
+      if (r->kind == GLRM_REG_UNIT_ONE_SPARSE) { glrm_cpu_reg_prox(&base, u, k * d, alpha); return; } /* argmax over the block */
+      for (int j = 0; j < d; ++j) glrm_cpu_reg_prox(&base, u + j * k, k, alpha); /* elementwise */
+      return;
+    case GLRM_WRAP_LASTENTRY1: /* prox!(r.r, u[1:end-1]); u[end] = 1 */
+      for (int j = 0; j < d; ++j) { glrm_cpu_reg_prox(&base, u + j * k, k - 1, alpha); u[j * k + k - 1] = 1; }
+      return;
+    case GLRM_WRAP_LASTENTRY_UNPENALIZED: /* prox!(r.r, u[1:end-1, :]) */
+      if (r->kind == GLRM_REG_UNIT_ONE_SPARSE && d > 1) { /* argmax over the (k-1) x d sub-block, column-major */
+        int bi = 0, bj = 0;
+        for (int j = 0; j < d; ++j) for (int i = 0; i < k - 1; ++i) if (u[j * k + i] > u[bj * k + bi]) { bi = i; bj = j; }
+        for (int j = 0; j < d; ++j) for (int i = 0; i < k - 1; ++i) u[j * k + i] = 0;
+        u[bj * k + bi] = 1;
+        return;
+      }
+      for (int j = 0; j < d; ++j) glrm_cpu_reg_prox(&base, u + j * k, k - 1, alpha);
+      return;
+    default: { /* OrdinalReg :360-379 / MNLOrdinalReg :391-405 */
+      double um[ORACLE_MAX_K];
+      for (int i = 0; i < k - 1; ++i) { /* mean(u[1:end-1, :], dims=2) */
+        double acc = 0.0;
+        for (int j = 0; j < d; ++j) acc += u[j * k + i];
+        um[i] = acc / d;
+      }
+      glrm_cpu_reg_prox(&base, um, k - 1, alpha);
+      for (int i = 0; i < k - 1; ++i) for (int j = 0; j < d; ++j) u[j * k + i] = um[i];
+      if (r->wrap == GLRM_WRAP_MNL_ORDINAL) {
+        const double TOL = 1e-3;
+        double* last = u + (k - 1);
+        last[0] = last[0] < -TOL ? last[0] : -TOL;
+        for (int j = 1; j < d; ++j) last[j * k] = last[j * k] < last[(j - 1) * k] - TOL ? last[j * k] : last[(j - 1) * k] - TOL;
+      }
+      return;
+    }
+  }
+}
+
+/* u = x' * Y[:, ys .. ys+d) */
+static void dots_block(const double* x, const double* Yb, int k, int d, double* u) {
+  for (int j = 0; j < d; ++j) u[j] = dotk(x, Yb + (int64_t)j * k, k);
+}
+
+static double gen_row_objective(const glrm_cpu_handle* h, int64_t el, const double* x) { /* src/evaluate_fit.jl:24-38 */
+  const int k = h->k;
+  double err = 0.0, u[GLRM_MAX_EMBEDDING_DIM];
+  for (int64_t t = h->rowptr[el]; t < h->rowptr[el + 1]; ++t) {
+    const int64_t f = h->colidx[t];
+    const glrm_loss* l = loss_of(h, f);
+    const int d = loss_dim(l);
+    dots_block(x, h->Y + h->ystart[f] * k, k, d, u);
+    err += d == 1 ? glrm_cpu_loss_evaluate(l, u[0], h->rowvals[t]) : glrm_cpu_vloss_evaluate(l, u, h->rowvals[t]);
+  }
+  return err + glrm_cpu_reg_evaluate_block(rx_of(h, el), x, k, 1);
+}
+
+/* loss part of col_objective for a k x d block y (src/evaluate_fit.jl:39-51); multi-dimensional losses sum
+ * sequentially from 0 (src/losses.jl:640-650), scalar ones as in col_loss above. */
+static double gen_col_loss(const glrm_cpu_handle* h, int64_t fl, const double* y, double* mapped) {
+  const int k = h->k;
+  const int64_t fg = h->col_begin + fl, b = h->colptr[fl], e = h->colptr[fl + 1], len = e - b;
+  const glrm_loss* l = loss_of(h, fg);
+  const int d = loss_dim(l);
+  double u[GLRM_MAX_EMBEDDING_DIM];
+  for (int64_t t = 0; t < len; ++t) {
+    dots_block(h->X + (int64_t)h->rowidx[b + t] * k, y, k, d, u);
+    mapped[t] = d == 1 ? glrm_cpu_loss_evaluate(l, u[0], h->colvals[b + t]) : glrm_cpu_vloss_evaluate(l, u, h->colvals[b + t]);
+  }
+  if (d == 1 && loss_is_single_dim(l->kind)) return julia_sum(mapped, len);
+  double out = 0;
+  for (int64_t t = 0; t < len; ++t) out += mapped[t];
+  return out;
+}
+
+static int gen_step_x(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_stepsize, double fixed_alpha) {
+  const int k = h->k;
+  int64_t trials = 0, accepts = 0;
+#pragma omp parallel num_threads(g_threads) reduction(+ : trials, accepts)
+  {
+    double g[ORACLE_MAX_K], newx[ORACLE_MAX_K], u[GLRM_MAX_EMBEDDING_DIM], cg[GLRM_MAX_EMBEDDING_DIM];
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t el = s0; el < s1; ++el) {
+      double* x = h->X + (h->row_begin + el) * k;
+      const int64_t b = h->rowptr[el], e = h->rowptr[el + 1];
+      for (int c = 0; c < k; ++c) g[c] = 0.0;
+      for (int64_t t = b; t < e; ++t) { /* proxgrad.jl:122-132 */
+        const int64_t f = h->colidx[t];
+        const glrm_loss* l = loss_of(h, f);
+        const int d = loss_dim(l);
+        const double* Yb = h->Y + h->ystart[f] * k;
+        dots_block(x, Yb, k, d, u);
+        if (d == 1) cg[0] = glrm_cpu_loss_grad(l, u[0], h->rowvals[t]);
+        else glrm_cpu_vloss_grad(l, u, h->rowvals[t], cg);
+        for (int j = 0; j < d; ++j) /* gemm!('N','N',1.0, vf[f], curgrad, 1.0, g): g += Y_f * curgrad */
+          for (int c = 0; c < k; ++c) g[c] = fma(cg[j], Yb[(int64_t)j * k + c], g[c]);
+      }
+      const double l1 = (double)(e - b) + 1;
+      const glrm_reg* r = rx_of(h, el);
+      if (fixed_alpha > 0.0) { /* sparse_proxgrad.jl:72-78 */
+        const double s = fixed_alpha / l1;
+        for (int c = 0; c < k; ++c) g[c] = g[c] * (-s);
+        for (int c = 0; c < k; ++c) x[c] = x[c] + g[c];
+        glrm_cpu_reg_prox_block(r, x, k, 1, s);
+        continue;
+      }
+      const double obj_old = gen_row_objective(h, el, x);
+      double alpha = h->alpharow[el];
+      while (alpha > min_stepsize) {
+        const double stepsize = alpha / l1;
+        for (int c = 0; c < k; ++c) newx[c] = fma(-stepsize, g[c], x[c]);
+        glrm_cpu_reg_prox_block(r, newx, k, 1, stepsize);
+        ++trials;
+        if (gen_row_objective(h, el, newx) < obj_old) {
+          memcpy(x, newx, (size_t)k * 8);
+          alpha *= 1.05;
+          ++accepts;
+          break;
+        } else {
+          alpha *= .7;
+          if (alpha < min_stepsize) { alpha = min_stepsize * 1.1; break; }
+        }
+      }
+      h->alpharow[el] = alpha;
+    }
+  }
+  if (fixed_alpha <= 0.0) { h->st.launches_x += 1; h->st.trials_x += trials; h->st.accepts_x += accepts; }
+  return GLRM_OK;
+}
+
+static int gen_step_y(glrm_cpu_handle* h, double min_stepsize, double fixed_alpha) {
+  const int k = h->k;
+  const int64_t nl = h->col_end - h->col_begin;
+  const int64_t mlen = max_col_len(h);
+  int64_t trials = 0, accepts = 0;
+  int oom = 0;
+#pragma omp parallel num_threads(g_threads) reduction(+ : trials, accepts) reduction(| : oom)
+  {
+    double* G = (double*)malloc((size_t)k * GLRM_MAX_EMBEDDING_DIM * 8);
+    double* newy = (double*)malloc((size_t)k * GLRM_MAX_EMBEDDING_DIM * 8);
+    double* mapped = (double*)malloc((size_t)(mlen ? mlen : 1) * 8);
+    double u[GLRM_MAX_EMBEDDING_DIM], cg[GLRM_MAX_EMBEDDING_DIM];
+    if (!G || !newy || !mapped) oom = 1;
+#pragma omp for schedule(dynamic, 1)
+    for (int64_t fl = 0; fl < nl; ++fl) {
+      if (oom) continue;
+      const int64_t fg = h->col_begin + fl;
+      const glrm_loss* lo = loss_of(h, fg);
+      const int d = loss_dim(lo);
+      double* y = h->Y + h->ystart[fg] * k; /* k x d block */
+      const int64_t b = h->colptr[fl], e = h->colptr[fl + 1];
+      for (int i = 0; i < k * d; ++i) G[i] = 0.0;
+      for (int64_t t = b; t < e; ++t) { /* proxgrad.jl:165-175 */
+        const double* x = h->X + (int64_t)h->rowidx[t] * k;
+        dots_block(x, y, k, d, u);
+        if (d == 1) cg[0] = glrm_cpu_loss_grad(lo, u[0], h->colvals[t]);
+        else glrm_cpu_vloss_grad(lo, u, h->colvals[t], cg);
+        for (int j = 0; j < d; ++j) /* gemm!('N','T',1.0, ve[e], curgrad, 1.0, gf[f]): G += x * curgrad' */
+          for (int c = 0; c < k; ++c) G[j * k + c] = fma(cg[j], x[c], G[j * k + c]);
+      }
+      const double l1 = (double)(e - b) + 1;
+      const glrm_reg* r = ry_of(h, fl);
+      if (fixed_alpha > 0.0) {
+        const double s = fixed_alpha / l1;
+        for (int i = 0; i < k * d; ++i) G[i] = G[i] * (-s);
+        for (int i = 0; i < k * d; ++i) y[i] = y[i] + G[i];
+        glrm_cpu_reg_prox_block(r, y, k, d, s);
+        continue;
+      }
+      double obj = 0.0;
+      obj += gen_col_loss(h, fl, y, mapped);
+      obj += glrm_cpu_reg_evaluate_block(r, y, k, d);
+      double alpha = h->alphacol[fl];
+      while (alpha > min_stepsize) {
+        const double stepsize = alpha / l1;
+        for (int i = 0; i < k * d; ++i) newy[i] = fma(-stepsize, G[i], y[i]);
+        glrm_cpu_reg_prox_block(r, newy, k, d, stepsize);
+        double nobj = 0.0;
+        nobj += gen_col_loss(h, fl, newy, mapped);
+        nobj += glrm_cpu_reg_evaluate_block(r, newy, k, d);
+        ++trials;
+        if (nobj < obj) {
+          memcpy(y, newy, (size_t)k * d * 8);
+          alpha *= 1.05;
+          obj = nobj;
+          ++accepts;
+          break;
+        } else {
+          alpha *= .7;
+          if (alpha < min_stepsize) { alpha = min_stepsize * 1.1; break; }
+        }
+      }
+      h->alphacol[fl] = alpha;
+      h->objcol[fg] = obj;
+    }
+    free(G); free(newy); free(mapped);
+  }
+  if (oom) return fail(GLRM_ERR_OOM, "out of memory");
+  if (fixed_alpha <= 0.0) { h->st.launches_y += 1; h->st.trials_y += trials; h->st.accepts_y += accepts; }
+  return GLRM_OK;
+}
+
+static double gen_full_objective(const glrm_cpu_handle* h, const double* X, const double* Y, int include_reg) {
+  const int k = h->k;
+  double err = 0.0, u[GLRM_MAX_EMBEDDING_DIM];
+  for (int64_t j = 0; j < h->n; ++j) { /* src/evaluate_fit.jl:13-17 */
+    const glrm_loss* lo = loss_of(h, j);
+    const int d = loss_dim(lo);
+    for (int64_t t = h->colptr[j]; t < h->colptr[j + 1]; ++t) {
+      dots_block(X + (int64_t)h->rowidx[t] * k, Y + h->ystart[j] * k, k, d, u);
+      err += d == 1 ? glrm_cpu_loss_evaluate(lo, u[0], h->colvals[t]) : glrm_cpu_vloss_evaluate(lo, u, h->colvals[t]);
+    }
+  }
+  if (include_reg) {
+    double penalty = 0.0;
+    for (int64_t i = 0; i < h->m; ++i) penalty += glrm_cpu_reg_evaluate_block(rx_of(h, i), X + i * k, k, 1);
+    for (int64_t f = 0; f < h->n; ++f) penalty += glrm_cpu_reg_evaluate_block(ry_of(h, f), Y + h->ystart[f] * k, k, loss_dim(loss_of(h, f)));
+    err += penalty;
+  }
+  return err;
+}
+
+static int gen_col_losses(glrm_cpu_handle* h) {
+  const int k = h->k;
+  double u[GLRM_MAX_EMBEDDING_DIM];
+  for (int64_t fl = 0; fl < h->col_end - h->col_begin; ++fl) {
+    const int64_t fg = h->col_begin + fl;
+    const glrm_loss* lo = loss_of(h, fg);
+    const int d = loss_dim(lo);
+    double err = 0.0;
+    for (int64_t t = h->colptr[fl]; t < h->colptr[fl + 1]; ++t) {
+      dots_block(h->X + (int64_t)h->rowidx[t] * k, h->Y + h->ystart[fg] * k, k, d, u);
+      err += d == 1 ? glrm_cpu_loss_evaluate(lo, u[0], h->colvals[t]) : glrm_cpu_vloss_evaluate(lo, u, h->colvals[t]);
+    }
+    h->objcol[fg] = err;
+  }
+  return GLRM_OK;
+}
+
+static int gen_penalties(glrm_cpu_handle* h, int rows) {
+  const int k = h->k;
+  if (rows) {
+    for (int64_t el = 0; el < h->row_end - h->row_begin; ++el)
+      h->objrow[h->row_begin + el] = glrm_cpu_reg_evaluate_block(rx_of(h, el), h->X + (h->row_begin + el) * k, k, 1);
+  } else {
+    for (int64_t fl = 0; fl < h->col_end - h->col_begin; ++fl) {
+      const int64_t fg = h->col_begin + fl;
+      h->objcol[fg] = glrm_cpu_reg_evaluate_block(ry_of(h, fl), h->Y + h->ystart[fg] * k, k, loss_dim(loss_of(h, fg)));
+    }
+  }
   return GLRM_OK;
 }

@@ -39,6 +39,14 @@ def oracle_lib():
         _lib.glrm_cpu_reg_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         _lib.glrm_cpu_reg_prox.restype = None
         _lib.glrm_cpu_reg_prox.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+        _lib.glrm_cpu_vloss_evaluate.restype = C.c_double
+        _lib.glrm_cpu_vloss_evaluate.argtypes = [C.c_void_p, C.c_void_p, C.c_double]
+        _lib.glrm_cpu_vloss_grad.restype = None
+        _lib.glrm_cpu_vloss_grad.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        _lib.glrm_cpu_reg_evaluate_block.restype = C.c_double
+        _lib.glrm_cpu_reg_evaluate_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        _lib.glrm_cpu_reg_prox_block.restype = None
+        _lib.glrm_cpu_reg_prox_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double]
         _lib.glrm_cpu_set_threads.argtypes = [C.c_int]
         _lib.glrm_cpu_set_dense_faithful.argtypes = [C.c_void_p, C.c_int]
         _lib.glrm_cpu_get_stepsizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -78,6 +86,37 @@ def loss_evaluate(loss, u, a):
 def loss_grad(loss, u, a):
     st = _loss_struct(loss)
     return oracle_lib().glrm_cpu_loss_grad(C.addressof(st), float(u), float(a))
+
+
+def vloss_evaluate(loss, u, a):
+    """evaluate(l, u::Vector, a::Integer) of a multi-dimensional loss (a = level 1..max)."""
+    st = _loss_struct(loss)
+    u = np.array(u, dtype=np.float64)
+    return oracle_lib().glrm_cpu_vloss_evaluate(C.addressof(st), u.ctypes.data, float(a))
+
+
+def vloss_grad(loss, u, a):
+    st = _loss_struct(loss)
+    u = np.array(u, dtype=np.float64)
+    g = np.zeros_like(u)
+    oracle_lib().glrm_cpu_vloss_grad(C.addressof(st), u.ctypes.data, float(a), g.ctypes.data)
+    return g
+
+
+def reg_evaluate_block(reg, a):
+    """evaluate(r, a) for a k x d block (numpy (k, d)); wrappers included."""
+    st = _reg_struct(reg)
+    a = np.asfortranarray(np.atleast_2d(np.asarray(a, dtype=np.float64).T).T if np.ndim(a) == 1 else np.asarray(a, dtype=np.float64))
+    k, d = (a.shape[0], 1) if a.ndim == 1 else a.shape
+    return oracle_lib().glrm_cpu_reg_evaluate_block(C.addressof(st), a.ctypes.data, k, d)
+
+
+def reg_prox_block(reg, u, alpha):
+    st = _reg_struct(reg)
+    u = np.array(u, dtype=np.float64, order="F")
+    k, d = (u.shape[0], 1) if u.ndim == 1 else u.shape
+    oracle_lib().glrm_cpu_reg_prox_block(C.addressof(st), u.ctypes.data, k, d, float(alpha))
+    return u
 
 
 def reg_evaluate(reg, x):

@@ -156,3 +156,163 @@ def test_c_oracle_agrees_with_dense_numpy_transcription(name):
     # identical line-search decisions: the per-row / per-column step sizes coincide
     np.testing.assert_allclose(a_r, ar, rtol=1e-12)
     np.testing.assert_allclose(a_c, ac, rtol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Multi-dimensional losses, block regularizers, offsets: the same transcription with Y's column spans (get_yidxs,
+# src/losses.jl:76-93), vector gradients (gemm! branches of proxgrad.jl:126-131,169-174) and k x d prox blocks.
+
+def numpy_proxgrad_general(A, losses, rx, ry, feats, exs, X, Y, p):
+    m, n = A.shape
+    k = X.shape[0]
+    X, Y = X.copy(), Y.copy()
+    yidxs = L.get_yidxs(losses)
+
+    def sl(j):
+        return slice(*yidxs[j])
+
+    def lev(j, u, a):                                       # scalar columns see a Float64, vector ones a Vector
+        return losses[j].evaluate(u[0], a) if losses[j].embedding_dim == 1 else losses[j].evaluate(u, a)
+
+    def lgrad(j, u, a):
+        return np.atleast_1d(losses[j].grad(u[0], a)) if losses[j].embedding_dim == 1 else np.asarray(losses[j].grad(u, a))
+
+    def yblock(j, Yb):                                      # what the reference hands to evaluate / prox: vf[f]
+        return Yb[:, 0] if losses[j].embedding_dim == 1 else Yb
+
+    XY = X.T @ Y
+    alpharow, alphacol = p.stepsize * np.ones(m), p.stepsize * np.ones(n)
+    scaled_abs_tol = p.abs_tol * sum(len(f) for f in feats)
+
+    def row_objective(i, x):
+        xy = x @ Y
+        err = 0.0
+        for j in feats[i]:
+            err += lev(j, xy[sl(j)], A[i, j])
+        return err + rx[i].evaluate(x)
+
+    def col_objective(j, yb):
+        xy = X.T @ yb.reshape(k, -1)
+        err = 0.0
+        for i in exs[j]:
+            err += lev(j, xy[i], A[i, j])
+        return err + ry[j].evaluate(yblock(j, yb.reshape(k, -1)))
+
+    obj0 = 0.0
+    for j in range(n):
+        for i in exs[j]:
+            obj0 += lev(j, XY[i, sl(j)], A[i, j])
+    obj0 += sum(rx[i].evaluate(X[:, i]) for i in range(m)) + sum(ry[j].evaluate(yblock(j, Y[:, sl(j)])) for j in range(n))
+    ch = [obj0]
+    obj_by_col = np.zeros(n)
+    for it in range(1, p.max_iter + 1):
+        if p.inner_iter_X > 1 or p.inner_iter_Y > 1:
+            alpharow[:] = p.stepsize
+            alphacol[:] = p.stepsize
+        for _ in range(p.inner_iter_X):
+            for e in range(m):
+                g = np.zeros(k)
+                for f in feats[e]:
+                    g += Y[:, sl(f)] @ lgrad(f, XY[e, sl(f)], A[e, f])
+                l = len(feats[e]) + 1
+                obj_old = row_objective(e, X[:, e])
+                while alpharow[e] > p.min_stepsize:
+                    stepsize = alpharow[e] / l
+                    newx = np.asarray(rx[e].prox(X[:, e] - stepsize * g, stepsize), dtype=float)
+                    if row_objective(e, newx) < obj_old:
+                        X[:, e] = newx
+                        alpharow[e] *= 1.05
+                        break
+                    alpharow[e] *= .7
+                    if alpharow[e] < p.min_stepsize:
+                        alpharow[e] = p.min_stepsize * 1.1
+                        break
+            XY = X.T @ Y
+        for _ in range(p.inner_iter_Y):
+            for f in range(n):
+                d = losses[f].embedding_dim
+                G = np.zeros((k, d))
+                for e in exs[f]:
+                    G += np.outer(X[:, e], lgrad(f, XY[e, sl(f)], A[e, f]))
+                l = len(exs[f]) + 1
+                obj_by_col[f] = col_objective(f, Y[:, sl(f)])
+                while alphacol[f] > p.min_stepsize:
+                    stepsize = alphacol[f] / l
+                    newy = np.asarray(ry[f].prox(yblock(f, Y[:, sl(f)] - stepsize * G), stepsize), dtype=float).reshape(k, d)
+                    new_obj = col_objective(f, newy)
+                    if new_obj < obj_by_col[f]:
+                        Y[:, sl(f)] = newy
+                        alphacol[f] *= 1.05
+                        obj_by_col[f] = new_obj
+                        break
+                    alphacol[f] *= .7
+                    if alphacol[f] < p.min_stepsize:
+                        alphacol[f] = p.min_stepsize * 1.1
+                        break
+            XY = X.T @ Y
+        obj = float(np.sum(obj_by_col))
+        ch.append(obj)
+        dec = ch[-2] - obj
+        if it > 10 and (dec < scaled_abs_tol or dec / obj < p.rel_tol):
+            break
+    return X, Y, ch, alpharow, alphacol
+
+
+def multidim_model(name, rng):
+    m, k = 28, 3
+    Z = rng.standard_normal((m, k))
+    if name == "multinomial_ova_bvs":
+        losses = [L.MultinomialLoss(4), L.QuadLoss(), L.OvALoss(3, bin_loss=L.LogisticLoss()), L.BvSLoss(5),
+                  L.OvALoss(4, bin_loss=L.HingeLoss()), L.LogisticLoss(), L.BvSLoss(3, bin_loss=L.HingeLoss()), L.MultinomialLoss(3, 0.7)]
+        rx, ry = [L.QuadReg(0.1)] * m, [L.QuadReg(0.2)] * len(losses)
+        p = L.ProxGradParams(max_iter=12)
+    elif name == "ordinal_with_offsets":
+        # the reference's ordinal recipe: lastentry1 on X, OrdinalReg / MNLOrdinalReg on the ordinal columns of Y
+        losses = [L.OrdisticLoss(4), L.MultinomialOrdinalLoss(5), L.QuadLoss(), L.BvSLoss(4), L.MultinomialOrdinalLoss(3)]
+        rx = [L.lastentry1(L.QuadReg(0.1))] * m
+        ry = [L.lastentry_unpenalized(L.QuadReg(0.1)), L.MNLOrdinalReg(L.QuadReg(0.1)), L.lastentry_unpenalized(L.QuadReg(0.3)),
+              L.OrdinalReg(L.QuadReg(0.1)), L.MNLOrdinalReg(L.ZeroReg())]
+        p = L.ProxGradParams(max_iter=12)
+    else:  # offsets_scalar: add_offset! on a scalar-loss model (src/modify_glrm.jl:20-25)
+        losses = [L.QuadLoss(), L.HuberLoss(), L.LogisticLoss(), L.QuadLoss(0.5), L.L1Loss()]
+        rx = [L.lastentry1(L.OneReg(0.05))] * m
+        ry = [L.lastentry_unpenalized(L.QuadReg(0.2))] * len(losses)
+        p = L.ProxGradParams(max_iter=14, inner_iter=2)
+    n = len(losses)
+    A = np.zeros((m, n))
+    for f, lo in enumerate(losses):
+        z = Z @ rng.standard_normal(k)
+        if hasattr(lo, "max"):
+            A[:, f] = np.clip(np.round((lo.max + 1) / 2 + z), 1, lo.max)
+        elif lo.classification:
+            A[:, f] = z > 0
+        else:
+            A[:, f] = z
+    mask = rng.random((m, n)) < 0.8
+    feats = [list(np.flatnonzero(mask[i])) for i in range(m)]
+    exs = [list(np.flatnonzero(mask[:, j])) for j in range(n)]
+    D = L.embedding_dim(losses)
+    return A, losses, rx, ry, feats, exs, rng.standard_normal((k, m)), rng.standard_normal((k, D)), p, k
+
+
+@pytest.mark.parametrize("name", ["multinomial_ova_bvs", "ordinal_with_offsets", "offsets_scalar"])
+def test_c_oracle_multidim_agrees_with_numpy_transcription(name):
+    rng = np.random.default_rng({"multinomial_ova_bvs": 11, "ordinal_with_offsets": 12, "offsets_scalar": 13}[name])
+    A, losses, rx, ry, feats, exs, X0, Y0, p, k = multidim_model(name, rng)
+    Xn, Yn, chn, ar, ac = numpy_proxgrad_general(A, losses, rx, ry, feats, exs, X0, Y0, p)
+    g = L.GLRM(A, losses, rx, ry, k, observed_features=feats, observed_examples=exs, X=X0, Y=Y0)
+    api, lib = O.oracle_api(), O.oracle_lib()
+    O.set_threads(1)
+    h = api.create(g.problem_arrays())
+    try:
+        X, Y = np.array(X0, order="F"), np.array(Y0, order="F")
+        obj, _ = api.fit(h, p, X, Y)
+        a_r, a_c = np.zeros(len(feats)), np.zeros(len(exs))
+        lib.glrm_cpu_get_stepsizes(h, a_r.ctypes.data, a_c.ctypes.data)
+    finally:
+        api.destroy(h)
+    assert len(obj) == len(chn)
+    assert cases.rel_err(obj, chn) < 1e-9
+    assert cases.fro_err(X, Xn) < 1e-9 and cases.fro_err(Y, Yn) < 1e-9
+    np.testing.assert_allclose(a_r, ar, rtol=1e-12)
+    np.testing.assert_allclose(a_c, ac, rtol=1e-12)
