@@ -3,9 +3,10 @@ src/utilities/conveniencemethods.jl:16-49) and its lowering to the engine's CSR 
 
 Differences from the Julia type that a user can see:
   * indices are 0-based (Python); the Julia shim (julia/HipGLRM.jl) keeps 1-based indices;
-  * only scalar losses and the regularizers of include/glrm_hip.h are accepted (everything else
-    is outside the accelerated path, SURVEY.md section 2);
-  * ``offset=True`` / ``scale=True`` wrap regularizers that are out of scope -> NotImplementedError.
+  * the losses and regularizers of include/glrm_hip.h are accepted (nine scalar losses, five multi-dimensional ones,
+    five base regularizers and their offset / ordinal wrappers); everything else is outside the accelerated path
+    (SURVEY.md section 2);
+  * ``scale=True`` (equilibrate_variance!) is out of scope -> NotImplementedError.
 """
 from __future__ import annotations
 
@@ -85,7 +86,7 @@ class GLRM:
             raise ValueError("There must be either one Y regularizer or as many Y regularizers as there are columns in the data matrix")
         for l in losses:
             if not isinstance(l, Loss) or l.kind < 0:
-                raise NotImplementedError(f"{type(l).__name__} is outside the accelerated path (scalar losses only)")
+                raise NotImplementedError(f"{type(l).__name__} is outside the accelerated path")
         for r in list(rx) + list(ry):
             if not isinstance(r, Regularizer) or r.kind < 0:
                 raise NotImplementedError(f"{type(r).__name__} is outside the accelerated path")

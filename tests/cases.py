@@ -67,7 +67,131 @@ def case_kmeans(rng):
                 X=rng.standard_normal((k, m)), Y=rng.standard_normal((k, n))), L.ProxGradParams(max_iter=15, inner_iter=10)
 
 
-GOLDEN_CASES = {"c1": (case_c1, 11), "nnmf": (case_nnmf, 12), "mixed": (case_mixed, 13), "kmeans": (case_kmeans, 14)}
+def _levels(z, lo, hi):
+    return np.clip(np.round((lo + hi) / 2 + z), lo, hi)
+
+
+def _observe(rng, m, n, density):
+    mask = rng.random((m, n)) < density
+    return [list(map(int, np.flatnonzero(mask[i]))) for i in range(m)], [list(map(int, np.flatnonzero(mask[:, j]))) for j in range(n)]
+
+
+def case_loss_test(rng):
+    """The model of the reference's test/loss_test.jl:6-69 -- every loss constructor in one GLRM, k = 5, QuadReg(1) on X,
+    OrdinalReg(QuadReg(1)) on the multi-dimensional ordinal columns and QuadReg(1) elsewhere, scale=false, offset=false --
+    at m = 80 (the reference uses 1000) with 85 % of the entries observed."""
+    losses = [L.QuadLoss(), L.QuadLoss(10), L.L1Loss(), L.L1Loss(5.2), L.HuberLoss(), L.HuberLoss(4), L.HuberLoss(3.1, crossover=3.2),
+              L.PeriodicLoss(2 * np.pi), L.PeriodicLoss(2 * np.pi, 4), L.PoissonLoss(20), L.PoissonLoss(22), L.OrdinalHingeLoss(1, 10),
+              L.OrdinalHingeLoss(2, 7, 5), L.LogisticLoss(), L.LogisticLoss(0.2), L.WeightedHingeLoss(), L.WeightedHingeLoss(11),
+              L.WeightedHingeLoss(1.5, case_weight_ratio=4.3), L.MultinomialLoss(4), L.MultinomialLoss(6, .5), L.MultinomialOrdinalLoss(3)]
+    m, n, k = 80, len(losses), 5
+    D = L.embedding_dim(losses)
+    XY = (rng.standard_normal((m, k)) @ rng.standard_normal((k, D)))
+    A = np.zeros((m, n))
+    for f, (lo, (y0, y1)) in enumerate(zip(losses, L.get_yidxs(losses))):
+        z = XY[:, y0]
+        if isinstance(lo, L.MultinomialLoss):
+            A[:, f] = 1 + np.argmax(XY[:, y0:y1], axis=1)
+        elif isinstance(lo, L.MultinomialOrdinalLoss):
+            A[:, f] = _levels(z, 1, lo.max)
+        elif isinstance(lo, L.OrdinalHingeLoss):
+            A[:, f] = _levels(z, lo.min, lo.max)
+        elif isinstance(lo, L.PoissonLoss):
+            A[:, f] = np.minimum(np.round(np.exp(z / 3)), 20)
+        elif isinstance(lo, L.PeriodicLoss):
+            A[:, f] = np.mod(z, lo.T)
+        elif lo.classification:
+            A[:, f] = z > 0
+        else:
+            A[:, f] = z
+    ry = [L.OrdinalReg(L.QuadReg(1)) if isinstance(lo, (L.MultinomialOrdinalLoss, L.OrdisticLoss)) else L.QuadReg(1) for lo in losses]
+    feats, exs = _observe(rng, m, n, 0.85)
+    return dict(A=A, losses=losses, rx=L.QuadReg(1), ry=ry, k=k, observed_features=feats, observed_examples=exs,
+                X=rng.standard_normal((k, m)), Y=rng.standard_normal((k, D))), L.ProxGradParams(max_iter=30)
+
+
+def case_mnl(rng):
+    """test/prob_tests/MultinomialLoss.jl:9-41 at m, n = 60, 12: n categorical columns with K = 4 levels sampled from the
+    multinomial logit of a rank-2 model, fitted with rank 3 and QuadReg() on both factors, fully observed."""
+    m, n, k, K = 60, 12, 3, 4
+    XY = rng.standard_normal((m, 2)) @ rng.standard_normal((2, n * K))
+    A = np.zeros((m, n))
+    for j in range(n):
+        u = XY[:, j * K:(j + 1) * K]
+        w = np.exp(-(u - u.mean(axis=1, keepdims=True)))
+        w /= w.sum(axis=1, keepdims=True)
+        A[:, j] = 1 + (rng.random((m, 1)) > np.cumsum(w, axis=1)).sum(axis=1).clip(0, K - 1)
+    return dict(A=A, losses=[L.MultinomialLoss(K) for _ in range(n)], rx=L.QuadReg(), ry=L.QuadReg(), k=k,
+                X=rng.standard_normal((k, m)), Y=rng.standard_normal((k, n * K))), L.ProxGradParams(max_iter=40)
+
+
+def case_mnl_ordinal(rng):
+    """test/prob_tests/MultinomialOrdinalLoss.jl:9-58 at m, n = 50, 14: ordinal columns with 5 levels, rank 3 fit with
+    lastentry1(QuadReg(.01)) on X and MNLOrdinalReg(QuadReg(.01)) on Y, and Y started from prox!(ry, Y_block, 1)."""
+    m, n, k, nlevels = 50, 14, 3, 5
+    d = nlevels - 1
+    z = rng.standard_normal((m, 2)) @ rng.standard_normal((2, n))
+    A = _levels(1.2 * z, 1, nlevels)
+    ry = L.MNLOrdinalReg(L.QuadReg(.01))
+    Y = rng.standard_normal((k, n * d))
+    for j in range(n):
+        Y[:, j * d:(j + 1) * d] = ry.prox(Y[:, j * d:(j + 1) * d], 1)
+    return dict(A=A, losses=[L.MultinomialOrdinalLoss(nlevels) for _ in range(n)], rx=L.lastentry1(L.QuadReg(.01)), ry=ry, k=k,
+                X=rng.standard_normal((k, m)), Y=Y), L.ProxGradParams(max_iter=40)
+
+
+def case_categorical_mix(rng):
+    """Multinomial / OvA (logistic and hinge bin_loss) / BvS next to scalar columns, partially observed."""
+    losses = [L.MultinomialLoss(4), L.QuadLoss(), L.OvALoss(3, bin_loss=L.LogisticLoss()), L.BvSLoss(5),
+              L.OvALoss(4, bin_loss=L.HingeLoss()), L.LogisticLoss(), L.BvSLoss(3, bin_loss=L.HingeLoss()), L.MultinomialLoss(3, 0.7)]
+    m, k = 28, 3
+    return _multidim_data(rng, m, k, losses, L.QuadReg(0.1), L.QuadReg(0.2), L.ProxGradParams(max_iter=12))
+
+
+def case_ordinal_offsets(rng):
+    """The reference's ordinal recipe: lastentry1 on X, OrdinalReg / MNLOrdinalReg / lastentry_unpenalized on Y's blocks."""
+    losses = [L.OrdisticLoss(4), L.MultinomialOrdinalLoss(5), L.QuadLoss(), L.BvSLoss(4), L.MultinomialOrdinalLoss(3)]
+    ry = [L.lastentry_unpenalized(L.QuadReg(0.1)), L.MNLOrdinalReg(L.QuadReg(0.1)), L.lastentry_unpenalized(L.QuadReg(0.3)),
+          L.OrdinalReg(L.QuadReg(0.1)), L.MNLOrdinalReg(L.ZeroReg())]
+    return _multidim_data(rng, 28, 3, losses, L.lastentry1(L.QuadReg(0.1)), ry, L.ProxGradParams(max_iter=12))
+
+
+def case_offsets_scalar(rng):
+    """add_offset! on a scalar-loss model (src/modify_glrm.jl:20-25), inner_iter = 2."""
+    losses = [L.QuadLoss(), L.HuberLoss(), L.LogisticLoss(), L.QuadLoss(0.5), L.L1Loss()]
+    return _multidim_data(rng, 28, 3, losses, L.lastentry1(L.OneReg(0.05)), L.lastentry_unpenalized(L.QuadReg(0.2)),
+                          L.ProxGradParams(max_iter=14, inner_iter=2))
+
+
+def _multidim_data(rng, m, k, losses, rx, ry, params):
+    n = len(losses)
+    Z = rng.standard_normal((m, k))
+    A = np.zeros((m, n))
+    for f, lo in enumerate(losses):
+        z = Z @ rng.standard_normal(k)
+        if hasattr(lo, "max"):
+            A[:, f] = _levels(z, 1, lo.max)
+        elif lo.classification:
+            A[:, f] = z > 0
+        else:
+            A[:, f] = z
+    feats, exs = _observe(rng, m, n, 0.8)
+    return dict(A=A, losses=losses, rx=rx, ry=ry, k=k, observed_features=feats, observed_examples=exs,
+                X=rng.standard_normal((k, m)), Y=rng.standard_normal((k, L.embedding_dim(losses)))), params
+
+
+MULTIDIM_CASES = {"categorical_mix": (case_categorical_mix, 21), "ordinal_offsets": (case_ordinal_offsets, 22),
+                  "offsets_scalar": (case_offsets_scalar, 23), "mnl": (case_mnl, 24), "mnl_ordinal": (case_mnl_ordinal, 25),
+                  "loss_test": (case_loss_test, 26)}
+
+
+def build_multidim_case(name):
+    fn, seed = MULTIDIM_CASES[name]
+    return fn(np.random.default_rng(seed))
+
+
+GOLDEN_CASES = {"c1": (case_c1, 11), "nnmf": (case_nnmf, 12), "mixed": (case_mixed, 13), "kmeans": (case_kmeans, 14),
+                "mnl_ordinal": (case_mnl_ordinal, 25), "loss_test": (case_loss_test, 26)}
 
 
 def build_golden_case(name):

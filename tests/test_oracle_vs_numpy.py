@@ -258,49 +258,22 @@ def numpy_proxgrad_general(A, losses, rx, ry, feats, exs, X, Y, p):
     return X, Y, ch, alpharow, alphacol
 
 
-def multidim_model(name, rng):
-    m, k = 28, 3
-    Z = rng.standard_normal((m, k))
-    if name == "multinomial_ova_bvs":
-        losses = [L.MultinomialLoss(4), L.QuadLoss(), L.OvALoss(3, bin_loss=L.LogisticLoss()), L.BvSLoss(5),
-                  L.OvALoss(4, bin_loss=L.HingeLoss()), L.LogisticLoss(), L.BvSLoss(3, bin_loss=L.HingeLoss()), L.MultinomialLoss(3, 0.7)]
-        rx, ry = [L.QuadReg(0.1)] * m, [L.QuadReg(0.2)] * len(losses)
-        p = L.ProxGradParams(max_iter=12)
-    elif name == "ordinal_with_offsets":
-        # the reference's ordinal recipe: lastentry1 on X, OrdinalReg / MNLOrdinalReg on the ordinal columns of Y
-        losses = [L.OrdisticLoss(4), L.MultinomialOrdinalLoss(5), L.QuadLoss(), L.BvSLoss(4), L.MultinomialOrdinalLoss(3)]
-        rx = [L.lastentry1(L.QuadReg(0.1))] * m
-        ry = [L.lastentry_unpenalized(L.QuadReg(0.1)), L.MNLOrdinalReg(L.QuadReg(0.1)), L.lastentry_unpenalized(L.QuadReg(0.3)),
-              L.OrdinalReg(L.QuadReg(0.1)), L.MNLOrdinalReg(L.ZeroReg())]
-        p = L.ProxGradParams(max_iter=12)
-    else:  # offsets_scalar: add_offset! on a scalar-loss model (src/modify_glrm.jl:20-25)
-        losses = [L.QuadLoss(), L.HuberLoss(), L.LogisticLoss(), L.QuadLoss(0.5), L.L1Loss()]
-        rx = [L.lastentry1(L.OneReg(0.05))] * m
-        ry = [L.lastentry_unpenalized(L.QuadReg(0.2))] * len(losses)
-        p = L.ProxGradParams(max_iter=14, inner_iter=2)
-    n = len(losses)
-    A = np.zeros((m, n))
-    for f, lo in enumerate(losses):
-        z = Z @ rng.standard_normal(k)
-        if hasattr(lo, "max"):
-            A[:, f] = np.clip(np.round((lo.max + 1) / 2 + z), 1, lo.max)
-        elif lo.classification:
-            A[:, f] = z > 0
-        else:
-            A[:, f] = z
-    mask = rng.random((m, n)) < 0.8
-    feats = [list(np.flatnonzero(mask[i])) for i in range(m)]
-    exs = [list(np.flatnonzero(mask[:, j])) for j in range(n)]
-    D = L.embedding_dim(losses)
-    return A, losses, rx, ry, feats, exs, rng.standard_normal((k, m)), rng.standard_normal((k, D)), p, k
+def expand(kwargs):
+    """GLRM constructor arguments -> per-column / per-row Python objects and the two observation views."""
+    g = L.GLRM(**kwargs)
+    feats = [list(g._colidx[g._rowptr[i]:g._rowptr[i + 1]]) for i in range(g.m)]
+    exs = [list(g._rowidx[g._colptr[j]:g._colptr[j + 1]]) for j in range(g.n)]
+    return g, np.asarray(kwargs["A"], dtype=float), g.losses, g.rx, g.ry, feats, exs
 
 
-@pytest.mark.parametrize("name", ["multinomial_ova_bvs", "ordinal_with_offsets", "offsets_scalar"])
+@pytest.mark.parametrize("name", list(cases.MULTIDIM_CASES))
 def test_c_oracle_multidim_agrees_with_numpy_transcription(name):
-    rng = np.random.default_rng({"multinomial_ova_bvs": 11, "ordinal_with_offsets": 12, "offsets_scalar": 13}[name])
-    A, losses, rx, ry, feats, exs, X0, Y0, p, k = multidim_model(name, rng)
+    kwargs, p = cases.build_multidim_case(name)
+    if name in ("mnl", "mnl_ordinal", "loss_test"):
+        p = L.ProxGradParams(max_iter=8)  # the pure-Python loops are slow; the early iterations carry the line search
+    g, A, losses, rx, ry, feats, exs = expand(kwargs)
+    X0, Y0 = kwargs["X"], kwargs["Y"]
     Xn, Yn, chn, ar, ac = numpy_proxgrad_general(A, losses, rx, ry, feats, exs, X0, Y0, p)
-    g = L.GLRM(A, losses, rx, ry, k, observed_features=feats, observed_examples=exs, X=X0, Y=Y0)
     api, lib = O.oracle_api(), O.oracle_lib()
     O.set_threads(1)
     h = api.create(g.problem_arrays())
