@@ -51,6 +51,8 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
   a.alpha = rows ? h->alpharow : h->alphacol;
   a.obj = rows ? nullptr : h->objcol;
   a.k = h->k; a.kp = h->kp; a.dmax = h->dmax;
+  a.lgP = 2;
+  while ((1 << a.lgP) < h->k || (1 << a.lgP) < h->dmax) ++a.lgP;
   a.mode = eval_only ? 1 : (h->fixed_alpha > 0.0 ? 2 : 0);
   a.fixed_alpha = h->fixed_alpha;
   a.min_stepsize = min_stepsize;
@@ -66,10 +68,10 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
   }
   if (a.nseg <= 0) return GLRM_OK;
   if (rows) {
-    const size_t lds = multi_lds_doubles(true, 1, h->kp, h->dmax) * 8;
+    const size_t lds = multi_lds_doubles(true, 1, h->kp, h->dmax, a.lgP) * 8;
     hipLaunchKernelGGL((multi_sweep_kernel<true, 1>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
   } else {
-    const size_t lds = multi_lds_doubles(false, 8, h->kp, h->dmax) * 8;
+    const size_t lds = multi_lds_doubles(false, 8, h->kp, h->dmax, a.lgP) * 8;
     hipLaunchKernelGGL((multi_sweep_kernel<false, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
   }
   HIPCK(hipGetLastError());

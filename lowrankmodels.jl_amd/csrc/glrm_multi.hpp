@@ -36,6 +36,7 @@ struct MultiArgs {
   double* alpha;         // local
   double* obj;           // columns: objcol (global column index); rows: nullptr
   int k, kp, dmax;
+  int lgP;               // log2 of the lanes per observation slot: 2^lgP >= max(k, dmax, 4)
   int mode;              // 0 = line-search step, 1 = losses only (columns), 2 = fixed step (SparseProxGradParams)
   double fixed_alpha, min_stepsize;
   int32_t* trials;
@@ -293,88 +294,239 @@ __device__ inline void block_prox(double* blk, int S, int k, int DO, const glrm_
   __syncthreads();
 }
 
+// ---------------------------------------------------------------- slot reductions
+// All-reduce over the P = 2^lg consecutive lanes of an observation slot (P >= 4).  DPP inside a 16-lane row, ds_bpermute
+// across rows.  Every lane of the slot gets the same value; a slot is always entirely active or entirely inactive.
+struct OpSum { __device__ __forceinline__ double operator()(double a, double b) const { return a + b; } };
+struct OpMax { __device__ __forceinline__ double operator()(double a, double b) const { return a > b ? a : b; } };
+
+template <class Op>
+__device__ __forceinline__ double slot_reduce(double v, int lg, Op op) {
+  v = op(v, dpp_f64<DPP_XOR1>(v));
+  v = op(v, dpp_f64<DPP_XOR2>(v));
+  if (lg >= 3) v = op(v, dpp_f64<DPP_HALF_MIRROR>(v));
+  if (lg >= 4) v = op(v, dpp_f64<DPP_MIRROR>(v));
+  if (lg >= 5) v = op(v, __shfl_xor(v, 16, 64));
+  if (lg >= 6) v = op(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+// Lane-parallel evaluate / grad of one observation per slot.  Called by ALL lanes of the wave in uniform control flow (every
+// cross-lane operation below executes with the full wave; slots differ only in data): dd = embedding dimension of the slot's
+// observation (0 = idle slot), lane `sub` holds u_sub (sub < dd), u0 = u_0 in every lane (scalar losses).  Returns the loss
+// (uniform over the slot) and leaves component `sub` of the gradient in cg.  Same formulas as src/losses.jl:377-406,424-446,
+// 461-483,499-519,581-609 with the inner sums over the categories done as slot reductions:
+//   Multinomial: sumexp_j of the reference is sum_j' exp(u_j' - max u) for every j, and exp(-M_j) = exp(u_j - max u);
+//   Ordistic:    the same with v_j = -u_j^2;
+//   MultinomialOrdinal: enforce_MNLOrdRules (:572-578) in closed form, u'_j = min(u_0, u_1 + TOL, ..., u_j + j TOL, -TOL) - j TOL.
+template <bool GRAD>
+__device__ inline double obs_loss(const LossDesc& l, double u, double u0, double av, int dd, int sub, int lg, int slot_lane0, double* us,
+                                  double& cg) {
+  const double s = l.scale;
+  const int kind = l.kind, P = 1 << lg;
+  const bool in = sub < dd, vec = dd > 1;
+  const int a = (int)av - 1;                           // level - 1: 0 .. dd (BvS / MultinomialOrdinal have dd + 1 levels)
+  const int ash = a < 0 ? 0 : (a > P - 1 ? P - 1 : a); // in-range lane for the shuffles (idle / scalar slots too)
+  // stage 1: slot maximum
+  double mv = -__builtin_inf();
+  if (in && vec && kind == GLRM_LOSS_MULTINOMIAL) mv = u;
+  if (in && vec && kind == GLRM_LOSS_ORDISTIC) mv = -(u * u);
+  const double mx = slot_reduce(mv, lg, OpMax());
+  // stage 2: per-lane term, slot sum
+  double term = 0.0, dLb = 0.0;
+  if (in && vec) {
+    if (kind == GLRM_LOSS_MULTINOMIAL) term = exp(u - mx);
+    else if (kind == GLRM_LOSS_ORDISTIC) term = exp(-(u * u) - mx);
+    else if (kind == GLRM_LOSS_OVA || kind == GLRM_LOSS_BVS) {
+      const bool truth = kind == GLRM_LOSS_OVA ? a == sub : a > sub;
+      loss_both<GRAD>(bin_loss_of(l), u, truth ? 1.0 : 0.0, term, dLb);
+    }
+  }
+  const double se = slot_reduce(term, lg, OpSum());
+  const double ua = __shfl(u, slot_lane0 + ash, 64);
+  // MultinomialOrdinal: thresholds through LDS
+  const bool ord = vec && kind == GLRM_LOSS_MULTINOMIAL_ORDINAL;
+  double e_hi = 0.0, e_lo = 0.0, u_hi = 0.0;
+  if (__any(ord)) {
+    const double TOL = 1e-3;
+    if (ord && in) us[sub] = u;
+    wave_sync();
+    double w = -TOL;
+    if (ord && in) for (int i = 0; i <= sub; ++i) { const double wi = us[i] + i * TOL; w = wi < w ? wi : w; }
+    const double up = w - sub * TOL;
+    const double ea = ord ? exp(up) : 0.0;
+    int hi = a > 0 ? a - 1 : 0, lo = a < dd ? a : dd - 1; // lanes of u'_{a-1}, u'_a
+    hi = hi < 0 ? 0 : (hi > P - 1 ? P - 1 : hi);
+    lo = lo < 0 ? 0 : (lo > P - 1 ? P - 1 : lo);
+    e_hi = __shfl(ea, slot_lane0 + hi, 64); // exp(u'_{a-1})
+    e_lo = __shfl(ea, slot_lane0 + lo, 64); // exp(u'_a)
+    u_hi = __shfl(up, slot_lane0 + hi, 64);
+    wave_sync();
+  }
+  // stage 3: per-kind closing formulas (lane-local)
+  cg = 0.0;
+  double L = 0.0;
+  if (dd == 1) {
+    loss_both<GRAD>(l, u0, av, L, cg);
+  } else if (vec) {
+    switch (kind) {
+      case GLRM_LOSS_MULTINOMIAL:
+        L = s * (log(se) + (mx - ua));
+        if (GRAD && in) cg = s * ((sub == a ? -1.0 : 0.0) + term / se);
+        break;
+      case GLRM_LOSS_OVA:
+      case GLRM_LOSS_BVS:
+        L = s * se;
+        if (GRAD && in) cg = s * dLb;
+        break;
+      case GLRM_LOSS_ORDISTIC:
+        L = s * ((ua * ua + mx) + log(se));
+        if (GRAD && in) cg = s * ((sub == a ? 2 * u : 0.0) - 2 * u * term / se);
+        break;
+      default: { // GLRM_LOSS_MULTINOMIAL_ORDINAL
+        double g = 0.0;
+        if (a == 0) {
+          L = -s * log(1.0 - e_lo);
+          if (sub == 0) g = -e_lo / (1.0 - e_lo);
+        } else if (a == dd) {
+          L = -s * u_hi;
+          if (sub == a - 1) g = 1.0;
+        } else {
+          const double den = e_hi - e_lo;
+          L = -s * log(den);
+          if (sub == a) g = -e_lo / den;
+          else if (sub == a - 1) g = e_hi / den;
+        }
+        if (GRAD && in) cg = -s * g;
+      }
+    }
+  }
+  return L;
+}
+
 // ---------------------------------------------------------------- one pass over the segment's observations
 // Returns the loss sum at the block `own` (workgroup-uniform); GRAD additionally leaves the gradient in Gt.
+//
+// A wave works on SL = 64/P observations at a time ("slots" of P = 2^lgP lanes, P >= max(k, dmax, 4)).  Lane `sub` of a
+// slot holds component `sub` of the own / opposing vector: u_j = <x, y_j> is a slot reduction of the products (u_j ends
+// up in lane j), the loss and its d-vector gradient are evaluated lane-parallel (vloss_lanes), and lane `sub` accumulates
+// component `sub` of the gradient.  Index / value loads run two wave-iterations ahead and (columns) the opposing row
+// one iteration ahead.  Slot partials are combined in slot order, wave partials in wave order.
 template <bool ROWS, int NW, bool GRAD>
-__device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, const double* own, double* oth, double* us, double* cgs,
-                                    double* Gt, double* red, const LossDesc& lseg, int dseg) {
+__device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, const double* own, double* wbase, double* Gt, double* red,
+                                    const LossDesc& lseg, int dseg) {
   constexpr int NT = NW * 64, GD = ROWS ? 1 : GLRM_MAX_EMBEDDING_DIM;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lg = a.lgP, P = 1 << lg, SL = 64 >> lg, slot = lane >> lg, sub = lane & (P - 1);
   const int S = a.kp + 1, k = a.k, kp = a.kp;
   const int DO = ROWS ? 1 : dseg;
+  const int dtcap = ROWS ? a.dmax : 1;
+  double* oth = wbase + (size_t)slot * (dtcap * S + 64);
+  double* us = oth + dtcap * S;
+  double* cgs = us + 32;
+  const bool comp = sub < k;
+  const double xown = (ROWS && comp) ? own[sub] : 0.0;
   double lsum = 0.0;
   double G[GD];
 #pragma unroll
   for (int j = 0; j < GD; ++j) G[j] = 0.0;
-  for (int64_t t = b + wave; t < e; t += NW) {
-    const int32_t id = a.idx[t];
-    const double av = a.vals[t];
+  const int64_t stride = (int64_t)NW * SL;
+  int64_t t = b + (int64_t)wave * SL + slot;
+  int32_t id_n = 0, id_nn = 0;
+  double av_n = 0.0, av_nn = 0.0, xr = 0.0;
+  if (e > b) { // clamped, unconditional loads: the waits stay counted
+    const int64_t t1 = t < e ? t : e - 1, t2 = t + stride < e ? t + stride : e - 1;
+    id_n = a.idx[t1]; av_n = a.vals[t1];
+    id_nn = a.idx[t2]; av_nn = a.vals[t2];
+    if constexpr (!ROWS) xr = a.other[(int64_t)id_n * kp + (comp ? sub : 0)];
+  }
+  for (int64_t t0 = b + (int64_t)wave * SL; t0 < e; t0 += stride) { // wave-uniform trip count
+    const bool valid = t < e;
+    const int32_t id = id_n;
+    const double av = av_n;
+    const double xc = ROWS ? xown : (comp ? xr : 0.0);
+    id_n = id_nn; av_n = av_nn;
+    {
+      const int64_t t3 = t + 2 * stride < e ? t + 2 * stride : e - 1;
+      id_nn = a.idx[t3]; av_nn = a.vals[t3];
+    }
     LossDesc l = lseg;
     int d = dseg;
     if constexpr (ROWS) {
       const int64_t li = a.loss_single ? 0 : id;
       l = load_loss(a.losses, li);
       d = a.losses[li].dim > 1 ? a.losses[li].dim : 1;
-      const double* Yb = a.other + a.ystart[id] * kp; // the d vectors of column id are contiguous
-      for (int i = lane; i < d * kp; i += 64) { const int j = i / kp, c = i - j * kp; oth[j * S + c] = Yb[i]; }
-    } else {
-      if (lane < kp) oth[lane] = a.other[(int64_t)id * kp + lane];
-    }
-    wave_sync();
-    if (lane < d) { // u_j = <x, y_j>, sequential over the components
-      const double* p = ROWS ? own : own + lane * S;
-      const double* q = ROWS ? oth + lane * S : oth;
-      double u = 0.0;
-      for (int c = 0; c < k; ++c) u = fma(p[c], q[c], u);
-      us[lane] = u;
-    }
-    wave_sync();
-    if (l.kind == GLRM_LOSS_MULTINOMIAL_ORDINAL) {
-      if (lane == 0) enforce_mnl_ord_rules(us, d);
+      if (valid) {
+        const double* Yb = a.other + a.ystart[id] * kp; // the d vectors of column id are contiguous
+        for (int i = sub; i < d * kp; i += P) { const int j = i / kp, c = i - j * kp; oth[j * S + c] = Yb[i]; }
+      }
       wave_sync();
+    } else {
+      xr = a.other[(int64_t)id_n * kp + (comp ? sub : 0)]; // next observation's row
     }
-    const int ai = (int)av - 1;
-    double L, dL = 0.0;
-    if (d == 1) loss_both<GRAD>(l, us[0], av, L, dL);
-    else L = vloss_eval(l, us, d, ai);
+    const double* blk = ROWS ? oth : own; // the d vectors this observation meets
+    const int dd = valid ? d : 0;
+    // u_j = <x, y_j>: one slot reduction per j, uniform trip count (the largest d among the wave's slots)
+    double u = 0.0, u0 = 0.0;
+    for (int j = 0; __any(j < dd); ++j) {
+      const double r = slot_reduce((comp && j < dd) ? xc * blk[j * S + sub] : 0.0, lg, OpSum());
+      u = (sub == j && j < dd) ? r : u;
+      u0 = j == 0 ? r : u0;
+    }
+    double cg = 0.0;
+    const double L = obs_loss<GRAD>(l, u, u0, av, dd, sub, lg, lane - sub, us, cg);
     lsum += L;
     if constexpr (GRAD) {
-      if (d > 1) {
-        if (lane < d) cgs[lane] = vloss_grad(l, us, d, ai, lane);
+      const bool vec = valid && d > 1;
+      if (__any(vec)) {
+        if (vec && sub < d) cgs[sub] = cg;
         wave_sync();
       }
-      if (lane < k) {
+      if (valid && comp) {
         if constexpr (ROWS) { // g += Y_f * curgrad
           double g = G[0];
-          if (d == 1) g = fma(dL, oth[lane], g);
-          else for (int j = 0; j < d; ++j) g = fma(cgs[j], oth[j * S + lane], g);
+          if (d == 1) g = fma(cg, oth[sub], g);
+          else for (int j = 0; j < d; ++j) g = fma(cgs[j], oth[j * S + sub], g);
           G[0] = g;
         } else {              // G += x * curgrad'
-          const double xc = oth[lane];
-          if (d == 1) G[0] = fma(dL, xc, G[0]);
+          if (d == 1) G[0] = fma(cg, xc, G[0]);
           else {
 #pragma unroll
             for (int j = 0; j < GD; ++j) if (j < d) G[j] = fma(cgs[j], xc, G[j]);
           }
         }
       }
+      wave_sync();
+    } else if constexpr (ROWS) {
+      wave_sync(); // oth is overwritten by the next staging
     }
-    wave_sync();
+    t += stride;
   }
-  double total = lsum;
+  // slot partials -> wave partial (slot order); lsum is uniform inside a slot
+  double wsum = 0.0;
+  for (int sidx = 0; sidx < SL; ++sidx) wsum += __shfl(lsum, sidx << lg, 64);
+  double total = wsum;
   if constexpr (NW > 1) {
     __syncthreads();
-    if (lane == 0) red[wave] = lsum;
+    if (lane == 0) red[wave] = wsum;
     __syncthreads();
     total = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) total += red[w];
   }
   if constexpr (GRAD) {
+#pragma unroll
+    for (int j = 0; j < GD; ++j) {
+      if (j < DO) { // uniform
+        double acc = 0.0;
+        for (int sidx = 0; sidx < SL; ++sidx) acc += __shfl(G[j], (sidx << lg) + sub, 64);
+        G[j] = acc;
+      }
+    }
     for (int i = tid; i < DO * S; i += NT) Gt[i] = 0.0;
     __syncthreads();
     for (int w = 0; w < NW; ++w) {
-      if (wave == w && lane < k) {
+      if (wave == w && lane < k) { // lane < k <= P: slot 0
 #pragma unroll
         for (int j = 0; j < GD; ++j) if (j < DO) Gt[j * S + lane] += G[j];
       }
@@ -384,10 +536,10 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
   return total;
 }
 
-// LDS carve-up (doubles): ownA | ownB | Gt (DOcap*S each) | tmp[64] | red[16] | per wave: oth[DTcap*S] us[32] cgs[32]
-__host__ __device__ inline size_t multi_lds_doubles(bool rows, int nw, int kp, int dmax) {
-  const size_t S = kp + 1, docap = rows ? 1 : dmax, dtcap = rows ? dmax : 1;
-  return 3 * docap * S + 64 + 16 + (size_t)nw * (dtcap * S + 64);
+// LDS carve-up (doubles): ownA | ownB | Gt (DOcap*S each) | tmp[64] | red[16] | per wave and slot: oth[DTcap*S] us[32] cgs[32]
+__host__ __device__ inline size_t multi_lds_doubles(bool rows, int nw, int kp, int dmax, int lgP) {
+  const size_t S = kp + 1, docap = rows ? 1 : dmax, dtcap = rows ? dmax : 1, sl = 64 >> lgP;
+  return 3 * docap * S + 64 + 16 + (size_t)nw * sl * (dtcap * S + 64);
 }
 
 template <bool ROWS, int NW>
@@ -402,9 +554,7 @@ __global__ void __launch_bounds__(NW * 64) multi_sweep_kernel(const MultiArgs a)
   double* Gt = ownB + docap * S;
   double* tmp = Gt + docap * S;
   double* red = tmp + 64;
-  double* oth = red + 16 + (size_t)wave * (dtcap * S + 64);
-  double* us = oth + dtcap * S;
-  double* cgs = us + 32;
+  double* wbase = red + 16 + (size_t)wave * (64 >> a.lgP) * (dtcap * S + 64); // this wave's slots
 
   const int64_t s = blockIdx.x, gseg = a.own_offset + s;
   const int64_t b = a.ptr[s], e = a.ptr[s + 1];
@@ -424,11 +574,11 @@ __global__ void __launch_bounds__(NW * 64) multi_sweep_kernel(const MultiArgs a)
   const glrm_reg rg = a.regs[a.reg_single ? 0 : s];
 
   if (a.mode == 1) { // losses only
-    const double tot = multi_pass<ROWS, NW, false>(a, b, e, ownA, oth, us, cgs, Gt, red, lseg, dseg);
+    const double tot = multi_pass<ROWS, NW, false>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
     if (tid == 0 && a.obj) a.obj[gseg] = tot;
     return;
   }
-  const double loss_old = multi_pass<ROWS, NW, true>(a, b, e, ownA, oth, us, cgs, Gt, red, lseg, dseg);
+  const double loss_old = multi_pass<ROWS, NW, true>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
   const double l1 = (double)(e - b) + 1;
   if (a.mode == 2) { // sparse_proxgrad.jl:72-78 / :94-99: scale the gradient, add, prox -- no line search
     const double st = a.fixed_alpha / l1;
@@ -452,7 +602,7 @@ __global__ void __launch_bounds__(NW * 64) multi_sweep_kernel(const MultiArgs a)
     }
     __syncthreads();
     block_prox<NW>(ownB, S, k, DO, rg, stepsize, tmp);
-    const double nloss = multi_pass<ROWS, NW, false>(a, b, e, ownB, oth, us, cgs, Gt, red, lseg, dseg);
+    const double nloss = multi_pass<ROWS, NW, false>(a, b, e, ownB, wbase, Gt, red, lseg, dseg);
     const double nobj = nloss + block_reg_eval<NW>(ownB, S, k, DO, rg, red);
     ++ntr;
     if (nobj < obj) {
