@@ -57,6 +57,12 @@ struct glrm_handle {
   int64_t d = 0;                      // vectors of Y = sum of embedding dimensions (= n for scalar losses)
   int dmax = 1;
   int64_t* ystart = nullptr;          // device, n+1
+  int64_t ys_cb = 0;                  // ystart[cb]: first vector of the shard's column block
+  int col_nsplit = 1;                 // > 1: the Y half-step runs as split passes + decide rounds
+  int64_t col_chunk = 0;
+  double *mtrial = nullptr, *mpart_loss = nullptr, *mpart_G = nullptr, *mgtot = nullptr, *mobjold = nullptr;
+  int32_t* mactive = nullptr;
+  unsigned int* mnactive = nullptr;
   // dense MFMA path (glrm_dense.hip)
   bool dense = false;
   double *Arow = nullptr, *Acol = nullptr; // packed, zero padded: [ml_pad][lda_r], [nl_pad][lda_c]

@@ -31,6 +31,73 @@ int glrm_setup_multi(glrm_handle* h, const glrm_problem* p) {
   HIPCK(hipMalloc((void**)&h->ystart, ((size_t)p->n + 1) * 8));
   HIPCK(hipMemcpyAsync(h->ystart, ys.data(), ((size_t)p->n + 1) * 8, hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream)); // ys is a local
+  h->ys_cb = ys[p->col_begin];
+  return GLRM_OK;
+}
+
+// A column longer than one chunk (8192 observations; GLRM_HIP_MULTI_CHUNK overrides, 0 = never) is swept by several
+// workgroups.  The rule looks at single columns only and the chunk is a constant, so results do not depend on the sharding.
+static int setup_split(glrm_handle* h) {
+  if (h->mtrial || h->col_nsplit < 0) return GLRM_OK;
+  const int64_t chunk = env_int("GLRM_HIP_MULTI_CHUNK", 8192);
+  std::vector<int64_t> cp((size_t)h->nl + 1);
+  HIPCK(hipMemcpy(cp.data(), h->colptr, ((size_t)h->nl + 1) * 8, hipMemcpyDeviceToHost));
+  int64_t longest = 0;
+  for (int64_t f = 0; f < h->nl; ++f) longest = cp[f + 1] - cp[f] > longest ? cp[f + 1] - cp[f] : longest;
+  const size_t blk = (size_t)h->dmax * h->kp;
+  const int64_t nsplit = chunk > 0 ? (longest + chunk - 1) / chunk : 1;
+  if (nsplit <= 1 || nsplit > 65535 || (size_t)h->nl * nsplit * blk * 8 > ((size_t)2 << 30)) { h->col_nsplit = -1; return GLRM_OK; }
+  h->col_chunk = chunk;
+  h->col_nsplit = (int)nsplit;
+  HIPCK(hipMalloc((void**)&h->mtrial, (size_t)h->d * h->kp * 8));
+  HIPCK(hipMalloc((void**)&h->mpart_loss, (size_t)h->nl * nsplit * 8));
+  HIPCK(hipMalloc((void**)&h->mpart_G, (size_t)h->nl * nsplit * blk * 8));
+  HIPCK(hipMalloc((void**)&h->mgtot, (size_t)h->nl * blk * 8));
+  HIPCK(hipMalloc((void**)&h->mobjold, (size_t)h->nl * 8));
+  HIPCK(hipMalloc((void**)&h->mactive, (size_t)h->nl * 4));
+  HIPCK(hipMalloc((void**)&h->mnactive, 4));
+  return GLRM_OK;
+}
+
+static int run_split_cols(glrm_handle* h, const MultiArgs& a) {
+  SplitArgs sa{};
+  sa.m = a;
+  sa.nsplit = h->col_nsplit;
+  sa.chunk = h->col_chunk;
+  sa.trial = h->mtrial;
+  sa.part_loss = h->mpart_loss; sa.part_G = h->mpart_G; sa.gtot = h->mgtot; sa.objold = h->mobjold;
+  sa.active = h->mactive; sa.nactive = h->mnactive;
+  const int S = h->kp + 1, sl = 64 >> a.lgP;
+  const size_t lds_pass = ((size_t)2 * h->dmax * S + 16 + (size_t)8 * sl * (S + 64)) * 8;
+  const size_t lds_dec = ((size_t)2 * h->dmax * S + 64 + 16) * 8;
+  const dim3 grid((unsigned)a.nseg, (unsigned)sa.nsplit);
+  hipStream_t st = h->stream;
+  sa.point = a.own;
+  if (a.mode == 1) { // losses only
+    sa.round = -1;
+    hipLaunchKernelGGL((multi_colpass_kernel<false>), grid, dim3(512), lds_pass, st, sa);
+    hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
+    HIPCK(hipGetLastError());
+    return GLRM_OK;
+  }
+  sa.round = 0;
+  HIPCK(hipMemsetAsync(h->mnactive, 0, 4, st));
+  hipLaunchKernelGGL((multi_colpass_kernel<true>), grid, dim3(512), lds_pass, st, sa);
+  hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
+  HIPCK(hipGetLastError());
+  if (a.mode == 2) return GLRM_OK;
+  sa.point = h->mtrial;
+  for (int round = 1; round < 4096; ++round) { // a column makes at most ~13 + log(alpha growth) trials
+    unsigned int nact = 0;
+    HIPCK(hipMemcpyAsync(&nact, h->mnactive, 4, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    if (nact == 0) break;
+    sa.round = round;
+    HIPCK(hipMemsetAsync(h->mnactive, 0, 4, st));
+    hipLaunchKernelGGL((multi_colpass_kernel<false>), grid, dim3(512), lds_pass, st, sa);
+    hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
+    HIPCK(hipGetLastError());
+  }
   return GLRM_OK;
 }
 
@@ -70,6 +137,8 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
   if (rows) {
     const size_t lds = multi_lds_doubles(true, 1, h->kp, h->dmax, a.lgP) * 8;
     hipLaunchKernelGGL((multi_sweep_kernel<true, 1>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+  } else if (({ int rc_ = setup_split(h); if (rc_) return rc_; h->col_nsplit > 1; })) {
+    return run_split_cols(h, a);
   } else {
     const size_t lds = multi_lds_doubles(false, 8, h->kp, h->dmax, a.lgP) * 8;
     hipLaunchKernelGGL((multi_sweep_kernel<false, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);

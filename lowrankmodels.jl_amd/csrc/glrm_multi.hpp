@@ -432,13 +432,18 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
   for (int j = 0; j < GD; ++j) G[j] = 0.0;
   const int64_t stride = (int64_t)NW * SL;
   int64_t t = b + (int64_t)wave * SL + slot;
-  int32_t id_n = 0, id_nn = 0;
-  double av_n = 0.0, av_nn = 0.0, xr = 0.0;
+  // software pipeline: index / value loads run three wave-iterations ahead, the opposing row (columns) two ahead
+  int32_t id_n = 0, id_nn = 0, id_nnn = 0;
+  double av_n = 0.0, av_nn = 0.0, av_nnn = 0.0, xr = 0.0, xr_n = 0.0;
   if (e > b) { // clamped, unconditional loads: the waits stay counted
-    const int64_t t1 = t < e ? t : e - 1, t2 = t + stride < e ? t + stride : e - 1;
+    const int64_t t1 = t < e ? t : e - 1, t2 = t + stride < e ? t + stride : e - 1, t3 = t + 2 * stride < e ? t + 2 * stride : e - 1;
     id_n = a.idx[t1]; av_n = a.vals[t1];
     id_nn = a.idx[t2]; av_nn = a.vals[t2];
-    if constexpr (!ROWS) xr = a.other[(int64_t)id_n * kp + (comp ? sub : 0)];
+    id_nnn = a.idx[t3]; av_nnn = a.vals[t3];
+    if constexpr (!ROWS) {
+      xr = a.other[(int64_t)id_n * kp + (comp ? sub : 0)];
+      xr_n = a.other[(int64_t)id_nn * kp + (comp ? sub : 0)];
+    }
   }
   for (int64_t t0 = b + (int64_t)wave * SL; t0 < e; t0 += stride) { // wave-uniform trip count
     const bool valid = t < e;
@@ -446,10 +451,13 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
     const double av = av_n;
     const double xc = ROWS ? xown : (comp ? xr : 0.0);
     id_n = id_nn; av_n = av_nn;
+    id_nn = id_nnn; av_nn = av_nnn;
+    xr = xr_n;
     {
-      const int64_t t3 = t + 2 * stride < e ? t + 2 * stride : e - 1;
-      id_nn = a.idx[t3]; av_nn = a.vals[t3];
+      const int64_t t4 = t + 3 * stride < e ? t + 3 * stride : e - 1;
+      id_nnn = a.idx[t4]; av_nnn = a.vals[t4];
     }
+    if constexpr (!ROWS) xr_n = a.other[(int64_t)id_nn * kp + (comp ? sub : 0)]; // the row two observations ahead
     LossDesc l = lseg;
     int d = dseg;
     if constexpr (ROWS) {
@@ -461,8 +469,6 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
         for (int i = sub; i < d * kp; i += P) { const int j = i / kp, c = i - j * kp; oth[j * S + c] = Yb[i]; }
       }
       wave_sync();
-    } else {
-      xr = a.other[(int64_t)id_n * kp + (comp ? sub : 0)]; // next observation's row
     }
     const double* blk = ROWS ? oth : own; // the d vectors this observation meets
     const int dd = valid ? d : 0;
@@ -620,6 +626,151 @@ __global__ void __launch_bounds__(NW * 64) multi_sweep_kernel(const MultiArgs a)
   if (tid == 0) {
     a.alpha[s] = alpha;
     if (a.obj) a.obj[gseg] = obj;
+    if (a.trials) a.trials[s] += ntr;
+    if (a.accepts) a.accepts[s] += nacc;
+  }
+}
+
+// ---------------------------------------------------------------- split column sweeps
+// A tall model has few columns with very long observation lists (one workgroup per column leaves most of the chip idle), so
+// the Y half-step is also available as rounds of two kernels: multi_colpass_kernel spreads each column's list over `nsplit`
+// workgroups that write partial (loss, gradient) records, multi_coldecide_kernel adds the partials in split order and runs one
+// step of the column's line-search state machine (proxgrad.jl:177-200).  The host repeats trial pass + decide until no column
+// is active.  Same arithmetic per observation; only the grouping of the partial sums differs from the one-kernel sweep.
+struct SplitArgs {
+  MultiArgs m;
+  int nsplit;
+  int64_t chunk;        // observations per split: a constant, so the grouping of a column's partial sums depends on nothing
+                        // but the column's own list (results do not depend on how columns are sharded)
+  int round;            // 0 = after the gradient pass, >= 1 = after a trial pass, -1 = losses only
+  const double* point;  // pass: the block to evaluate (own factor or trial buffer), indexed like m.own
+  double* trial;        // trial points, indexed like m.own
+  double* part_loss;    // [nseg][nsplit]
+  double* part_G;       // [nseg][nsplit][dmax * kp]
+  double* gtot;         // [nseg][dmax * kp]
+  double* objold;       // [nseg]
+  int32_t* active;      // [nseg]
+  unsigned int* nactive;
+};
+
+template <bool GRAD>
+__global__ void __launch_bounds__(512) multi_colpass_kernel(const SplitArgs sa) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  constexpr int NW = 8, NT = NW * 64;
+  const MultiArgs& a = sa.m;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  const int S = a.kp + 1, kp = a.kp;
+  const int64_t s = blockIdx.x, gseg = a.own_offset + s;
+  const int y = blockIdx.y;
+  if (!GRAD && sa.round >= 1 && !sa.active[s]) return;
+  double* own = sm;
+  double* Gt = own + a.dmax * S;
+  double* red = Gt + a.dmax * S;
+  double* wbase = red + 16 + (size_t)wave * (64 >> a.lgP) * (S + 64);
+  const int64_t li = a.loss_single ? 0 : gseg;
+  const LossDesc lseg = load_loss(a.losses, li);
+  const int dseg = a.losses[li].dim > 1 ? a.losses[li].dim : 1;
+  const int64_t vec0 = a.ystart[gseg];
+  const double* src = sa.point + vec0 * kp;
+  for (int i = tid; i < dseg * kp; i += NT) { const int j = i / kp, c = i - j * kp; own[j * S + c] = src[i]; }
+  __syncthreads();
+  const int64_t b0 = a.ptr[s], e0 = a.ptr[s + 1];
+  int64_t b = b0 + (int64_t)y * sa.chunk, e = b + sa.chunk;
+  b = b < e0 ? b : e0;
+  e = e < e0 ? e : e0;
+  const double tot = multi_pass<false, NW, GRAD>(a, b, e, own, wbase, Gt, red, lseg, dseg);
+  if (tid == 0) sa.part_loss[s * sa.nsplit + y] = tot;
+  if constexpr (GRAD) {
+    double* pg = sa.part_G + ((size_t)s * sa.nsplit + y) * a.dmax * kp;
+    for (int i = tid; i < dseg * kp; i += NT) { const int j = i / kp, c = i - j * kp; pg[i] = c < a.k ? Gt[j * S + c] : 0.0; }
+  }
+}
+
+// One workgroup per column, same shape (8 waves) and the same block_prox / block_reg_eval instantiations as the one-kernel
+// sweep: a column whose list fits one chunk gets bit-identical results on either path.
+__global__ void __launch_bounds__(512) multi_coldecide_kernel(const SplitArgs sa) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const MultiArgs& a = sa.m;
+  const int tid = threadIdx.x, S = a.kp + 1, k = a.k, kp = a.kp;
+  const int64_t s = blockIdx.x, gseg = a.own_offset + s;
+  if (sa.round >= 1 && !sa.active[s]) return;
+  const int64_t li = a.loss_single ? 0 : gseg;
+  const int DO = a.losses[li].dim > 1 ? a.losses[li].dim : 1;
+  const int64_t vec0 = a.ystart[gseg];
+  double* blkA = sm;                 // own block
+  double* blkB = blkA + a.dmax * S;  // trial block
+  double* tmp = blkB + a.dmax * S;
+  double* red = tmp + 64;
+  double loss = 0.0;                 // partial losses in split order
+  for (int y = 0; y < sa.nsplit; ++y) loss += sa.part_loss[s * sa.nsplit + y];
+  if (sa.round < 0) { // losses only
+    if (tid == 0 && a.obj) a.obj[gseg] = loss;
+    return;
+  }
+  const glrm_reg rg = a.regs[a.reg_single ? 0 : s];
+  double* ownp = a.own + vec0 * kp;
+  double* trialp = sa.trial + vec0 * kp;
+  double* gt = sa.gtot + (size_t)s * a.dmax * kp;
+  const double l1 = (double)(a.ptr[s + 1] - a.ptr[s]) + 1;
+  for (int i = tid; i < DO * kp; i += 512) { const int j = i / kp, c = i - j * kp; blkA[j * S + c] = ownp[i]; }
+  double alpha = a.alpha[s], obj;
+  bool finished = false;
+  int ntr = 0, nacc = 0;
+  if (sa.round == 0) {
+    for (int i = tid; i < DO * kp; i += 512) { // gradient = partials in split order
+      double g = 0.0;
+      for (int y = 0; y < sa.nsplit; ++y) g += sa.part_G[((size_t)s * sa.nsplit + y) * a.dmax * kp + i];
+      gt[i] = g;
+    }
+    __syncthreads();
+    if (a.mode == 2) { // fixed step, no line search
+      const double st = a.fixed_alpha / l1;
+      for (int i = tid; i < DO * kp; i += 512) {
+        const int j = i / kp, c = i - j * kp;
+        if (c < k) { const double g = gt[i] * (-st); blkA[j * S + c] = blkA[j * S + c] + g; }
+      }
+      __syncthreads();
+      block_prox<8>(blkA, S, k, DO, rg, st, tmp);
+      for (int i = tid; i < DO * kp; i += 512) { const int j = i / kp, c = i - j * kp; ownp[i] = blkA[j * S + c]; }
+      if (tid == 0) sa.active[s] = 0;
+      return;
+    }
+    __syncthreads();
+    obj = loss + block_reg_eval<8>(blkA, S, k, DO, rg, red);
+    if (!(alpha > a.min_stepsize)) finished = true;
+  } else {
+    for (int i = tid; i < DO * kp; i += 512) { const int j = i / kp, c = i - j * kp; blkB[j * S + c] = trialp[i]; }
+    __syncthreads();
+    const double nobj = loss + block_reg_eval<8>(blkB, S, k, DO, rg, red);
+    obj = sa.objold[s];
+    ntr = 1;
+    if (nobj < obj) {
+      for (int i = tid; i < DO * kp; i += 512) ownp[i] = trialp[i];
+      alpha *= 1.05;
+      obj = nobj;
+      nacc = 1;
+      finished = true;
+    } else {
+      alpha *= .7;
+      if (alpha < a.min_stepsize) { alpha = a.min_stepsize * 1.1; finished = true; }
+    }
+  }
+  if (!finished) { // next trial point
+    const double stepsize = alpha / l1;
+    for (int i = tid; i < DO * kp; i += 512) {
+      const int j = i / kp, c = i - j * kp;
+      blkB[j * S + c] = c < k ? fma(-stepsize, gt[i], blkA[j * S + c]) : 0.0;
+    }
+    __syncthreads();
+    block_prox<8>(blkB, S, k, DO, rg, stepsize, tmp);
+    for (int i = tid; i < DO * kp; i += 512) { const int j = i / kp, c = i - j * kp; trialp[i] = blkB[j * S + c]; }
+  }
+  if (tid == 0) {
+    a.alpha[s] = alpha;
+    sa.objold[s] = obj;
+    sa.active[s] = finished ? 0 : 1;
+    if (!finished) atomicAdd(sa.nactive, 1u);
+    if (finished && a.obj) a.obj[gseg] = obj;
     if (a.trials) a.trials[s] += ntr;
     if (a.accepts) a.accepts[s] += nacc;
   }

@@ -81,6 +81,46 @@ def test_long_columns_use_all_waves():
     compare(g.problem_arrays(), X0, Y0, L.ProxGradParams(max_iter=6))
 
 
+def test_split_column_sweeps_on_a_tall_model():
+    """Columns longer than one chunk (8192 observations) are swept by several workgroups per column (pass + decide rounds)."""
+    rng = np.random.default_rng(78)
+    g, X0, Y0 = random_categorical(rng, 30000, 6, 5, 4, density=0.7, ordinal=True)
+    compare(g.problem_arrays(), X0, Y0, L.ProxGradParams(max_iter=5))
+
+
+@pytest.mark.parametrize("name", ["categorical_mix", "ordinal_offsets", "loss_test"])
+def test_split_and_one_kernel_column_sweeps_agree(name, monkeypatch):
+    """GLRM_HIP_MULTI_CHUNK=8 forces the split path on the small cases: same trajectory as the one-kernel sweep (only the grouping
+    of the partial sums differs), and two column shards reproduce the single handle bit for bit on the split path."""
+    kwargs, p = cases.build_multidim_case(name)
+    g = L.GLRM(**kwargs)
+    api = hip()
+    ref = cases.run_engine(api, g.problem_arrays(), kwargs["X"], kwargs["Y"], p)
+    monkeypatch.setenv("GLRM_HIP_MULTI_CHUNK", "8")
+    spl = cases.run_engine(api, g.problem_arrays(), kwargs["X"], kwargs["Y"], p)
+    assert len(spl[0]) == len(ref[0])
+    assert cases.rel_err(spl[0], ref[0]) < 1e-9 and cases.fro_err(spl[1], ref[1]) < 1e-9 and cases.fro_err(spl[2], ref[2]) < 1e-9
+    # sharded, split path: one Y half-step on two column blocks == on the whole
+    X, Y = np.array(kwargs["X"], order="F"), np.array(kwargs["Y"], order="F")
+    ys = g.problem_arrays().ystart
+    outs = []
+    for bounds in ([0, g.n], [0, g.n // 3, g.n]):
+        Yout = Y.copy()
+        for r in range(len(bounds) - 1):
+            h = api.create(g.problem_arrays(cols=(bounds[r], bounds[r + 1])))
+            try:
+                api.set_factors(h, X, Y)
+                api.reset_stepsizes(h, 1.0)
+                api.step_y(h, 0.01)
+                Xr, Yr = np.zeros_like(X), np.zeros_like(Y)
+                api.get_factors(h, Xr, Yr)
+                Yout[:, ys[bounds[r]]:ys[bounds[r + 1]]] = Yr[:, ys[bounds[r]]:ys[bounds[r + 1]]]
+            finally:
+                api.destroy(h)
+        outs.append(Yout)
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_rank_above_64_is_rejected_for_multidim():
     rng = np.random.default_rng(5)
     g, X0, Y0 = random_categorical(rng, 40, 6, 70, 3)
