@@ -11,15 +11,17 @@ using LowRankModels
 import LowRankModels: fit!, GLRM, AbstractParams, ConvergenceHistory, update_ch!,
                       Loss, Regularizer, QuadLoss, L1Loss, HuberLoss, QuantileLoss, PeriodicLoss, PoissonLoss,
                       OrdinalHingeLoss, LogisticLoss, WeightedHingeLoss,
-                      ZeroReg, QuadReg, OneReg, NonNegConstraint, UnitOneSparseConstraint, ProxGradParams
+                      MultinomialLoss, OvALoss, BvSLoss, OrdisticLoss, MultinomialOrdinalLoss, embedding_dim,
+                      ZeroReg, QuadReg, OneReg, NonNegConstraint, UnitOneSparseConstraint,
+                      lastentry1, lastentry_unpenalized, OrdinalReg, MNLOrdinalReg, ProxGradParams
 
 export HipProxGradParams
 
 const LIB = get(ENV, "GLRM_HIP_LIB", "libglrm_hip.so")
 
 # mirrors of the C structs (include/glrm_hip.h)
-struct CLoss; kind::Int32; reserved::Int32; scale::Float64; p0::Float64; p1::Float64; end
-struct CReg;  kind::Int32; reserved::Int32; scale::Float64; end
+struct CLoss; kind::Int32; dim::Int32; scale::Float64; p0::Float64; p1::Float64; end   # dim = embedding_dim (0/1: scalar)
+struct CReg;  kind::Int32; wrap::Int32; scale::Float64; end                             # wrap = GLRM_WRAP_* flag
 struct CProblem
     m::Int64; n::Int64; k::Int32; flags::Int32
     row_begin::Int64; row_end::Int64; col_begin::Int64; col_end::Int64
@@ -55,12 +57,27 @@ closs(l::PoissonLoss) = CLoss(5, 0, l.scale, 0, 0)
 closs(l::OrdinalHingeLoss) = CLoss(6, 0, l.scale, l.min, l.max)
 closs(l::LogisticLoss) = CLoss(7, 0, l.scale, 0, 0)
 closs(l::WeightedHingeLoss) = CLoss(8, 0, l.scale, l.case_weight_ratio, 0)
-closs(l::Loss) = nothing                     # multi-dimensional losses: not on the accelerated path
+# multi-dimensional losses (src/losses.jl:360-620): dim columns of Y per column of A; bin_loss must be Logistic / Hinge
+binkind(b::LogisticLoss) = 7.0
+binkind(b::WeightedHingeLoss) = b.case_weight_ratio == 1 ? 8.0 : NaN
+binkind(b) = NaN
+closs(l::MultinomialLoss) = CLoss(9, l.max, l.scale, 0, 0)
+closs(l::OvALoss) = isnan(binkind(l.bin_loss)) ? nothing : CLoss(10, l.max, l.scale, l.bin_loss.scale, binkind(l.bin_loss))
+closs(l::BvSLoss) = isnan(binkind(l.bin_loss)) ? nothing : CLoss(11, l.max - 1, l.scale, l.bin_loss.scale, binkind(l.bin_loss))
+closs(l::OrdisticLoss) = CLoss(12, l.max, l.scale, 0, 0)
+closs(l::MultinomialOrdinalLoss) = CLoss(13, l.max - 1, l.scale, 0, 0)
+closs(l::Loss) = nothing                     # anything else: reference path
 creg(r::ZeroReg) = CReg(0, 0, 1.0)
 creg(r::QuadReg) = CReg(1, 0, r.scale)
 creg(r::OneReg) = CReg(2, 0, r.scale)
 creg(r::NonNegConstraint) = CReg(3, 0, 1.0)
 creg(r::UnitOneSparseConstraint) = CReg(4, 0, 1.0)
+# wrappers around one of the five base regularizers (src/regularizers.jl:163-189,356-411)
+wrapped(r, flag) = (b = creg(r.r); (b === nothing || b.wrap != 0) ? nothing : CReg(b.kind, flag, b.scale))
+creg(r::lastentry1) = wrapped(r, 1)
+creg(r::lastentry_unpenalized) = wrapped(r, 2)
+creg(r::OrdinalReg) = wrapped(r, 4)
+creg(r::MNLOrdinalReg) = wrapped(r, 8)
 creg(r::Regularizer) = nothing
 
 isclass(l) = l isa LogisticLoss || l isa WeightedHingeLoss
@@ -89,7 +106,10 @@ function fit!(glrm::GLRM, p::HipProxGradParams; ch::ConvergenceHistory=Convergen
                     inner_iter_Y=p.inner_iter_Y, abs_tol=p.abs_tol, rel_tol=p.rel_tol, min_stepsize=p.min_stepsize);
                     ch=ch, verbose=verbose, kwargs...)
     end
-    A = glrm.A; m, n = size(A); k = glrm.k
+    A = glrm.A; m, n = size(A); k = glrm.k          # glrm.Y is k x embedding_dim(glrm.losses): passed through as is
+    (k > 64 && (embedding_dim(glrm.losses) != n || any(c -> c.wrap != 0, crx) || any(c -> c.wrap != 0, cry))) &&
+        return fit!(glrm, ProxGradParams(p.stepsize; max_iter=p.max_iter, inner_iter_X=p.inner_iter_X, inner_iter_Y=p.inner_iter_Y,
+                    abs_tol=p.abs_tol, rel_tol=p.rel_tol, min_stepsize=p.min_stepsize); ch=ch, verbose=verbose, kwargs...)
     losses = Vector{CLoss}(cl); rx = Vector{CReg}(crx); ry = Vector{CReg}(cry)
     rowptr, colidx, rowvals = flatten(glrm.observed_features, (e, f) -> value(glrm.losses[f], A[e, f]))
     colptr, rowidx, colvals = flatten(glrm.observed_examples, (f, e) -> value(glrm.losses[f], A[e, f]))
