@@ -244,6 +244,15 @@ int glrm_hip_col_penalties(glrm_handle* h);
  * column).  Omega, A and the losses stay on the device: this is what `regularization_path` / `scale_regularizer!`
  * (src/cross_validate.jl:228-231, src/glrm.jl:85-89) need between warm-started fits. */
 int glrm_hip_set_regularizers(glrm_handle* h, const glrm_reg* rx, int64_t n_rx, const glrm_reg* ry, int64_t n_ry);
+/* A new handle over a SUBSET of the parent's observations, built on the device from the parent's resident Omega views and
+ * values (nothing but the tags crosses PCIe: 1 byte per observation and view instead of 12).  Entry t of the parent's row
+ * view is kept iff (row_tags[t] == match) != invert, entry t of its column view iff (col_tags[t] == match) != invert; order
+ * and duplicates inside a row / column are preserved.  Losses, regularizers, rank, shard ranges and options are the parent's.
+ * This is the train / test split of cross_validate, cv_by_iter and regularization_path (getfolds / get_train_and_test,
+ * src/cross_validate.jl:54-105): fold f's training model is subset(tags = fold ids, match = f, invert = 1), its test model
+ * subset(..., invert = 0).  The parent must be a list (not dense) handle; it is not modified and may be destroyed first. */
+int glrm_hip_subset(glrm_handle* parent, const uint8_t* row_tags, const uint8_t* col_tags, int32_t match, int32_t invert,
+                    glrm_handle** out);
 /* Fixed-order sum of n device doubles (independent of the number of shards); synchronises. */
 int glrm_hip_sum(glrm_handle* h, const void* dvec, int64_t n, double* out);
 int glrm_hip_synchronize(glrm_handle* h);

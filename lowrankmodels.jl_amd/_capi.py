@@ -87,7 +87,7 @@ class CKernelStats(C.Structure):
 ABI_SYMBOLS = (
     "version", "last_error", "create", "destroy", "fit", "fit_sparse", "objective", "factor_ld", "bind_buffers",
     "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "gradstep_x", "gradstep_y", "col_losses", "row_penalties",
-    "col_penalties", "set_regularizers", "sum", "synchronize", "kernel_stats",
+    "col_penalties", "set_regularizers", "subset", "sum", "synchronize", "kernel_stats",
 )
 
 
@@ -131,6 +131,7 @@ class Api:
             "row_penalties": (C.c_int, [H]),
             "col_penalties": (C.c_int, [H]),
             "set_regularizers": (C.c_int, [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+            "subset": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(H)]),
             "sum": (C.c_int, [H, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
             "synchronize": (C.c_int, [H]),
             "kernel_stats": (C.c_int, [H, C.POINTER(CKernelStats), C.c_int]),
@@ -250,6 +251,16 @@ class Api:
     def set_regularizers(self, h, rx, ry):
         """rx, ry: REG_DTYPE arrays with the same lengths as at create."""
         self._ck(self._f["set_regularizers"](h, _ptr(rx), len(rx), _ptr(ry), len(ry)))
+
+    def subset(self, h, row_tags, col_tags, match, invert=False):
+        """Child handle over the entries whose tag (uint8 per entry of the parent's row view / column view) equals
+        ``match`` (or differs from it when ``invert``): the train / test split of the cross-validation drivers, compacted
+        from the parent's resident data."""
+        row_tags = np.ascontiguousarray(row_tags, dtype=np.uint8)
+        col_tags = np.ascontiguousarray(col_tags, dtype=np.uint8)
+        out = C.c_void_p()
+        self._ck(self._f["subset"](h, _ptr(row_tags), _ptr(col_tags), int(match), 1 if invert else 0, C.byref(out)))
+        return out
 
     def sum(self, h, vec, n) -> float:
         out = C.c_double(0.0)

@@ -89,6 +89,11 @@ struct glrm_handle {
   int32_t *trials_r = nullptr, *accepts_r = nullptr, *trials_c = nullptr, *accepts_c = nullptr;
   int waves_row = 1, waves_col = 4;
   int profile = 0;
+  // what glrm_hip_subset needs to build a child handle: the options and host copies of the descriptors
+  glrm_options opts{};
+  int wr_opt = 0, wc_opt = 0;
+  std::vector<glrm_loss> losses_h;
+  std::vector<glrm_reg> rx_h, ry_h;
   struct Ev { hipEvent_t a, b; int which; };
   std::vector<Ev> pending, pool;
   int64_t launches_x = 0, launches_y = 0;

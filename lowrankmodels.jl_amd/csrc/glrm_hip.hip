@@ -518,6 +518,10 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   h->unroll_col = env_int("GLRM_HIP_UNROLL_COL", 1) == 2 ? 2 : 1;
   h->profile = o ? o->profile : 0;
   h->tiled_opt = o ? o->tiled : 0;
+  if (o) h->opts = *o; else { h->opts = glrm_options{}; h->opts.device_id = -1; }
+  h->losses_h.assign(p->losses, p->losses + p->n_losses);
+  h->rx_h.assign(p->rx, p->rx + p->n_rx);
+  h->ry_h.assign(p->ry, p->ry + p->n_ry);
   if (o && (o->stream || o->caller_stream)) {
     h->stream = (hipStream_t)o->stream; // may be NULL = the legacy default stream (caller_stream)
   } else {
@@ -701,6 +705,8 @@ extern "C" int glrm_hip_set_regularizers(glrm_handle* h, const glrm_reg* rx, int
     }
   }
   DeviceGuard dg(h->device);
+  h->rx_h.assign(rx, rx + n_rx);
+  h->ry_h.assign(ry, ry + n_ry);
   HIPCK(hipMemcpyAsync(h->rx, rx, (size_t)n_rx * sizeof(glrm_reg), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipMemcpyAsync(h->ry, ry, (size_t)n_ry * sizeof(glrm_reg), hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));

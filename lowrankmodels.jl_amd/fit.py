@@ -51,6 +51,28 @@ def partition(ptr, parts):
     return b
 
 
+def _ensure_handle(glrm, api, params, allow_dense=True):
+    """The model's engine handle (created on first use, kept on the model: Omega and A stay on the device across fit! calls,
+    README.md:337-346 warm starts, cross-validation drivers).  A change of the regularizers only replaces the descriptors
+    (scale_regularizer!, regularization_path).  Returns (handle, hard key, soft key)."""
+    use_dense = allow_dense and api.dense_ok and glrm.dense_eligible() and getattr(params, "dense", True)
+    hard, soft = glrm._descriptor_key()
+    key = (id(api), _engine_opts(params)["device_id"], hard)
+    cache = glrm._handle_cache
+    if cache is not None and (cache[2] != key or cache[4] != use_dense):
+        glrm.close()
+        cache = None
+    if cache is None:
+        h = api.create(glrm.problem_arrays(dense=use_dense), **_engine_opts(params))
+        glrm._handle_cache = (api, h, key, soft, use_dense)
+    elif cache[3] != soft:
+        # only the regularizers changed: keep Omega / A on the device
+        from .regularizers import pack_regs
+        api.set_regularizers(cache[1], pack_regs(glrm.rx), pack_regs(glrm.ry))
+        glrm._handle_cache = cache[:3] + (soft,) + tuple(cache[4:])
+    return glrm._handle_cache[1], key, soft
+
+
 def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, **kwargs):
     """``fit!(glrm, params; ch, verbose)`` -> ``(glrm.X, glrm.Y, ch)``; glrm.X / glrm.Y are updated in
     place (warm start: a second call continues, README.md:337-346).  ``params`` may also be passed
@@ -78,20 +100,7 @@ def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, 
 
     if np.linalg.norm(glrm.Y) == 0:
         raise ValueError("Y is all zeros (the reference cannot start from Y == 0, src/algorithms/proxgrad.jl:45-48)")
-    use_dense = api.dense_ok and glrm.dense_eligible() and getattr(params, "dense", True)
-    hard, soft = glrm._descriptor_key()
-    key = (id(api), _engine_opts(params)["device_id"], hard, use_dense)
-    if glrm._handle_cache is not None and glrm._handle_cache[2] != key:
-        glrm.close()
-    if glrm._handle_cache is None:
-        h = api.create(glrm.problem_arrays(dense=use_dense), **_engine_opts(params))
-        glrm._handle_cache = (api, h, key, soft)
-    elif glrm._handle_cache[3] != soft:
-        # only the regularizers changed (scale_regularizer!, regularization_path): keep Omega / A on the device
-        from .regularizers import pack_regs
-        api.set_regularizers(glrm._handle_cache[1], pack_regs(glrm.rx), pack_regs(glrm.ry))
-        glrm._handle_cache = glrm._handle_cache[:3] + (soft,)
-    h = glrm._handle_cache[1]
+    h = _ensure_handle(glrm, api, params)[0]
     X = np.asfortranarray(glrm.X, dtype=np.float64)
     Y = np.asfortranarray(glrm.Y, dtype=np.float64)
     if sparse:  # src/algorithms/sparse_proxgrad.jl:22-134
@@ -134,11 +143,8 @@ def objective(glrm, X=None, Y=None, *, include_regularization=True, engine=None,
     api = engine if engine is not None else _capi.hip_api()
     X = np.asfortranarray(glrm.X if X is None else X, dtype=np.float64)
     Y = np.asfortranarray(glrm.Y if Y is None else Y, dtype=np.float64)
-    h = api.create(glrm.problem_arrays())
-    try:
-        return api.objective(h, X, Y, include_regularization)
-    finally:
-        api.destroy(h)
+    h = _ensure_handle(glrm, api, HipProxGradParams())[0]  # resident handle: no re-upload per evaluation
+    return api.objective(h, X, Y, include_regularization)
 
 
 # ----------------------------------------------------------------------------- multi-GPU host

@@ -1420,3 +1420,53 @@ static int gen_penalties(glrm_cpu_handle* h, int rows) {
   }
   return GLRM_OK;
 }
+
+/* =====================================================================================================
+ * glrm_cpu_subset: the train / test split of cross_validate, cv_by_iter and regularization_path
+ * (getfolds / get_train_and_test, src/cross_validate.jl:54-105) as a child handle over the tagged entries
+ * of both Omega views; order and duplicates inside a row / column are preserved (sort_observations pushes in
+ * obs order, src/modify_glrm.jl:5-18).
+ * ===================================================================================================== */
+static int compact_view_cpu(const int64_t* ptr, const int32_t* idx, const double* vals, int64_t nseg, const uint8_t* tags, int match,
+                            int invert, int64_t** optr, int32_t** oidx, double** ovals) {
+  const int64_t nnz = ptr[nseg];
+  int64_t kept = 0;
+  for (int64_t t = 0; t < nnz; ++t) kept += (((int)tags[t] == match) != (invert != 0));
+  *optr = (int64_t*)malloc((size_t)(nseg + 1) * 8);
+  *oidx = (int32_t*)malloc((size_t)(kept ? kept : 1) * 4);
+  *ovals = (double*)malloc((size_t)(kept ? kept : 1) * 8);
+  if (!*optr || !*oidx || !*ovals) return fail(GLRM_ERR_OOM, "out of memory");
+  int64_t q = 0;
+  for (int64_t s = 0; s < nseg; ++s) {
+    (*optr)[s] = q;
+    for (int64_t t = ptr[s]; t < ptr[s + 1]; ++t)
+      if (((int)tags[t] == match) != (invert != 0)) { (*oidx)[q] = idx[t]; (*ovals)[q] = vals[t]; ++q; }
+  }
+  (*optr)[nseg] = q;
+  return GLRM_OK;
+}
+
+int glrm_cpu_subset(glrm_cpu_handle* parent, const uint8_t* row_tags, const uint8_t* col_tags, int32_t match, int32_t invert,
+                    glrm_cpu_handle** out) {
+  if (!parent || !out) return fail(GLRM_ERR_INVALID, "NULL argument");
+  *out = NULL;
+  const int64_t ml = parent->row_end - parent->row_begin, nl = parent->col_end - parent->col_begin;
+  if ((parent->rowptr[ml] > 0 && !row_tags) || (parent->colptr[nl] > 0 && !col_tags)) return fail(GLRM_ERR_INVALID, "NULL tag array");
+  int64_t *rp = NULL, *cp = NULL;
+  int32_t *ci = NULL, *ri = NULL;
+  double *rv = NULL, *cv = NULL;
+  int rc = compact_view_cpu(parent->rowptr, parent->colidx, parent->rowvals, ml, row_tags, match, invert, &rp, &ci, &rv);
+  if (!rc) rc = compact_view_cpu(parent->colptr, parent->rowidx, parent->colvals, nl, col_tags, match, invert, &cp, &ri, &cv);
+  if (!rc) {
+    glrm_problem p;
+    memset(&p, 0, sizeof p);
+    p.m = parent->m; p.n = parent->n; p.k = parent->k;
+    p.row_begin = parent->row_begin; p.row_end = parent->row_end; p.col_begin = parent->col_begin; p.col_end = parent->col_end;
+    p.rowptr = rp; p.colidx = ci; p.rowvals = rv; p.colptr = cp; p.rowidx = ri; p.colvals = cv;
+    p.losses = parent->losses; p.n_losses = parent->n_losses;
+    p.rx = parent->rx; p.n_rx = parent->n_rx; p.ry = parent->ry; p.n_ry = parent->n_ry;
+    rc = glrm_cpu_create(out, &p, NULL);
+  }
+  free(rp); free(ci); free(rv); free(cp); free(ri); free(cv);
+  return rc;
+}
