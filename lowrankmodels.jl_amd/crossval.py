@@ -37,6 +37,22 @@ def _lists(ptr, idx):
     return [idx[ptr[s]:ptr[s + 1]] for s in range(len(ptr) - 1)]
 
 
+def _stable_order_by_column(rowptr, colidx, n):
+    """Positions of the row-view entries listed column by column, obs order kept inside a column (what sort_observations'
+    push! produces).  CSR -> CSC transposition of the entry numbers when scipy is there (linear time), a stable argsort
+    otherwise."""
+    nnz = len(colidx)
+    try:
+        import scipy.sparse as sp
+        if nnz < 2 ** 31:
+            csr = sp.csr_matrix((np.arange(1, nnz + 1, dtype=np.int32 if nnz < 2 ** 31 - 1 else np.int64), colidx, rowptr),
+                                shape=(len(rowptr) - 1, n))
+            return csr.tocsc().data.astype(np.int64) - 1
+    except ImportError:
+        pass
+    return np.argsort(colidx.astype(np.int64), kind="stable")
+
+
 class _Split:
     """The row view of a model flattened in list order (= `obs`), the permutation that turns it into the column view
     sort_observations would build (stable by column, src/modify_glrm.jl:5-18), and whether the model's own column view
@@ -46,7 +62,7 @@ class _Split:
         self.g = glrm
         self.I = np.repeat(np.arange(glrm.m, dtype=np.int64), np.diff(glrm._rowptr))
         self.J = glrm._colidx.astype(np.int64)
-        self.perm = np.argsort(self.J, kind="stable")
+        self.perm = _stable_order_by_column(glrm._rowptr, glrm._colidx, glrm.n)
         counts = np.bincount(self.J, minlength=glrm.n)
         self.canon_colptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
         self.canonical = (np.array_equal(self.canon_colptr, glrm._colptr)

@@ -22,14 +22,19 @@ ap.add_argument("--q", type=int, default=500)
 ap.add_argument("--k", type=int, default=32)
 ap.add_argument("--folds", type=int, default=5)
 a = ap.parse_args()
-pa, X0, Y0 = O.synth_cpu(a.m, a.n, a.k, a.q)
+rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(a.m, a.n, a.k, a.q)
+from lowrankmodels.jl_amd.losses import pack_losses  # noqa: E402
+from lowrankmodels.jl_amd.regularizers import pack_regs  # noqa: E402
+pa = _capi.ProblemArrays(a.m, a.n, a.k, rowptr, colidx, rowvals, colptr, rowidx, colvals, pack_losses([L.QuadLoss()]),
+                         pack_regs([L.QuadReg(1.0)]), pack_regs([L.QuadReg(1.0)]))
 nnz = int(pa.rowptr[-1])
 api = _capi.hip_api()
 t = time.time(); h = api.create(pa); api.synchronize(h); t_create = time.time() - t
 rng = np.random.default_rng(0)
 tags = rng.integers(0, a.folds, nnz).astype(np.uint8)
 I = np.repeat(np.arange(a.m), np.diff(pa.rowptr)); J = pa.colidx.astype(np.int64)
-t = time.time(); perm = np.argsort(J, kind="stable"); ctags = tags[perm]; t_perm = time.time() - t
+from lowrankmodels.jl_amd.crossval import _stable_order_by_column  # noqa: E402
+t = time.time(); perm = _stable_order_by_column(pa.rowptr, pa.colidx, a.n); ctags = tags[perm]; t_perm = time.time() - t
 p = L.ProxGradParams(max_iter=10, abs_tol=0, rel_tol=0)
 t_sub = t_host = t_fit = 0.0
 for f in range(a.folds):
