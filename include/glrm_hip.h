@@ -253,6 +253,17 @@ int glrm_hip_set_regularizers(glrm_handle* h, const glrm_reg* rx, int64_t n_rx, 
  * subset(..., invert = 0).  The parent must be a list (not dense) handle; it is not modified and may be destroyed first. */
 int glrm_hip_subset(glrm_handle* parent, const uint8_t* row_tags, const uint8_t* col_tags, int32_t match, int32_t invert,
                     glrm_handle** out);
+/* init_svd!(glrm) (src/initialize.jl:35-132) on the resident lists of a single-shard list handle: the observed entries are
+ * expanded to reals (categorical / ordinal multi-dimensional columns become +-1 indicators), centred by the per-column mean of
+ * the observed entries, scaled by m*n/|Omega|, and X = sqrt(S) U', Y = sqrt(S) V' diag(std) of the top-k singular triplets are
+ * written to the caller's k x m and k x d buffers (unobserved entries count as 0, like in the reference).  The reference calls
+ * Arpack's svds; here a randomized subspace iteration (block size k + 8) runs until the k leading singular values move by
+ * less than tol * s_1 (tol <= 0: 1e-12; max_iter <= 0: 60).  X and Y are determined up to the sign of each component; X'Y is
+ * unique.  The two Omega views must list the same entries without duplicates (the reference works on the expanded MATRIX).
+ * `offset` / `scale` of the reference are dead code there (typeof(glrm.rx) == lastentry1 is never true for a Vector) and not
+ * reproduced.  singular_values (k) and iters_done may be NULL. */
+int glrm_hip_init_svd(glrm_handle* h, double* X, double* Y, int32_t max_iter, double tol, uint64_t seed, double* singular_values,
+                      int32_t* iters_done);
 /* Fixed-order sum of n device doubles (independent of the number of shards); synchronises. */
 int glrm_hip_sum(glrm_handle* h, const void* dvec, int64_t n, double* out);
 int glrm_hip_synchronize(glrm_handle* h);

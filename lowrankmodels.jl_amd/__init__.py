@@ -10,6 +10,7 @@ from .convergence import ConvergenceHistory, update_ch
 from .fit import ShardedFit, fit, fit_b, objective, partition
 from .crossval import (cross_validate, cv_by_iter, flatten_observations, get_train_and_test, getfolds, loss_fn,
                              regularization_path)
+from .initialize import init_svd_
 from .glrm import GLRM, add_offset_, copy_estimate, parameter_estimate, scale_regularizer_, sort_observations
 from .losses import (BvSLoss, HingeLoss, HuberLoss, L1Loss, LogisticLoss, Loss, MultinomialLoss, MultinomialOrdinalLoss,
                      OrdinalHingeLoss, OrdisticLoss, OvALoss, PeriodicLoss, PoissonLoss, QuadLoss, QuantileLoss,

@@ -87,7 +87,7 @@ class CKernelStats(C.Structure):
 ABI_SYMBOLS = (
     "version", "last_error", "create", "destroy", "fit", "fit_sparse", "objective", "factor_ld", "bind_buffers",
     "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "gradstep_x", "gradstep_y", "col_losses", "row_penalties",
-    "col_penalties", "set_regularizers", "subset", "sum", "synchronize", "kernel_stats",
+    "col_penalties", "set_regularizers", "subset", "init_svd", "sum", "synchronize", "kernel_stats",
 )
 
 
@@ -132,6 +132,7 @@ class Api:
             "col_penalties": (C.c_int, [H]),
             "set_regularizers": (C.c_int, [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
             "subset": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(H)]),
+            "init_svd": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_void_p, C.POINTER(C.c_int32)]),
             "sum": (C.c_int, [H, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
             "synchronize": (C.c_int, [H]),
             "kernel_stats": (C.c_int, [H, C.POINTER(CKernelStats), C.c_int]),
@@ -261,6 +262,13 @@ class Api:
         out = C.c_void_p()
         self._ck(self._f["subset"](h, _ptr(row_tags), _ptr(col_tags), int(match), 1 if invert else 0, C.byref(out)))
         return out
+
+    def init_svd(self, h, X, Y, max_iter=0, tol=0.0, seed=1):
+        """init_svd! on the handle's resident lists: fills X (k x m) and Y (k x d); returns (singular values, iterations)."""
+        sv = np.zeros(X.shape[0])
+        it = C.c_int32(0)
+        self._ck(self._f["init_svd"](h, _ptr(X), _ptr(Y), int(max_iter), float(tol), int(seed), _ptr(sv), C.byref(it)))
+        return sv, it.value
 
     def sum(self, h, vec, n) -> float:
         out = C.c_double(0.0)

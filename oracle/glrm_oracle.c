@@ -1470,3 +1470,105 @@ int glrm_cpu_subset(glrm_cpu_handle* parent, const uint8_t* row_tags, const uint
   free(rp); free(ci); free(rv); free(cp); free(ri); free(cv);
   return rc;
 }
+
+/* =====================================================================================================
+ * glrm_cpu_init_svd: init_svd!(glrm) (src/initialize.jl:35-132) restated with the dense standardized matrix the reference
+ * builds and an exact SVD (one-sided Jacobi in place of Arpack's svds): small problems only (m * d doubles).
+ *   Areal (:47-80): scalar columns keep their value, CategoricalDomain columns become +-1 per level, multi-dimensional
+ *   OrdinalDomain columns +-1 per threshold; means / stds over the observed entries of each expanded column (:83-95);
+ *   Astd = Areal - mean on the observed entries, 0 elsewhere (:96); Astd *= m*n/|Omega_rows| (:113); X = sqrt(S) U',
+ *   Y = sqrt(S) V' diag(stds) (:129-130).  `offset` / `scale` (:36-39) are dead code in the reference: glrm.rx is a Vector,
+ *   so typeof(glrm.rx) == lastentry1 is never true.
+ * ===================================================================================================== */
+static double areal_of(const glrm_loss* l, double a, int j) {
+  const int d = l->dim > 1 ? l->dim : 1;
+  if (d <= 1) return a;
+  if (l->kind == GLRM_LOSS_MULTINOMIAL || l->kind == GLRM_LOSS_OVA) return a == (double)(j + 1) ? 1.0 : -1.0;
+  const int nlev = l->kind == GLRM_LOSS_ORDISTIC ? d : d + 1; /* levels 1..max; one column per level but the last */
+  return j < nlev - 1 ? (a > (double)(j + 1) ? 1.0 : -1.0) : 0.0;
+}
+
+int glrm_cpu_init_svd(glrm_cpu_handle* h, double* X, double* Y, int32_t max_iter, double tol, uint64_t seed, double* singular_values,
+                      int32_t* iters_done) {
+  (void)max_iter; (void)tol; (void)seed;
+  if (!h || !X || !Y) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (!(h->row_begin == 0 && h->row_end == h->m && h->col_begin == 0 && h->col_end == h->n))
+    return fail(GLRM_ERR_INVALID, "glrm_cpu_init_svd needs a single-shard handle");
+  const int64_t m = h->m, n = h->n, d = h->d;
+  const int k = h->k;
+  if (k > m || k > d) return fail(GLRM_ERR_INVALID, "k = %d exceeds min(m, d): no k singular triplets", k);
+  if ((double)m * (double)d > 5e7) return fail(GLRM_ERR_UNSUPPORTED, "the oracle's init_svd builds the dense m x d matrix: too large");
+  double* W = (double*)calloc((size_t)m * d, 8);      /* Astd, column-major: W[e + j*m] */
+  double* V = (double*)calloc((size_t)d * d, 8);      /* right rotations, column-major */
+  double* means = (double*)malloc((size_t)d * 8);
+  double* stds = (double*)malloc((size_t)d * 8);
+  double* sv = (double*)malloc((size_t)d * 8);
+  int64_t* order = (int64_t*)malloc((size_t)d * 8);
+  if (!W || !V || !means || !stds || !sv || !order) { free(W); free(V); free(means); free(stds); free(sv); free(order); return fail(GLRM_ERR_OOM, "out of memory"); }
+  for (int64_t f = 0; f < n; ++f) {
+    const glrm_loss* l = loss_of(h, f);
+    const int df = l->dim > 1 ? l->dim : 1;
+    const int64_t b = h->colptr[f], e = h->colptr[f + 1], cnt = e - b;
+    for (int j = 0; j < df; ++j) {
+      const int64_t col = h->ystart[f] + j;
+      double s = 0.0;
+      for (int64_t t = b; t < e; ++t) s += areal_of(l, h->colvals[t], j);
+      double mean = s / (double)cnt; /* NaN for an empty column */
+      double q = 0.0;
+      for (int64_t t = b; t < e; ++t) { const double x = areal_of(l, h->colvals[t], j) - mean; q += x * x; }
+      double sd = sqrt(q / (double)(cnt - 1));
+      if (isnan(mean)) mean = 1.0;
+      if (sd < 1e-10 || isnan(sd)) sd = 1.0;
+      means[col] = mean; stds[col] = sd;
+      for (int64_t t = b; t < e; ++t) W[h->rowidx[t] + col * m] = areal_of(l, h->colvals[t], j) - mean;
+    }
+  }
+  const double cs = h->rowptr[m] > 0 ? (double)m * (double)n / (double)h->rowptr[m] : 0.0;
+  for (int64_t i = 0; i < m * d; ++i) W[i] *= cs;
+  for (int64_t j = 0; j < d; ++j) V[j + j * d] = 1.0;
+  /* one-sided Jacobi (Hestenes): rotate column pairs of W until they are mutually orthogonal; W = U S, rotations -> V */
+  int sweeps = 0;
+  for (; sweeps < 80; ++sweeps) {
+    double worst = 0.0;
+    for (int64_t p = 0; p < d - 1; ++p)
+      for (int64_t q = p + 1; q < d; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        const double *wp = W + p * m, *wq = W + q * m;
+        for (int64_t i = 0; i < m; ++i) { alpha += wp[i] * wp[i]; beta += wq[i] * wq[i]; gamma += wp[i] * wq[i]; }
+        if (gamma == 0.0 || alpha == 0.0 || beta == 0.0) continue;
+        const double r = fabs(gamma) / sqrt(alpha * beta);
+        if (r > worst) worst = r;
+        if (r < 1e-15) continue;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        double *wpm = W + p * m, *wqm = W + q * m;
+        for (int64_t i = 0; i < m; ++i) { const double a = wpm[i], b2 = wqm[i]; wpm[i] = c * a - s * b2; wqm[i] = s * a + c * b2; }
+        double *vp = V + p * d, *vq = V + q * d;
+        for (int64_t i = 0; i < d; ++i) { const double a = vp[i], b2 = vq[i]; vp[i] = c * a - s * b2; vq[i] = s * a + c * b2; }
+      }
+    if (worst < 1e-15) break;
+  }
+  for (int64_t j = 0; j < d; ++j) {
+    double s = 0.0;
+    for (int64_t i = 0; i < m; ++i) s += W[i + j * m] * W[i + j * m];
+    sv[j] = sqrt(s);
+    order[j] = j;
+  }
+  for (int64_t a = 1; a < d; ++a) { /* insertion sort, descending */
+    const int64_t o = order[a];
+    int64_t b2 = a - 1;
+    while (b2 >= 0 && sv[order[b2]] < sv[o]) { order[b2 + 1] = order[b2]; --b2; }
+    order[b2 + 1] = o;
+  }
+  for (int c = 0; c < k; ++c) {
+    const int64_t j = order[c];
+    const double s = sv[j], rs = sqrt(s);
+    for (int64_t e = 0; e < m; ++e) X[c + (int64_t)k * e] = s > 0 ? rs * (W[e + j * m] / s) : 0.0; /* sqrt(S) U' */
+    for (int64_t col = 0; col < d; ++col) Y[c + (int64_t)k * col] = rs * V[col + j * d] * stds[col];
+    if (singular_values) singular_values[c] = s;
+  }
+  if (iters_done) *iters_done = sweeps;
+  free(W); free(V); free(means); free(stds); free(sv); free(order);
+  return GLRM_OK;
+}
