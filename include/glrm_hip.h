@@ -105,6 +105,23 @@ typedef struct glrm_reg {
   double scale;
 } glrm_reg; /* 16 bytes */
 
+/* Domains (src/domains.jl): how a column's values are imputed from the fitted model, used only by the post-fit evaluation
+ * entry points glrm_hip_impute / glrm_hip_error_metric (src/impute_and_err.jl). */
+enum glrm_domain_kind {
+  GLRM_DOMAIN_REAL = 0,        /* RealDomain() */
+  GLRM_DOMAIN_BOOL = 1,        /* BoolDomain(): values true (1.0) / false (0.0) */
+  GLRM_DOMAIN_ORDINAL = 2,     /* OrdinalDomain(lo, hi) */
+  GLRM_DOMAIN_PERIODIC = 3,    /* PeriodicDomain(T): lo = T */
+  GLRM_DOMAIN_COUNT = 4,       /* CountDomain(max_count): hi = max_count */
+  GLRM_DOMAIN_CATEGORICAL = 5, /* CategoricalDomain(1, hi) */
+  GLRM_DOMAIN_KIND_COUNT = 6
+};
+typedef struct glrm_domain {
+  int32_t kind;
+  int32_t reserved; /* must be 0 */
+  double lo, hi;
+} glrm_domain; /* 24 bytes */
+
 #define GLRM_PROBLEM_DEVICE_ARRAYS 1 /* flags bit 0: rowptr..colvals are DEVICE pointers (copied, not adopted) */
 
 /*
@@ -264,6 +281,15 @@ int glrm_hip_subset(glrm_handle* parent, const uint8_t* row_tags, const uint8_t*
  * reproduced.  singular_values (k) and iters_done may be NULL. */
 int glrm_hip_init_svd(glrm_handle* h, double* X, double* Y, int32_t max_iter, double tol, uint64_t seed, double* singular_values,
                       int32_t* iters_done);
+/* error_metric(glrm, X, Y, domains; standardize) (src/evaluate_fit.jl:107-153): over observed_examples, the squared error
+ * (Real / Ordinal / Count / Periodic domains) or 0-1 misclassification (Bool / Categorical) between A[i,j] and
+ * impute(domains[j], losses[j], (X'Y)[i, yidxs[j]]) (src/impute_and_err.jl:37-130); with standardize each column's sum is
+ * divided by the mean of A[i,j]^2 over its observed entries (when that is not 0).  domains: n descriptors.  Single-shard
+ * list handle.  Domain / loss pairs for which the reference throws (RealDomain + LogisticLoss) return GLRM_ERR_UNSUPPORTED. */
+int glrm_hip_error_metric(glrm_handle* h, const double* X, const double* Y, const glrm_domain* domains, int32_t standardize, double* out);
+/* impute(domains, losses, X'Y) (src/impute_and_err.jl:149-165, impute(glrm) src/evaluate_fit.jl:156): the full m x n matrix of
+ * imputed values, column-major (Ahat[i + j*m]), Bool columns as 1.0 / 0.0. */
+int glrm_hip_impute(glrm_handle* h, const double* X, const double* Y, const glrm_domain* domains, double* Ahat);
 /* Fixed-order sum of n device doubles (independent of the number of shards); synchronises. */
 int glrm_hip_sum(glrm_handle* h, const void* dvec, int64_t n, double* out);
 int glrm_hip_synchronize(glrm_handle* h);

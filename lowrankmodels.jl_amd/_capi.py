@@ -37,6 +37,7 @@ class CReg(C.Structure):
 
 LOSS_DTYPE = np.dtype([("kind", "<i4"), ("dim", "<i4"), ("scale", "<f8"), ("p0", "<f8"), ("p1", "<f8")])
 REG_DTYPE = np.dtype([("kind", "<i4"), ("wrap", "<i4"), ("scale", "<f8")])
+DOMAIN_DTYPE = np.dtype([("kind", "<i4"), ("reserved", "<i4"), ("lo", "<f8"), ("hi", "<f8")])  # glrm_domain, 24 bytes
 assert LOSS_DTYPE.itemsize == C.sizeof(CLoss) == 32 and REG_DTYPE.itemsize == C.sizeof(CReg) == 16
 
 
@@ -87,7 +88,7 @@ class CKernelStats(C.Structure):
 ABI_SYMBOLS = (
     "version", "last_error", "create", "destroy", "fit", "fit_sparse", "objective", "factor_ld", "bind_buffers",
     "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "gradstep_x", "gradstep_y", "col_losses", "row_penalties",
-    "col_penalties", "set_regularizers", "subset", "init_svd", "sum", "synchronize", "kernel_stats",
+    "col_penalties", "set_regularizers", "subset", "init_svd", "error_metric", "impute", "sum", "synchronize", "kernel_stats",
 )
 
 
@@ -133,6 +134,8 @@ class Api:
             "set_regularizers": (C.c_int, [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
             "subset": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(H)]),
             "init_svd": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_uint64, C.c_void_p, C.POINTER(C.c_int32)]),
+            "error_metric": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_double)]),
+            "impute": (C.c_int, [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
             "sum": (C.c_int, [H, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
             "synchronize": (C.c_int, [H]),
             "kernel_stats": (C.c_int, [H, C.POINTER(CKernelStats), C.c_int]),
@@ -269,6 +272,17 @@ class Api:
         it = C.c_int32(0)
         self._ck(self._f["init_svd"](h, _ptr(X), _ptr(Y), int(max_iter), float(tol), int(seed), _ptr(sv), C.byref(it)))
         return sv, it.value
+
+    def error_metric(self, h, X, Y, domains, standardize=False) -> float:
+        """domains: DOMAIN_DTYPE array, one per column."""
+        out = C.c_double(0.0)
+        self._ck(self._f["error_metric"](h, _ptr(X), _ptr(Y), _ptr(domains), 1 if standardize else 0, C.byref(out)))
+        return out.value
+
+    def impute(self, h, X, Y, domains, m, n):
+        Ahat = np.zeros((m, n), order="F")
+        self._ck(self._f["impute"](h, _ptr(X), _ptr(Y), _ptr(domains), _ptr(Ahat)))
+        return Ahat
 
     def sum(self, h, vec, n) -> float:
         out = C.c_double(0.0)

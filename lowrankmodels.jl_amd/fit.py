@@ -205,7 +205,9 @@ class ShardedFit:
         dist, sizes = self.dist, [(bounds[r + 1] - bounds[r]) * unit for r in range(self.world)]
         if self._inplace_ok and len(set(sizes)) == 1 and sizes[0] > 0:
             own = buf[bounds[self.rank] * unit: bounds[self.rank + 1] * unit]
-            dist.all_gather_into_tensor(buf, own, group=self.group)
+            # NCCL / RCCL allow sendbuff == recvbuff + rank * count; GLRM_GATHER_INPLACE=0 sends a copy of the block instead
+            src = own if os.environ.get("GLRM_GATHER_INPLACE", "1") != "0" else own.clone()
+            dist.all_gather_into_tensor(buf, src, group=self.group)
             return
         for r in range(self.world):
             if sizes[r]:

@@ -1572,3 +1572,153 @@ int glrm_cpu_init_svd(glrm_cpu_handle* h, double* X, double* Y, int32_t max_iter
   free(W); free(V); free(means); free(stds); free(sv); free(order);
   return GLRM_OK;
 }
+
+/* =====================================================================================================
+ * Post-fit evaluation: impute(D, l, u) and error_metric(D, l, u, a) (src/impute_and_err.jl:24-130), error_metric(glrm, X, Y,
+ * domains; standardize) (src/evaluate_fit.jl:107-153) and impute(domains, losses, X'Y) (src/impute_and_err.jl:149-165).
+ * ===================================================================================================== */
+static double roundcutoff_c(double x, double a, double b) { /* T(min(max(round(x),a),b)); Julia's round is half-to-even */
+  const double r = rint(x);
+  return fmin(fmax(r, a), b);
+}
+static int is_diff_loss_c(int kind) {
+  return kind == GLRM_LOSS_QUAD || kind == GLRM_LOSS_L1 || kind == GLRM_LOSS_HUBER || kind == GLRM_LOSS_QUANTILE || kind == GLRM_LOSS_PERIODIC;
+}
+
+/* returns the imputed value; *bad = 1 for pairs the reference rejects (or has no method for) */
+static double impute_c(const glrm_domain* D, const glrm_loss* l, const double* u, int* bad) {
+  const int d = l->dim > 1 ? l->dim : 1, kind = l->kind;
+  int dk = D->kind;
+  double lo = D->lo, hi = D->hi;
+  if (dk == GLRM_DOMAIN_COUNT) { dk = GLRM_DOMAIN_ORDINAL; lo = 0.0; } /* :124 */
+  if (d > 1) {
+    if (dk == GLRM_DOMAIN_CATEGORICAL && (kind == GLRM_LOSS_MULTINOMIAL || kind == GLRM_LOSS_OVA)) { /* argmax(u) :106-107 */
+      int best = 0;
+      for (int j = 1; j < d; ++j) if (u[j] > u[best]) best = j;
+      return best + 1;
+    }
+    if (dk == GLRM_DOMAIN_ORDINAL && kind == GLRM_LOSS_ORDISTIC) { /* argmin(u.^2) :82 */
+      int best = 0;
+      for (int j = 1; j < d; ++j) if (u[j] * u[j] < u[best] * u[best]) best = j;
+      return best + 1;
+    }
+    if (dk == GLRM_DOMAIN_ORDINAL && kind == GLRM_LOSS_MULTINOMIAL_ORDINAL) { /* :91-96 */
+      double v[GLRM_MAX_EMBEDDING_DIM], p[GLRM_MAX_EMBEDDING_DIM + 1];
+      for (int j = 0; j < d; ++j) v[j] = u[j];
+      enforce_mnl_ord_rules(v, d);
+      for (int j = 0; j < d; ++j) v[j] = exp(v[j]);
+      p[0] = 1 - v[0];
+      for (int j = 1; j < d; ++j) p[j] = -(v[j] - v[j - 1]);
+      p[d] = v[d - 1];
+      int best = 0;
+      for (int j = 1; j <= d; ++j) if (p[j] > p[best]) best = j;
+      return best + 1;
+    }
+    if (dk == GLRM_DOMAIN_ORDINAL && (kind == GLRM_LOSS_BVS || kind == GLRM_LOSS_OVA || kind == GLRM_LOSS_MULTINOMIAL)) { /* generic :98-100 */
+      if (kind == GLRM_LOSS_MULTINOMIAL && (lo < 1 || hi > d)) { *bad = 1; return 0.0; } /* u[a]: BoundsError in the reference */
+      int best = -1;
+      double bl = 0.0, w[GLRM_MAX_EMBEDDING_DIM];
+      for (int lev = (int)lo; lev <= (int)hi; ++lev) {
+        for (int j = 0; j < d; ++j) w[j] = u[j];
+        const double val = glrm_cpu_vloss_evaluate(l, w, (double)lev);
+        if (best < 0 || val < bl) { best = lev; bl = val; }
+      }
+      return best;
+    }
+    *bad = 1;
+    return 0.0;
+  }
+  const double u0 = u[0];
+  switch (dk) {
+    case GLRM_DOMAIN_REAL:
+    case GLRM_DOMAIN_PERIODIC: /* :113 */
+      if (is_diff_loss_c(kind)) return u0;                                   /* :39 */
+      if (kind == GLRM_LOSS_POISSON) return exp(u0);                         /* :40 */
+      if (kind == GLRM_LOSS_ORDINAL_HINGE) return roundcutoff_c(u0, l->p0, l->p1); /* :41 */
+      if (kind == GLRM_LOSS_WEIGHTED_HINGE) return 1 / u0;                   /* :43-46 */
+      *bad = 1;                                                              /* :42 */
+      return 0.0;
+    case GLRM_DOMAIN_BOOL:
+      if (kind == GLRM_LOSS_LOGISTIC || kind == GLRM_LOSS_WEIGHTED_HINGE) return u0 >= 0 ? 1.0 : 0.0; /* :57 */
+      return glrm_cpu_loss_evaluate(l, u0, 0.0) < glrm_cpu_loss_evaluate(l, u0, 1.0) ? 0.0 : 1.0;  /* :60 */
+    case GLRM_DOMAIN_ORDINAL:
+      if (is_diff_loss_c(kind) || kind == GLRM_LOSS_ORDINAL_HINGE) return roundcutoff_c(u0, lo, hi); /* :72,:74 */
+      if (kind == GLRM_LOSS_POISSON) return roundcutoff_c(exp(u0), lo, hi);                          /* :73 */
+      if (kind == GLRM_LOSS_LOGISTIC) return u0 > 0 ? hi : lo;                                        /* :75 */
+      if (kind == GLRM_LOSS_WEIGHTED_HINGE) return roundcutoff_c(u0 > 0 ? ceil(1 / u0) : floor(1 / u0), lo, hi); /* :76-80 */
+      *bad = 1;
+      return 0.0;
+    default:
+      *bad = 1;
+      return 0.0;
+  }
+}
+
+static double pos_mod_c(double T, double x) { return x > 0 ? fmod(x, T) : fmod(x, T) + T; } /* :116 */
+
+static double entry_error_c(const glrm_domain* D, double imp, double a) {
+  if (D->kind == GLRM_DOMAIN_BOOL || D->kind == GLRM_DOMAIN_CATEGORICAL) return imp == a ? 0.0 : 1.0; /* misclassification :33 */
+  if (D->kind == GLRM_DOMAIN_PERIODIC) { const double d = pos_mod_c(D->lo, imp) - pos_mod_c(D->lo, a); return d * d; }
+  return (imp - a) * (imp - a);
+}
+
+/* probe for the tests: impute(D, l, u) for one entry (u has embedding_dim(l) values) */
+double glrm_cpu_impute_entry(const glrm_domain* D, const glrm_loss* l, const double* u, int* bad) {
+  *bad = 0;
+  return impute_c(D, l, u, bad);
+}
+
+static int eval_checks(const glrm_cpu_handle* h, const glrm_domain* domains) {
+  if (!(h->row_begin == 0 && h->row_end == h->m && h->col_begin == 0 && h->col_end == h->n)) return fail(GLRM_ERR_INVALID, "needs a single-shard handle");
+  for (int64_t f = 0; f < h->n; ++f)
+    if (domains[f].kind < 0 || domains[f].kind >= GLRM_DOMAIN_KIND_COUNT || domains[f].reserved != 0)
+      return fail(GLRM_ERR_INVALID, "domain descriptor %lld is invalid", (long long)f);
+  return GLRM_OK;
+}
+
+int glrm_cpu_error_metric(glrm_cpu_handle* h, const double* X, const double* Y, const glrm_domain* domains, int32_t standardize, double* out) {
+  if (!h || !X || !Y || !domains || !out) return fail(GLRM_ERR_INVALID, "NULL argument");
+  int rc = eval_checks(h, domains);
+  if (rc) return rc;
+  const int k = h->k;
+  double err = 0.0, u[GLRM_MAX_EMBEDDING_DIM];
+  int bad = 0;
+  for (int64_t j = 0; j < h->n; ++j) { /* raw_error_metric / std_error_metric, src/evaluate_fit.jl:107-135 */
+    const glrm_loss* l = loss_of(h, j);
+    const int d = l->dim > 1 ? l->dim : 1;
+    double column_mean = 0.0, column_err = 0.0;
+    for (int64_t t = h->colptr[j]; t < h->colptr[j + 1]; ++t) {
+      dots_block(X + (int64_t)h->rowidx[t] * k, Y + h->ystart[j] * k, k, d, u);
+      const double a = h->colvals[t];
+      column_mean += a * a;
+      column_err += entry_error_c(&domains[j], impute_c(&domains[j], l, u, &bad), a);
+    }
+    if (standardize) {
+      column_mean = column_mean / (double)(h->colptr[j + 1] - h->colptr[j]);
+      if (column_mean != 0) column_err = column_err / column_mean;
+    }
+    err += column_err;
+  }
+  if (bad) return fail(GLRM_ERR_UNSUPPORTED, "a column's (domain, loss) pair has no imputation rule in the reference (src/impute_and_err.jl)");
+  *out = err;
+  return GLRM_OK;
+}
+
+int glrm_cpu_impute(glrm_cpu_handle* h, const double* X, const double* Y, const glrm_domain* domains, double* Ahat) {
+  if (!h || !X || !Y || !domains || !Ahat) return fail(GLRM_ERR_INVALID, "NULL argument");
+  int rc = eval_checks(h, domains);
+  if (rc) return rc;
+  const int k = h->k;
+  double u[GLRM_MAX_EMBEDDING_DIM];
+  int bad = 0;
+  for (int64_t f = 0; f < h->n; ++f) {
+    const glrm_loss* l = loss_of(h, f);
+    const int d = l->dim > 1 ? l->dim : 1;
+    for (int64_t i = 0; i < h->m; ++i) {
+      dots_block(X + i * k, Y + h->ystart[f] * k, k, d, u);
+      Ahat[i + f * h->m] = impute_c(&domains[f], l, u, &bad);
+    }
+  }
+  if (bad) return fail(GLRM_ERR_UNSUPPORTED, "a column's (domain, loss) pair has no imputation rule in the reference (src/impute_and_err.jl)");
+  return GLRM_OK;
+}

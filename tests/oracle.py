@@ -47,6 +47,8 @@ def oracle_lib():
         _lib.glrm_cpu_reg_evaluate_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib.glrm_cpu_reg_prox_block.restype = None
         _lib.glrm_cpu_reg_prox_block.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_double]
+        _lib.glrm_cpu_impute_entry.restype = C.c_double
+        _lib.glrm_cpu_impute_entry.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
         _lib.glrm_cpu_set_threads.argtypes = [C.c_int]
         _lib.glrm_cpu_set_dense_faithful.argtypes = [C.c_void_p, C.c_int]
         _lib.glrm_cpu_get_stepsizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
@@ -101,6 +103,19 @@ def vloss_grad(loss, u, a):
     g = np.zeros_like(u)
     oracle_lib().glrm_cpu_vloss_grad(C.addressof(st), u.ctypes.data, float(a), g.ctypes.data)
     return g
+
+
+def impute_entry(domain, loss, u):
+    """impute(D, l, u) of the oracle for one entry; raises TypeError for pairs the reference has no rule for."""
+    from lowrankmodels.jl_amd import _capi
+    st = _loss_struct(loss)
+    dom = np.array([domain.descriptor()], dtype=_capi.DOMAIN_DTYPE)
+    u = np.atleast_1d(np.asarray(u, dtype=np.float64)).copy()
+    bad = C.c_int(0)
+    v = oracle_lib().glrm_cpu_impute_entry(dom.ctypes.data, C.addressof(st), u.ctypes.data, C.byref(bad))
+    if bad.value:
+        raise TypeError("no impute rule")
+    return v
 
 
 def reg_evaluate_block(reg, a):
