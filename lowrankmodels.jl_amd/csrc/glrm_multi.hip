@@ -71,18 +71,21 @@ static int run_split_cols(glrm_handle* h, const MultiArgs& a) {
   const size_t lds_pass = ((size_t)2 * h->dmax * S + 16 + (size_t)8 * sl * (S + 64)) * 8;
   const size_t lds_dec = ((size_t)2 * h->dmax * S + 64 + 16) * 8;
   const dim3 grid((unsigned)a.nseg, (unsigned)sa.nsplit);
+  const bool small = h->dmax <= 8; // gradient registers per lane: 8 instead of 32 -> 4 waves per SIMD instead of 2
   hipStream_t st = h->stream;
   sa.point = a.own;
   if (a.mode == 1) { // losses only
     sa.round = -1;
-    hipLaunchKernelGGL((multi_colpass_kernel<false>), grid, dim3(512), lds_pass, st, sa);
+    if (small) hipLaunchKernelGGL((multi_colpass_kernel<false, 8>), grid, dim3(512), lds_pass, st, sa);
+    else hipLaunchKernelGGL((multi_colpass_kernel<false, GLRM_MAX_EMBEDDING_DIM>), grid, dim3(512), lds_pass, st, sa);
     hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
     HIPCK(hipGetLastError());
     return GLRM_OK;
   }
   sa.round = 0;
   HIPCK(hipMemsetAsync(h->mnactive, 0, 4, st));
-  hipLaunchKernelGGL((multi_colpass_kernel<true>), grid, dim3(512), lds_pass, st, sa);
+  if (small) hipLaunchKernelGGL((multi_colpass_kernel<true, 8>), grid, dim3(512), lds_pass, st, sa);
+  else hipLaunchKernelGGL((multi_colpass_kernel<true, GLRM_MAX_EMBEDDING_DIM>), grid, dim3(512), lds_pass, st, sa);
   hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
   HIPCK(hipGetLastError());
   if (a.mode == 2) return GLRM_OK;
@@ -94,7 +97,8 @@ static int run_split_cols(glrm_handle* h, const MultiArgs& a) {
     if (nact == 0) break;
     sa.round = round;
     HIPCK(hipMemsetAsync(h->mnactive, 0, 4, st));
-    hipLaunchKernelGGL((multi_colpass_kernel<false>), grid, dim3(512), lds_pass, st, sa);
+    if (small) hipLaunchKernelGGL((multi_colpass_kernel<false, 8>), grid, dim3(512), lds_pass, st, sa);
+    else hipLaunchKernelGGL((multi_colpass_kernel<false, GLRM_MAX_EMBEDDING_DIM>), grid, dim3(512), lds_pass, st, sa);
     hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
     HIPCK(hipGetLastError());
   }
@@ -141,7 +145,8 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
     return run_split_cols(h, a);
   } else {
     const size_t lds = multi_lds_doubles(false, 8, h->kp, h->dmax, a.lgP) * 8;
-    hipLaunchKernelGGL((multi_sweep_kernel<false, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+    if (h->dmax <= 8) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+    else hipLaunchKernelGGL((multi_sweep_kernel<false, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
   }
   HIPCK(hipGetLastError());
   return GLRM_OK;

@@ -412,10 +412,10 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
 // up in lane j), the loss and its d-vector gradient are evaluated lane-parallel (vloss_lanes), and lane `sub` accumulates
 // component `sub` of the gradient.  Index / value loads run two wave-iterations ahead and (columns) the opposing row
 // one iteration ahead.  Slot partials are combined in slot order, wave partials in wave order.
-template <bool ROWS, int NW, bool GRAD>
+template <bool ROWS, int NW, bool GRAD, int GDC = GLRM_MAX_EMBEDDING_DIM>
 __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, const double* own, double* wbase, double* Gt, double* red,
                                     const LossDesc& lseg, int dseg) {
-  constexpr int NT = NW * 64, GD = ROWS ? 1 : GLRM_MAX_EMBEDDING_DIM;
+  constexpr int NT = NW * 64, GD = ROWS ? 1 : GDC; // GDC >= the largest embedding dimension of the problem
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lg = a.lgP, P = 1 << lg, SL = 64 >> lg, slot = lane >> lg, sub = lane & (P - 1);
   const int S = a.kp + 1, k = a.k, kp = a.kp;
@@ -548,8 +548,8 @@ __host__ __device__ inline size_t multi_lds_doubles(bool rows, int nw, int kp, i
   return 3 * docap * S + 64 + 16 + (size_t)nw * sl * (dtcap * S + 64);
 }
 
-template <bool ROWS, int NW>
-__global__ void __launch_bounds__(NW * 64) multi_sweep_kernel(const MultiArgs a) {
+template <bool ROWS, int NW, int GDC = GLRM_MAX_EMBEDDING_DIM>
+__global__ void __launch_bounds__(NW * 64, NW == 1 ? 4 : 2) multi_sweep_kernel(const MultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NT = NW * 64;
   const int tid = threadIdx.x, wave = tid >> 6;
@@ -580,11 +580,11 @@ __global__ void __launch_bounds__(NW * 64) multi_sweep_kernel(const MultiArgs a)
   const glrm_reg rg = a.regs[a.reg_single ? 0 : s];
 
   if (a.mode == 1) { // losses only
-    const double tot = multi_pass<ROWS, NW, false>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
+    const double tot = multi_pass<ROWS, NW, false, GDC>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
     if (tid == 0 && a.obj) a.obj[gseg] = tot;
     return;
   }
-  const double loss_old = multi_pass<ROWS, NW, true>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
+  const double loss_old = multi_pass<ROWS, NW, true, GDC>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
   const double l1 = (double)(e - b) + 1;
   if (a.mode == 2) { // sparse_proxgrad.jl:72-78 / :94-99: scale the gradient, add, prox -- no line search
     const double st = a.fixed_alpha / l1;
@@ -608,7 +608,7 @@ __global__ void __launch_bounds__(NW * 64) multi_sweep_kernel(const MultiArgs a)
     }
     __syncthreads();
     block_prox<NW>(ownB, S, k, DO, rg, stepsize, tmp);
-    const double nloss = multi_pass<ROWS, NW, false>(a, b, e, ownB, wbase, Gt, red, lseg, dseg);
+    const double nloss = multi_pass<ROWS, NW, false, GDC>(a, b, e, ownB, wbase, Gt, red, lseg, dseg);
     const double nobj = nloss + block_reg_eval<NW>(ownB, S, k, DO, rg, red);
     ++ntr;
     if (nobj < obj) {
@@ -653,8 +653,8 @@ struct SplitArgs {
   unsigned int* nactive;
 };
 
-template <bool GRAD>
-__global__ void __launch_bounds__(512) multi_colpass_kernel(const SplitArgs sa) {
+template <bool GRAD, int GDC>
+__global__ void __launch_bounds__(512, (GRAD && GDC > 8) ? 2 : 4) multi_colpass_kernel(const SplitArgs sa) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NW = 8, NT = NW * 64;
   const MultiArgs& a = sa.m;
@@ -678,7 +678,7 @@ __global__ void __launch_bounds__(512) multi_colpass_kernel(const SplitArgs sa) 
   int64_t b = b0 + (int64_t)y * sa.chunk, e = b + sa.chunk;
   b = b < e0 ? b : e0;
   e = e < e0 ? e : e0;
-  const double tot = multi_pass<false, NW, GRAD>(a, b, e, own, wbase, Gt, red, lseg, dseg);
+  const double tot = multi_pass<false, NW, GRAD, GDC>(a, b, e, own, wbase, Gt, red, lseg, dseg);
   if (tid == 0) sa.part_loss[s * sa.nsplit + y] = tot;
   if constexpr (GRAD) {
     double* pg = sa.part_G + ((size_t)s * sa.nsplit + y) * a.dmax * kp;
