@@ -141,9 +141,10 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
   if (rows) {
     const size_t lds = multi_lds_doubles(true, 1, h->kp, h->dmax, a.lgP) * 8;
     hipLaunchKernelGGL((multi_sweep_kernel<true, 1>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
-  } else if (({ int rc_ = setup_split(h); if (rc_) return rc_; h->col_nsplit > 1; })) {
-    return run_split_cols(h, a);
   } else {
+    const int rc = setup_split(h); // decides once per handle whether the columns are long enough to split
+    if (rc) return rc;
+    if (h->col_nsplit > 1) return run_split_cols(h, a);
     const size_t lds = multi_lds_doubles(false, 8, h->kp, h->dmax, a.lgP) * 8;
     if (h->dmax <= 8) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
     else hipLaunchKernelGGL((multi_sweep_kernel<false, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
