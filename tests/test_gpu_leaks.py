@@ -1,0 +1,56 @@
+"""-m gpu: every entry point releases what it allocates: device memory in use returns to its level after repeated
+create / fit / subset / init_svd / error_metric / destroy cycles on all kernel families."""
+import numpy as np
+import pytest
+
+import cases
+import lowrankmodels.jl_amd as L
+from lowrankmodels.jl_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+def free_bytes():
+    import torch
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info()[0]
+
+
+def cycle(kind, rng):
+    api = _capi.hip_api()
+    if kind == "tiled":
+        m, n, k = 6000, 300, 16
+        A = rng.standard_normal((m, k)) @ rng.standard_normal((k, n))
+        g = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.1), k, obs=np.nonzero(rng.random((m, n)) < 0.5))
+    elif kind == "dense":
+        A = rng.standard_normal((512, 256))
+        g = L.GLRM(A, L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), 16)
+    else:  # general sweeps with split columns
+        kwargs, _ = cases.build_multidim_case("loss_test")
+        g = L.GLRM(**kwargs)
+    L.fit_b(g, L.HipProxGradParams(max_iter=3), verbose=False)
+    if kind != "dense":
+        h = g._handle_cache[1]
+        tags = rng.integers(0, 2, len(g._colidx)).astype(np.uint8)
+        ctags = rng.integers(0, 2, len(g._rowidx)).astype(np.uint8)
+        hc = api.subset(h, tags, ctags, 1, False)
+        api.destroy(hc)
+        L.error_metric(g)
+        if kind == "tiled":
+            L.init_svd_(g, tol=1e-6)
+        L.fit_b(g, L.SparseProxGradParams(max_iter=3), verbose=False)
+    g.close()
+
+
+@pytest.mark.parametrize("kind", ["tiled", "dense", "general"])
+def test_no_device_memory_leak(kind, monkeypatch):
+    if kind == "general":
+        monkeypatch.setenv("GLRM_HIP_MULTI_CHUNK", "16")  # force the split column sweeps and their buffers
+    rng = np.random.default_rng(0)
+    cycle(kind, rng)          # first use: library / context one-time allocations
+    cycle(kind, rng)
+    before = free_bytes()
+    for _ in range(15):
+        cycle(kind, rng)
+    after = free_bytes()
+    assert before - after < 8 << 20, f"{(before - after) / 2**20:.1f} MiB not returned after 15 cycles"
