@@ -83,3 +83,17 @@ def test_pipelined_x_exchange_equals_one_rank(tmp_path):
         for z in ranks:
             assert np.array_equal(z[name + "_X"], X) and np.array_equal(z[name + "_Y"], Y), name
             assert np.array_equal(z[name + "_obj"][1:], np.array(ch.objective[1:])), name
+
+
+def test_two_ranks_multidimensional_losses(tmp_path):
+    """Columns that own several vectors of Y: the Y exchange moves the span [ystart[cb], ystart[ce]) of each rank's block."""
+    names = ["mnl_ordinal", "loss_test"]
+    ranks = run_world(tmp_path, names, 2, {"GLRM_GATHER": "allgather"})
+    O.set_threads(1)
+    for name in names:
+        kwargs, params = cases.build_golden_case(name)
+        g = L.GLRM(**kwargs)
+        X, Y, ch = L.fit_b(g, params, verbose=False, engine=O.oracle_api())
+        for z in ranks:
+            assert np.array_equal(z[name + "_X"], X) and np.array_equal(z[name + "_Y"], Y), name
+            assert np.array_equal(z[name + "_obj"][1:], np.array(ch.objective[1:])), name
