@@ -1,6 +1,6 @@
 """Driver-level fusion: time per fold of building the train / test models of a k-fold cross-validation
 (a) from host arrays (upload 12 B per observation and view) vs (b) as glrm_hip_subset of the resident parent handle (1 tag byte
-per observation and view), plus the fit time for scale.   python tools/bench_cv.py --m 200000 --n 10000 --q 500 --k 32"""
+per observation and view), plus the fit time for scale.   python tests/perf/bench_cv.py --m 200000 --n 10000 --q 500 --k 32"""
 import argparse
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import lowrankmodels.jl_amd as L  # noqa: E402

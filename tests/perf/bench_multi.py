@@ -1,7 +1,7 @@
 """Time the general sweeps (multi-dimensional losses) on a categorical model: m rows x n columns with K levels each,
 MultinomialLoss / BvSLoss / MultinomialOrdinalLoss columns, rank k, fully observed.  Prints ms per half-step and
 observation-updates/s; with --cpu also times the oracle on the same model.
-    python tools/bench_multi.py --m 200000 --n 100 --K 5 --k 10 --iters 5 [--cpu]
+    python tests/perf/bench_multi.py --m 200000 --n 100 --K 5 --k 10 --iters 5 [--cpu]
 """
 import argparse
 import os
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import lowrankmodels.jl_amd as L  # noqa: E402

@@ -1,6 +1,6 @@
 """init_svd! at scale: glrm_hip_init_svd on the synthetic workload of BASELINE config 2 generated in HBM,
 next to scipy's Arpack svds (what the reference calls, src/initialize.jl:121) on a host sample of the same generator.
-    python tools/bench_svd.py --m 1000000 --n 10000 --q 500 --k 32 [--cpu-rows 50000]"""
+    python tests/perf/bench_svd.py --m 1000000 --n 10000 --q 500 --k 32 [--cpu-rows 50000]"""
 import argparse
 import os
 import sys
@@ -8,7 +8,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from lowrankmodels.jl_amd import _capi  # noqa: E402

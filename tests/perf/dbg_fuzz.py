@@ -1,6 +1,6 @@
-"""Per-iteration objective agreement (HIP vs oracle) of the fuzz models: python tools/dbg_fuzz.py 1 16 17 ..."""
+"""Per-iteration objective agreement (HIP vs oracle) of the fuzz models: python tests/perf/dbg_fuzz.py 1 16 17 ..."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, cases, oracle as O
 import importlib.util

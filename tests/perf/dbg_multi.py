@@ -1,7 +1,7 @@
 """Debug helper: one X half-step and one Y half-step on the oracle and on the HIP engine from the same state.
-    python tools/dbg_multi.py <case name | custom:LOSS,LOSS,...>   e.g. custom:ova3,bvs5,quad"""
+    python tests/perf/dbg_multi.py <case name | custom:LOSS,LOSS,...>   e.g. custom:ova3,bvs5,quad"""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, cases, oracle as O
 import lowrankmodels.jl_amd as L
