@@ -2,6 +2,8 @@
 // Separate translation unit so that the two kernel families compile in parallel.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "glrm_engine.hpp"
 #include "glrm_tiled.hpp"
 
@@ -55,6 +57,15 @@ int glrm_setup_tiled(glrm_handle* h) {
     HIPCK(hipMalloc((void**)&h->activebuf, (size_t)nl1 * 4));
     HIPCK(hipMalloc((void**)&h->ntrialbuf, (size_t)nl1 * 4));
     HIPCK(hipMalloc((void**)&h->nactive, 4));
+    if (h->n_losses > 1) { // per-column losses: give every wave columns of ONE loss kind (no divergent loss branches)
+      std::vector<int32_t> perm((size_t)h->nl);
+      for (int64_t f = 0; f < h->nl; ++f) perm[f] = (int32_t)f;
+      const glrm_loss* lt = h->losses_h.data() + h->cb;
+      std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return lt[x].kind < lt[y].kind; });
+      HIPCK(hipMalloc((void**)&h->colperm, (size_t)nl1 * 4));
+      HIPCK(hipMemcpyAsync(h->colperm, perm.data(), (size_t)h->nl * 4, hipMemcpyHostToDevice, st));
+      HIPCK(hipStreamSynchronize(st)); // perm is a local
+    }
   }
   return GLRM_OK;
 }
@@ -168,6 +179,7 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
   a.tiles_per_sup = h->tiles_per_sup;
   a.part = h->part; a.gsum = h->gsum; a.trial = h->trialbuf; a.jold = h->joldbuf;
   a.active = h->activebuf; a.ntrial = h->ntrialbuf; a.nactive = h->nactive;
+  a.segperm = h->colperm;
   int rc;
   HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
   if ((rc = launch_tiled(h, loss, 1, a))) return rc;

@@ -54,6 +54,8 @@ struct TiledArgs {
   int eval_only;         // col_reduce: obj = sum of losses, nothing else
   int64_t dense_len;     // ptr == nullptr (dense problem): every segment has this many observations
   double fixed_alpha;    // > 0: one prox-gradient step with this global step size, no line search
+  const int32_t* segperm; // column passes: lane-group slot -> local segment (nullptr = identity).  Heterogeneous models sort
+                          // the columns by loss kind so that the 16 groups of a wave evaluate the same loss formula.
 };
 
 template <int G>
@@ -385,9 +387,10 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_col_pass_kernel(const TiledA
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % G, gi = lane / G;
-  const int64_t seg = (int64_t)blockIdx.x * SPB + wave * NGW + gi;
+  const int64_t slot = (int64_t)blockIdx.x * SPB + wave * NGW + gi;
   const int sup = blockIdx.y;
-  bool have = seg < a.nseg;
+  bool have = slot < a.nseg;
+  const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[slot] : slot; // which column a group works on does not change any sum
   if (!GRAD && have) have = a.active[seg] != 0;
   if (!GRAD && !__syncthreads_or(have ? 1 : 0)) return; // nothing left to evaluate in this column group
   const int64_t beg = have ? a.ptr[seg] : 0, end = have ? a.ptr[seg + 1] : 0;
