@@ -6,7 +6,8 @@ Differences from the Julia type that a user can see:
   * the losses and regularizers of include/glrm_hip.h are accepted (nine scalar losses, five multi-dimensional ones,
     five base regularizers and their offset / ordinal wrappers); everything else is outside the accelerated path
     (SURVEY.md section 2);
-  * ``scale=True`` (equilibrate_variance!) is out of scope -> NotImplementedError.
+  * ``scale=True`` (equilibrate_variance!) runs for scalar losses; the reference's M-estimators of the multi-dimensional
+    losses do not execute, so that combination raises NotImplementedError.
 """
 from __future__ import annotations
 
@@ -104,8 +105,8 @@ class GLRM:
         Y = np.asarray(Y, dtype=np.float64)
         if Y.shape != (k, d):
             raise ValueError("Y must be of size (k,d) where d is the sum of the embedding dimensions of all the losses.")
-        if scale:
-            raise NotImplementedError("scale=true needs the M-estimators (src/modify_glrm.jl:34-58), outside the accelerated path")
+        if scale and d != n:
+            raise NotImplementedError("scale=true with multi-dimensional losses: their M-estimators do not run in the reference either")
 
         self.A, self.losses, self.rx, self.ry, self.k = A, losses, rx, ry, k
         self.X = np.array(X, dtype=np.float64, order="F")
@@ -142,6 +143,9 @@ class GLRM:
         self._rowvals = self._gather(np.repeat(np.arange(m, dtype=np.int64), np.diff(rowptr)), colidx.astype(np.int64), checknan)
         self._colvals = self._gather(rowidx.astype(np.int64), np.repeat(np.arange(n, dtype=np.int64), np.diff(colptr)), False)
         self._handle_cache = None
+        if scale:   # equilibrate_variance!(glrm) BEFORE add_offset!, src/glrm.jl:73-78
+            from .scaling import equilibrate_variance_
+            equilibrate_variance_(self)
         if offset:  # add_offset!(glrm), src/glrm.jl:76-78, src/modify_glrm.jl:21-24
             add_offset_(self)
 
