@@ -6,7 +6,7 @@ import pytest
 import cases
 import lowrankmodels.jl_amd as L
 import oracle as O
-from lowrankmodels.jl_amd import _capi
+from lowrankmodels.jl_amd import _capi, crossval
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -63,7 +63,7 @@ def test_subset_child_outlives_parent_and_keeps_kernel_family():
     api = hip()
     h = api.create(g.problem_arrays(), tiled=2)
     tags_r = (rng.random(len(g._colidx)) < 0.2).astype(np.uint8)
-    sp = __import__("lowrankmodels.jl_amd.crossval", fromlist=["_Split"])._Split(g)
+    sp = crossval._Split(g)
     hc = api.subset(h, tags_r, tags_r[sp.perm], 1, True)
     api.destroy(h)
     try:
