@@ -10,10 +10,15 @@
  * Reference interfaces replaced (paths relative to the LowRankModels.jl tree):
  *   glrm_params    <- ProxGradParams                src/algorithms/proxgrad.jl:4-31
  *   glrm_problem   <- GLRM struct + Omega lists     src/glrm.jl:12-22, src/modify_glrm.jl:5-18
- *   glrm_loss      <- Loss subtypes (scalar)        src/losses.jl:138-352
- *   glrm_reg       <- Regularizer subtypes          src/regularizers.jl:52-114,295-318
+ *   glrm_loss      <- Loss subtypes                 src/losses.jl:138-352 (scalar), :360-620 (multi-dimensional)
+ *   glrm_reg       <- Regularizer subtypes          src/regularizers.jl:52-114,295-318; wrappers :163-189,356-411
+ *   glrm_domain    <- Domain subtypes               src/domains.jl
  *   glrm_hip_fit   <- fit!(::GLRM,::ProxGradParams) src/algorithms/proxgrad.jl:34-220
+ *   glrm_hip_fit_sparse <- fit!(::GLRM,::SparseProxGradParams) src/algorithms/sparse_proxgrad.jl:22-134
  *   glrm_hip_objective <- objective(glrm,X,Y;...)   src/evaluate_fit.jl:57-81
+ *   glrm_hip_init_svd  <- init_svd!(glrm)           src/initialize.jl:35-132
+ *   glrm_hip_subset    <- fold models of cross_validate / cv_by_iter / regularization_path   src/cross_validate.jl:20-37,54-105
+ *   glrm_hip_error_metric / glrm_hip_impute <- error_metric / impute   src/evaluate_fit.jl:107-168, src/impute_and_err.jl
  *   objective/seconds arrays <- ConvergenceHistory  src/convergence.jl:3-27
  *
  * Conventions
