@@ -41,12 +41,32 @@ int glrm_setup_tiled(glrm_handle* h) {
   // GLRM_HIP_TILED (tuning): bit0 rows, bit1 columns; overrides the option.
   int want = h->tiled_opt == 1 ? 0 : (h->tiled_opt == 2 ? 3 : -1);
   want = env_int("GLRM_HIP_TILED", want);
-  h->tiled_row = h->rows_sorted && (want < 0 ? (per_tile_r >= 4.0 && h->ml >= 2048) : (want & 1)) ? 1 : 0;
-  h->tiled_col = h->cols_sorted && (want < 0 ? (per_tile_c >= 4.0 && h->nl >= 256) : ((want >> 1) & 1)) ? 1 : 0;
+  // Auto choice (measured on MI355X, tests/perf/bench_small.py): the tiled sweeps need enough workgroups to fill 256 CUs and
+  // enough observations to amortise their per-tile barriers; below ~2e7 observations per view the gather sweeps win (100k x 5k
+  // at 1e7 observations: 1.06 vs 1.23 ms per iteration; 300k x 3k at 4.5e7: 4.6 vs 3.1 ms).
+  const int spb_auto = (h->tile_cfg ? 16 : 8) * (64 / h->tG);
+  const bool big_r = h->nnz_r >= 20000000 && h->ml >= (int64_t)512 * spb_auto;
+  const bool big_c = h->nnz_c >= 20000000 && h->nl >= 256;
+  h->tiled_row = h->rows_sorted && (want < 0 ? (per_tile_r >= 4.0 && big_r) : (want & 1)) ? 1 : 0;
+  h->tiled_col = h->cols_sorted && (want < 0 ? (per_tile_c >= 4.0 && big_c) : ((want >> 1) & 1)) ? 1 : 0;
   // super-tiles of ~32k rows: a function of (m, tile) only -- never of the shard layout -- so the partial-sum order
   // (and the result bits) do not depend on the GPU count, while long columns still spread over enough workgroups
   const int64_t ntiles = (h->m + T - 1) / T;
-  h->tiles_per_sup = 32768 / T > 1 ? 32768 / T : 1;
+  {
+    // enough (column group, super-tile) workgroups to fill the chip a few times over: the column groups come from the GLOBAL n
+    // (256 columns per 16-wave workgroup at G=4), so the super-tile size -- hence the order of the partial sums -- is a function
+    // of (m, n, tile) only, never of the shard layout
+    const int spb = (h->tile_cfg ? 16 : 8) * (64 / h->tG);
+    const int64_t groups = (h->n + spb - 1) / spb;
+    const int64_t want_wg = env_int("GLRM_HIP_COL_WORKGROUPS", 1024);
+    int64_t nsup_target = (want_wg + groups - 1) / groups;
+    if (nsup_target < 1) nsup_target = 1;
+    int64_t tps = ntiles / nsup_target;
+    const int64_t tps_max = 32768 / T > 1 ? 32768 / T : 1; // at most ~32k rows per super-tile (long columns still spread out)
+    if (tps > tps_max) tps = tps_max;
+    if (tps < 1) tps = 1;
+    h->tiles_per_sup = (int)tps;
+  }
   h->nsup = (int)((ntiles + h->tiles_per_sup - 1) / h->tiles_per_sup);
   if (h->tiled_col) {
     const int64_t nl1 = h->nl > 0 ? h->nl : 1;
