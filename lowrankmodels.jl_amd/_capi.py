@@ -92,6 +92,32 @@ ABI_SYMBOLS = (
 )
 
 
+#: Bumped whenever a loss / regularizer object is created or modified or a model's descriptor list changes: lets a model reuse
+#: its packed descriptors (and its engine handle) without re-reading a million Python objects per fit! call.
+EPOCH = [0]
+
+
+def bump_epoch():
+    EPOCH[0] += 1
+
+
+class TrackedList(list):
+    """A list whose mutations bump EPOCH (the losses / rx / ry lists of a GLRM)."""
+
+    def _mut(name):  # noqa: N805
+        base = getattr(list, name)
+
+        def f(self, *a, **k):
+            bump_epoch()
+            return base(self, *a, **k)
+        f.__name__ = name
+        return f
+
+    for _n in ("__setitem__", "__delitem__", "__iadd__", "__imul__", "append", "extend", "insert", "pop", "remove", "clear", "sort", "reverse"):
+        locals()[_n] = _mut(_n)
+    del _n, _mut
+
+
 def _ptr(a):
     """numpy array -> address; int -> address; None -> NULL."""
     if a is None:

@@ -15,7 +15,7 @@ import copy as _copy
 
 import numpy as np
 
-from ._capi import ProblemArrays
+from ._capi import EPOCH, ProblemArrays, TrackedList
 from .losses import Loss, embedding_dim, get_yidxs, pack_losses
 from .regularizers import OrdinalReg, Regularizer, lastentry1, lastentry_unpenalized, pack_regs
 
@@ -108,7 +108,8 @@ class GLRM:
         if scale and d != n:
             raise NotImplementedError("scale=true with multi-dimensional losses: their M-estimators do not run in the reference either")
 
-        self.A, self.losses, self.rx, self.ry, self.k = A, losses, rx, ry, k
+        self.A, self.losses, self.rx, self.ry, self.k = A, TrackedList(losses), TrackedList(rx), TrackedList(ry), k
+        self._dk_cache = None
         self.X = np.array(X, dtype=np.float64, order="F")
         self.Y = np.array(Y, dtype=np.float64, order="F")
         self.m, self.n, self.d = m, n, d
@@ -226,8 +227,14 @@ class GLRM:
     def _descriptor_key(self):
         """(what forces a new engine handle, what can be updated in place): losses are baked into the handle's
         validation and kernel choice; regularizer descriptors can be replaced as long as their counts stay."""
+        tracked = all(isinstance(x, TrackedList) for x in (self.losses, self.rx, self.ry))
+        fp = (EPOCH[0], id(self.losses), id(self.rx), id(self.ry)) if tracked else None
+        if fp is not None and self._dk_cache is not None and self._dk_cache[0] == fp:
+            return self._dk_cache[1]
         rx, ry = pack_regs(self.rx), pack_regs(self.ry)
-        return (pack_losses(self.losses).tobytes(), len(rx), len(ry)), (rx.tobytes(), ry.tobytes())
+        key = (pack_losses(self.losses).tobytes(), len(rx), len(ry)), (rx.tobytes(), ry.tobytes())
+        self._dk_cache = (fp, key)
+        return key
 
     def close(self):
         """Release the cached engine handle (device copies of Omega)."""
@@ -246,8 +253,8 @@ class GLRM:
 def add_offset_(glrm):
     """add_offset!(glrm) (src/modify_glrm.jl:21-24): the last latent feature of every row is pinned to 1 and the last row
     of Y is not penalised -- an unpenalised per-column offset.  OrdinalReg / MNLOrdinalReg already exempt their last row."""
-    glrm.rx = [lastentry1(r) for r in glrm.rx]
-    glrm.ry = [lastentry_unpenalized(r) for r in glrm.ry]
+    glrm.rx = TrackedList(lastentry1(r) for r in glrm.rx)
+    glrm.ry = TrackedList(lastentry_unpenalized(r) for r in glrm.ry)
     return glrm
 
 

@@ -12,7 +12,7 @@ import math
 
 import numpy as np
 
-from ._capi import LOSS_DTYPE
+from ._capi import LOSS_DTYPE, bump_epoch as _bump_epoch
 
 QUAD, L1, HUBER, QUANTILE, PERIODIC, POISSON, ORDINAL_HINGE, LOGISTIC, WEIGHTED_HINGE = range(9)
 MULTINOMIAL, OVA, BVS, ORDISTIC, MULTINOMIAL_ORDINAL = range(9, 14)
@@ -48,6 +48,10 @@ def myBool(a):
 class Loss:
     kind = -1
     classification = False  # ClassificationLoss (src/losses.jl:56)
+
+    def __setattr__(self, name, value):  # any change of a descriptor field invalidates cached packed descriptors
+        object.__setattr__(self, name, value)
+        _bump_epoch()
 
     def __init__(self, scale=1.0):
         self.scale = float(scale)

@@ -9,13 +9,17 @@ import copy as _copy
 
 import numpy as np
 
-from ._capi import REG_DTYPE
+from ._capi import REG_DTYPE, bump_epoch as _bump_epoch
 
 ZERO, QUAD, ONE, NONNEG, UNIT_ONE_SPARSE = range(5)
 
 
 class Regularizer:
     kind = -1
+
+    def __setattr__(self, name, value):  # any change of a descriptor field invalidates cached packed descriptors
+        object.__setattr__(self, name, value)
+        _bump_epoch()
 
     def __init__(self, scale=1.0):
         self.scale = float(scale)
