@@ -80,8 +80,9 @@ def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, 
 
     ``engine`` is a test hook (an ``_capi.Api``); the product default is the HIP library.
     """
-    if params is None:
-        params = HipProxGradParams()
+    if params is None:  # src/fit.jl:13-18: a SparseMatrixCSC model defaults to the sparse solver, everything else to prox-grad
+        from .glrm import _issparse
+        params = SparseProxGradParams() if _issparse(glrm.A) else HipProxGradParams()
     if not isinstance(params, AbstractParams):
         raise TypeError("params must be an AbstractParams (ProxGradParams / HipProxGradParams)")
     sparse = isinstance(params, SparseProxGradParams)

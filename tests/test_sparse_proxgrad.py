@@ -153,3 +153,16 @@ def test_hip_sparse_proxgrad_matches_oracle(case):
         X, Y, ch = L.fit_b(g, L.SparseProxGradParams(2.0, max_iter=30), verbose=False)
         assert cases.rel_err(ch.objective, o_c) < 1e-5
         g.close()
+
+
+def test_default_solver_follows_the_reference_dispatch():
+    """fit!(glrm) without params: SparseMatrixCSC input -> SparseProxGradParams, dense input -> ProxGradParams (src/fit.jl:13-18)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(0)
+    A = sp.random(30, 20, density=0.3, random_state=1, format="csc")
+    g = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.1), 3, rng=rng)
+    _, _, ch = L.fit_b(g, verbose=False, engine=O.oracle_api())
+    assert ch.name == "SparseProxGradGLRM"
+    gd = L.GLRM(A.toarray(), L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.1), 3, rng=rng)
+    _, _, chd = L.fit_b(gd, verbose=False, engine=O.oracle_api())
+    assert chd.name == "ProxGradGLRM"
