@@ -90,6 +90,12 @@ struct glrm_handle {
   int32_t *trials_r = nullptr, *accepts_r = nullptr, *trials_c = nullptr, *accepts_c = nullptr;
   int waves_row = 1, waves_col = 4;
   int profile = 0;
+  // hipGraph of one outer iteration (gather sweeps on a private stream): small fits are launch bound
+  hipGraph_t iter_graph = nullptr;
+  hipGraphExec_t iter_exec = nullptr;
+  double* pinned_obj = nullptr;       // host-pinned scalar the graph copies sum(obj_by_col) into
+  int64_t graph_ix = 0, graph_iy = 0; // inner iteration counts the graph was captured for
+  double graph_min = 0.0, graph_step = 0.0;
   // what glrm_hip_subset needs to build a child handle: the options and host copies of the descriptors
   glrm_options opts{};
   int wr_opt = 0, wc_opt = 0;

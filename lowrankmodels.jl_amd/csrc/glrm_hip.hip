@@ -501,6 +501,9 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
                   h->mobjold, h->mactive, h->mnactive, h->colperm};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (h->iter_exec) (void)hipGraphExecDestroy(h->iter_exec);
+  if (h->iter_graph) (void)hipGraphDestroy(h->iter_graph);
+  if (h->pinned_obj) (void)hipHostFree(h->pinned_obj);
   for (auto& e : h->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -648,6 +651,7 @@ extern "C" int glrm_hip_bind_buffers(glrm_handle* h, void* dX, void* dY, void* d
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
   DeviceGuard dg(h->device);
   h->X = (double*)dX; h->Y = (double*)dY; h->objcol = (double*)dObjCol; h->objrow = (double*)dObjRow;
+  if (h->iter_exec) { (void)hipGraphExecDestroy(h->iter_exec); h->iter_exec = nullptr; } // the captured launches hold the old pointers
   return ensure_owned(h);
 }
 
@@ -1000,6 +1004,43 @@ extern "C" int glrm_hip_objective(glrm_handle* h, const double* X, const double*
   return device_objective(h, include_reg, out);
 }
 
+// One outer iteration as a hipGraph.  Eligible: gather sweeps (fixed launch sequence, no host round trips inside a half-step) on
+// the handle's private stream (the legacy default stream cannot be captured), no per-launch event timing.
+static bool graph_eligible(const glrm_handle* h) {
+  return h->own_stream && !h->profile && !h->multi && !h->dense && !h->tiled_row && !h->tiled_col && env_int("GLRM_HIP_GRAPH", 1) != 0;
+}
+
+static int build_iteration_graph(glrm_handle* h, const glrm_params* prm) {
+  if (h->iter_exec && h->graph_ix == prm->inner_iter_X && h->graph_iy == prm->inner_iter_Y && h->graph_min == prm->min_stepsize &&
+      h->graph_step == prm->stepsize)
+    return GLRM_OK;
+  if (h->iter_exec) { (void)hipGraphExecDestroy(h->iter_exec); h->iter_exec = nullptr; }
+  if (h->iter_graph) { (void)hipGraphDestroy(h->iter_graph); h->iter_graph = nullptr; }
+  if (!h->pinned_obj) HIPCK(hipHostMalloc((void**)&h->pinned_obj, 8, hipHostMallocDefault));
+  int rc = ensure_owned(h);
+  if (rc) return rc;
+  HIPCK(hipStreamSynchronize(h->stream));
+  if (hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return GLRM_OK; } // no graph: plain launches
+  bool ok = true;
+  const int64_t lx = h->launches_x, ly = h->launches_y;
+  if (prm->inner_iter_X > 1 || prm->inner_iter_Y > 1) ok = ok && glrm_hip_reset_stepsizes(h, prm->stepsize) == GLRM_OK;
+  for (int64_t in = 0; ok && in < prm->inner_iter_X; ++in) ok = run_sweep(h, 0, prm->min_stepsize, 0) == GLRM_OK;
+  for (int64_t in = 0; ok && in < prm->inner_iter_Y; ++in) ok = run_sweep(h, 1, prm->min_stepsize, 0) == GLRM_OK;
+  if (ok) {
+    hipLaunchKernelGGL(sum_stage1, dim3(SUM_BLOCKS), dim3(SUM_THREADS), 0, h->stream, (const double*)h->objcol, h->n, h->partials);
+    hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(SUM_THREADS), 0, h->stream, h->partials, h->dscalar);
+    ok = hipMemcpyAsync(h->pinned_obj, h->dscalar, 8, hipMemcpyDeviceToHost, h->stream) == hipSuccess;
+  }
+  h->launches_x = lx; h->launches_y = ly; // capturing is not launching
+  hipGraph_t g = nullptr;
+  const hipError_t ec = hipStreamEndCapture(h->stream, &g);
+  if (!ok || ec != hipSuccess || !g) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); return GLRM_OK; }
+  if (hipGraphInstantiate(&h->iter_exec, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); h->iter_exec = nullptr; (void)hipGetLastError(); return GLRM_OK; }
+  h->iter_graph = g;
+  h->graph_ix = prm->inner_iter_X; h->graph_iy = prm->inner_iter_Y; h->graph_min = prm->min_stepsize; h->graph_step = prm->stepsize;
+  return GLRM_OK;
+}
+
 extern "C" int glrm_hip_fit(glrm_handle* h, const glrm_params* prm, double* X, double* Y, double* objective,
                             double* seconds, int64_t cap, int64_t* n_recorded) {
   if (!h || !prm || !X || !Y || !objective || !seconds || !n_recorded) return fail(GLRM_ERR_INVALID, "NULL argument");
@@ -1019,15 +1060,24 @@ extern "C" int glrm_hip_fit(glrm_handle* h, const glrm_params* prm, double* X, d
   seconds[0] = 0.0;
   nrec = 1;
   double t = now_s();
+  const bool use_graph = graph_eligible(h);
+  if (use_graph && (rc = build_iteration_graph(h, prm))) return rc;
   for (int64_t i = 1; i <= prm->max_iter; ++i) {                       // :107
-    if (prm->inner_iter_X > 1 || prm->inner_iter_Y > 1)
-      if ((rc = glrm_hip_reset_stepsizes(h, prm->stepsize))) return rc; // :112-115
-    for (int64_t in = 0; in < prm->inner_iter_X; ++in)
-      if ((rc = run_sweep(h, 0, prm->min_stepsize, 0))) return rc;    // :117-158
-    for (int64_t in = 0; in < prm->inner_iter_Y; ++in)
-      if ((rc = run_sweep(h, 1, prm->min_stepsize, 0))) return rc;    // :160-203
     double obj = 0.0;
-    if ((rc = glrm_hip_sum(h, h->objcol, h->n, &obj))) return rc;     // obj = sum(obj_by_col) :205
+    if (use_graph && h->iter_exec) { // the same launches, replayed from one hipGraph
+      HIPCK(hipGraphLaunch(h->iter_exec, h->stream));
+      HIPCK(hipStreamSynchronize(h->stream));
+      obj = *h->pinned_obj;
+      h->launches_x += prm->inner_iter_X; h->launches_y += prm->inner_iter_Y;
+    } else {
+      if (prm->inner_iter_X > 1 || prm->inner_iter_Y > 1)
+        if ((rc = glrm_hip_reset_stepsizes(h, prm->stepsize))) return rc; // :112-115
+      for (int64_t in = 0; in < prm->inner_iter_X; ++in)
+        if ((rc = run_sweep(h, 0, prm->min_stepsize, 0))) return rc;    // :117-158
+      for (int64_t in = 0; in < prm->inner_iter_Y; ++in)
+        if ((rc = run_sweep(h, 1, prm->min_stepsize, 0))) return rc;    // :160-203
+      if ((rc = glrm_hip_sum(h, h->objcol, h->n, &obj))) return rc;     // obj = sum(obj_by_col) :205
+    }
     const double dt = now_s() - t;
     objective[nrec] = obj;
     seconds[nrec] = seconds[nrec - 1] + dt;                            // update_ch! (src/convergence.jl:22-26)
