@@ -18,19 +18,20 @@ static int tile_rows(int kp, int cfg) { return tile_rows_c(kp, cfg); }
 
 int glrm_setup_tiled(glrm_handle* h) {
   hipStream_t st = h->stream;
+  h->tile_cfg = env_int("GLRM_HIP_TILE_CFG", 1) ? 1 : 0;
+  h->tG = h->G;
+  h->tR = h->R;
+  const int T0 = tile_rows(h->kp, h->tile_cfg);
   HIPCK(hipMalloc((void**)&h->dflag, 2 * sizeof(int)));
   HIPCK(hipMemsetAsync(h->dflag, 0, 2 * sizeof(int), st));
-  if (h->ml > 0) hipLaunchKernelGGL(check_sorted_kernel, dim3((unsigned)h->ml), dim3(64), 0, st, h->rowptr, h->colidx, h->ml, h->dflag);
-  if (h->nl > 0) hipLaunchKernelGGL(check_sorted_kernel, dim3((unsigned)h->nl), dim3(256), 0, st, h->colptr, h->rowidx, h->nl, h->dflag + 1);
+  if (h->ml > 0) hipLaunchKernelGGL(check_sorted_kernel, dim3((unsigned)h->ml), dim3(64), 0, st, h->rowptr, h->colidx, h->ml, T0, h->dflag);
+  if (h->nl > 0) hipLaunchKernelGGL(check_sorted_kernel, dim3((unsigned)h->nl), dim3(256), 0, st, h->colptr, h->rowidx, h->nl, T0, h->dflag + 1);
   HIPCK(hipGetLastError());
   int flags[2] = {0, 0};
   HIPCK(hipMemcpyAsync(flags, h->dflag, sizeof flags, hipMemcpyDeviceToHost, st));
   HIPCK(hipStreamSynchronize(st));
   h->rows_sorted = flags[0] == 0;
   h->cols_sorted = flags[1] == 0;
-  h->tile_cfg = env_int("GLRM_HIP_TILE_CFG", 1) ? 1 : 0;
-  h->tG = h->G;
-  h->tR = h->R;
 
   const int T = tile_rows(h->kp, h->tile_cfg);
   // expected observations of one segment inside one tile; the tiled sweeps pay off when a staged
@@ -49,6 +50,19 @@ int glrm_setup_tiled(glrm_handle* h) {
   const bool big_c = h->nnz_c >= 20000000 && h->nl >= 256;
   h->tiled_row = h->rows_sorted && (want < 0 ? (per_tile_r >= 4.0 && big_r) : (want & 1)) ? 1 : 0;
   h->tiled_col = h->cols_sorted && (want < 0 ? (per_tile_c >= 4.0 && big_c) : ((want >> 1) & 1)) ? 1 : 0;
+  if (h->tiled_row && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_GROUP_KINDS", 1)) {
+    int32_t* oidx = nullptr;
+    double* ovals = nullptr;
+    HIPCK(hipMalloc((void**)&oidx, (size_t)h->nnz_r * 4));
+    if (hipMalloc((void**)&ovals, (size_t)h->nnz_r * 8) != hipSuccess) { (void)hipFree(oidx); return fail(GLRM_ERR_OOM, "out of device memory"); }
+    hipLaunchKernelGGL(group_rows_by_kind_kernel, dim3((unsigned)h->ml), dim3(64), 0, st, h->rowptr, h->colidx, h->rowvals, h->ml, T, h->losses, oidx, ovals);
+    HIPCK(hipGetLastError());
+    HIPCK(hipStreamSynchronize(st));
+    (void)hipFree(h->colidx);
+    (void)hipFree(h->rowvals);
+    h->colidx = oidx;
+    h->rowvals = ovals;
+  }
   // super-tiles of ~32k rows: a function of (m, tile) only -- never of the shard layout -- so the partial-sum order
   // (and the result bits) do not depend on the GPU count, while long columns still spread over enough workgroups
   const int64_t ntiles = (h->m + T - 1) / T;

@@ -553,14 +553,38 @@ __global__ void __launch_bounds__(256) col_decide_kernel(const TiledArgs a) {
   }
 }
 
-// 1 if idx is non-decreasing inside every segment
-static __global__ void check_sorted_kernel(const int64_t* ptr, const int32_t* idx, int64_t nseg, int* unsorted) {
+// 1 if some segment's list is not ordered by TILE: the tiled sweeps need the entries of tile t to precede those of tile t+1
+// (order inside a tile is free: the tile sits in LDS); a non-decreasing index list is the common special case.
+static __global__ void check_sorted_kernel(const int64_t* ptr, const int32_t* idx, int64_t nseg, int tile, int* unsorted) {
   const int64_t seg = (int64_t)blockIdx.x;
   if (seg >= nseg) return;
   const int64_t b = ptr[seg], e = ptr[seg + 1];
   int bad = 0;
-  for (int64_t t = b + 1 + threadIdx.x; t < e; t += blockDim.x) bad |= idx[t] < idx[t - 1];
+  for (int64_t t = b + 1 + threadIdx.x; t < e; t += blockDim.x) bad |= idx[t] / tile < idx[t - 1] / tile;
   if (bad) *unsorted = 1;
+}
+
+// Heterogeneous models (a loss descriptor per column): inside every tile window of a row, group the entries by loss kind
+// (stable).  The lane groups of a wave walk their windows in lockstep, so most steps then meet ONE loss formula instead of all
+// of them.  Only the engine's private copy of the row view is reordered; the sums change by rounding only.
+static __global__ void __launch_bounds__(64) group_rows_by_kind_kernel(const int64_t* ptr, const int32_t* idx, const double* vals, int64_t nseg, int tile,
+                                                                        const glrm_loss* losses, int32_t* oidx, double* ovals) {
+  const int64_t seg = (int64_t)blockIdx.x;
+  if (seg >= nseg) return;
+  const int64_t b = ptr[seg], e = ptr[seg + 1];
+  for (int64_t t = b + threadIdx.x; t < e; t += 64) {
+    const int c = idx[t], tl = c / tile, kind = losses[c].kind;
+    int64_t wb = t, we = t + 1; // window of the entry's tile (windows hold a few dozen entries)
+    while (wb > b && idx[wb - 1] / tile == tl) --wb;
+    while (we < e && idx[we] / tile == tl) ++we;
+    int64_t rank = 0;
+    for (int64_t u = wb; u < we; ++u) {
+      const int ku = losses[idx[u]].kind;
+      rank += (ku < kind) || (ku == kind && u < t);
+    }
+    oidx[wb + rank] = c;
+    ovals[wb + rank] = vals[t];
+  }
 }
 
 } // namespace glrm

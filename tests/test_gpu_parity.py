@@ -105,13 +105,21 @@ def test_auto_wave_selection_long_columns():
 
 
 def test_unsorted_lists_fall_back_to_gather_sweeps():
-    """The LDS-tiled sweeps need non-decreasing index lists; a permuted Omega silently uses the gather sweeps."""
+    """The LDS-tiled sweeps need the entries of tile t before those of tile t+1 (any order inside a tile); an Omega that is
+    permuted across tiles silently uses the gather sweeps, one that fits a single tile does not care about its order."""
     rng = np.random.default_rng(81)
-    pa, X0, Y0 = random_problem(rng, 300, 80, 8, 0.4, dup=True)
+    pa, X0, Y0 = random_problem(rng, 2500, 2500, 8, 0.02, dup=True)  # k=8: 1920 vectors per tile -> two tiles per view
     h = hip().create(pa, tiled=2)
     st = hip().kernel_stats(h)
     hip().destroy(h)
     assert st["tiled"] == 0
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=5), tiled=2)
+    pa, X0, Y0 = random_problem(rng, 300, 80, 8, 0.4, dup=True)      # everything inside one tile: order is irrelevant
+    h = hip().create(pa, tiled=2)
+    st = hip().kernel_stats(h)
+    hip().destroy(h)
+    assert st["tiled"] == 3
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=8), tiled=2)
     pa, X0, Y0 = random_problem(rng, 300, 80, 8, 0.4)
     h = hip().create(pa, tiled=2)
     st = hip().kernel_stats(h)
