@@ -195,8 +195,8 @@ typedef struct glrm_options {
   int32_t caller_stream; /* 0: stream==NULL means "the handle creates a private non-blocking stream";
                             1: launch on `stream` exactly as given, even NULL (the legacy default stream) --
                             what a host that orders its own collectives on that stream must pass */
-  int32_t tiled;     /* sweep kernels: 0 = choose (LDS-tiled when the index lists are sorted and dense enough),
-                        1 = gather sweeps only, 2 = LDS-tiled sweeps wherever the lists are sorted */
+  int32_t tiled;     /* sweep kernels: 0 = choose (LDS-tiled when the index lists are tile-ordered -- e.g. sorted -- and the
+                        problem is large enough), 1 = gather sweeps only, 2 = LDS-tiled sweeps wherever the lists allow */
 } glrm_options;
 
 typedef struct glrm_handle glrm_handle;

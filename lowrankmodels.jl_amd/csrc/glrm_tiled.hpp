@@ -9,8 +9,9 @@
 // factor vector is thus read from memory once per (workgroup, pass) instead of once per observation, and
 // the per-observation traffic left is the 12-byte (index, value) stream.
 //
-// Requirements: the segment's index list is non-decreasing (true for `findall` / sparse input,
-// src/glrm.jl:46-48; checked at create, otherwise the gather sweeps are used).  Duplicates are fine.
+// Requirements: the segment's index list is ordered by tile -- the entries of tile t come before those of tile t+1; a
+// non-decreasing list (`findall` / sparse input, src/glrm.jl:46-48) is the common case.  Checked at create, otherwise the
+// gather sweeps are used.  Duplicates are fine.
 //
 // Summation order: a group accumulates its segment's losses and gradient sequentially in list order --
 // the reference's own order (src/algorithms/proxgrad.jl:122-132, src/evaluate_fit.jl:28-32).  The column
