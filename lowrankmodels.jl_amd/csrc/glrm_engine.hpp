@@ -118,6 +118,9 @@ inline int env_int(const char* name, int dflt) {
 int glrm_setup_tiled(glrm_handle* h);
 int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only);
 
+// stable segmented sort of a view by tile index (glrm_tilesort.hip)
+int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals);
+
 // dense MFMA path (glrm_dense.hip)
 int glrm_setup_dense(glrm_handle* h, const glrm_problem* p);
 int glrm_run_dense(glrm_handle* h, bool rows, double min_stepsize, int eval_only);

@@ -48,8 +48,23 @@ int glrm_setup_tiled(glrm_handle* h) {
   const int spb_auto = (h->tile_cfg ? 16 : 8) * (64 / h->tG);
   const bool big_r = h->nnz_r >= 20000000 && h->ml >= (int64_t)512 * spb_auto;
   const bool big_c = h->nnz_c >= 20000000 && h->nl >= 256;
-  h->tiled_row = h->rows_sorted && (want < 0 ? (per_tile_r >= 4.0 && big_r) : (want & 1)) ? 1 : 0;
-  h->tiled_col = h->cols_sorted && (want < 0 ? (per_tile_c >= 4.0 && big_c) : ((want >> 1) & 1)) ? 1 : 0;
+  bool want_row = want < 0 ? (per_tile_r >= 4.0 && big_r) : (want & 1) != 0;
+  bool want_col = want < 0 ? (per_tile_c >= 4.0 && big_c) : ((want >> 1) & 1) != 0;
+  // Lists in arbitrary order (obs tuples pushed in sampling order): the engine's private copy is brought into tile order by a
+  // stable segmented sort, so such inputs run the tiled sweeps too.  Only when the auto choice wants the tiled sweeps -- an
+  // explicit tiled = 2 keeps its meaning "wherever the lists allow" (GLRM_HIP_TILE_SORT=0 disables, =2 sorts for tiled = 2 as well).
+  const int tsort = env_int("GLRM_HIP_TILE_SORT", 1);
+  const bool may_sort = tsort == 2 || (tsort == 1 && want < 0);
+  if (want_row && !h->rows_sorted && may_sort) {
+    const int rc = glrm_tile_sort_view(st, h->rowptr, h->ml, h->nnz_r, T, h->n, &h->colidx, &h->rowvals);
+    if (rc == GLRM_OK) h->rows_sorted = true; else if (rc != GLRM_ERR_UNSUPPORTED) return rc;
+  }
+  if (want_col && !h->cols_sorted && may_sort) {
+    const int rc = glrm_tile_sort_view(st, h->colptr, h->nl, h->nnz_c, T, h->m, &h->rowidx, &h->colvals);
+    if (rc == GLRM_OK) h->cols_sorted = true; else if (rc != GLRM_ERR_UNSUPPORTED) return rc;
+  }
+  h->tiled_row = (h->rows_sorted && want_row) ? 1 : 0;
+  h->tiled_col = (h->cols_sorted && want_col) ? 1 : 0;
   if (h->tiled_row && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_GROUP_KINDS", 1)) {
     int32_t* oidx = nullptr;
     double* ovals = nullptr;

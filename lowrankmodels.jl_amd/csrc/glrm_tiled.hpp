@@ -13,7 +13,8 @@
 // non-decreasing list (`findall` / sparse input, src/glrm.jl:46-48) is the common case.  Checked at create, otherwise the
 // gather sweeps are used.  Duplicates are fine.
 //
-// Summation order: a group accumulates its segment's losses and gradient sequentially in list order --
+// Summation order: a group accumulates its segment's losses and gradient sequentially in the order of the engine's private
+// list (the caller's list order unless the engine had to tile-sort or kind-group it) --
 // the reference's own order (src/algorithms/proxgrad.jl:122-132, src/evaluate_fit.jl:28-32).  The column
 // sweep additionally splits the rows into NSUP super-tiles whose partial sums are added in order; NSUP
 // depends only on (m, TILE), never on the shard layout, so results stay independent of the GPU count.

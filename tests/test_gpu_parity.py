@@ -114,6 +114,16 @@ def test_unsorted_lists_fall_back_to_gather_sweeps():
     hip().destroy(h)
     assert st["tiled"] == 0
     compare(pa, X0, Y0, L.ProxGradParams(max_iter=5), tiled=2)
+    # GLRM_HIP_TILE_SORT=2: the engine tile-sorts its private copy of such lists (what the auto choice does for large problems)
+    os.environ["GLRM_HIP_TILE_SORT"] = "2"
+    try:
+        h = hip().create(pa, tiled=2)
+        st = hip().kernel_stats(h)
+        hip().destroy(h)
+        assert st["tiled"] == 3
+        compare(pa, X0, Y0, L.ProxGradParams(max_iter=8), tiled=2)
+    finally:
+        del os.environ["GLRM_HIP_TILE_SORT"]
     pa, X0, Y0 = random_problem(rng, 300, 80, 8, 0.4, dup=True)      # everything inside one tile: order is irrelevant
     h = hip().create(pa, tiled=2)
     st = hip().kernel_stats(h)
