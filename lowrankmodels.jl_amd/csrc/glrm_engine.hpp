@@ -52,7 +52,7 @@ struct glrm_handle {
   int32_t *activebuf = nullptr, *ntrialbuf = nullptr;
   unsigned int* nactive = nullptr;
   int* dflag = nullptr;
-  int32_t* colperm = nullptr;         // tiled column passes of heterogeneous models: columns sorted by loss kind
+  int32_t *colperm = nullptr, *rowperm = nullptr; // tiled sweeps: segments sorted by (loss kind, length) / by length
   // general sweeps: multi-dimensional losses / wrapped regularizers (glrm_multi.hip)
   bool multi = false;
   int64_t d = 0;                      // vectors of Y = sum of embedding dimensions (= n for scalar losses)

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
+#include <vector>
 
 #include "glrm_engine.hpp"
 #include "glrm_tiled.hpp"
@@ -16,8 +18,36 @@ using namespace glrm;
 constexpr int tile_rows_c(int kp, int cfg) { return ((cfg ? 150 * 1024 : 64 * 1024) / (kp * 8 + 16)) / 16 * 16; }
 static int tile_rows(int kp, int cfg) { return tile_rows_c(kp, cfg); }
 
+// slot -> segment permutation of a tiled sweep: segments sorted by (loss kind of the column,) descending length, so that the 16
+// lane groups of a wave meet one loss formula and lists of similar length.  nullptr when the natural order is already that
+// (one loss kind and lengths within 25 % of each other: the synthetic BASELINE workloads).
+static int make_segperm(glrm_handle* h, bool rows, int32_t** out) {
+  *out = nullptr;
+  const int64_t nseg = rows ? h->ml : h->nl;
+  if (nseg <= 1 || !env_int("GLRM_HIP_SEGPERM", 1)) return GLRM_OK;
+  std::vector<int64_t> ptr((size_t)nseg + 1);
+  HIPCK(hipMemcpyAsync(ptr.data(), rows ? h->rowptr : h->colptr, ((size_t)nseg + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  int64_t lmin = INT64_MAX, lmax = 0;
+  for (int64_t s = 0; s < nseg; ++s) { const int64_t l = ptr[s + 1] - ptr[s]; lmin = l < lmin ? l : lmin; lmax = l > lmax ? l : lmax; }
+  const bool kinds = !rows && h->n_losses > 1;
+  if (!kinds && lmax * 4 <= lmin * 5) return GLRM_OK;
+  std::vector<int32_t> perm((size_t)nseg);
+  for (int64_t s = 0; s < nseg; ++s) perm[s] = (int32_t)s;
+  const glrm_loss* lt = kinds ? h->losses_h.data() + h->cb : nullptr;
+  std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) {
+    if (kinds && lt[x].kind != lt[y].kind) return lt[x].kind < lt[y].kind;
+    return ptr[x + 1] - ptr[x] > ptr[y + 1] - ptr[y];
+  });
+  HIPCK(hipMalloc((void**)out, (size_t)nseg * 4));
+  HIPCK(hipMemcpyAsync(*out, perm.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream)); // perm is a local
+  return GLRM_OK;
+}
+
 int glrm_setup_tiled(glrm_handle* h) {
   hipStream_t st = h->stream;
+  int rc0 = GLRM_OK;
   h->tile_cfg = env_int("GLRM_HIP_TILE_CFG", 1) ? 1 : 0;
   h->tG = h->G;
   h->tR = h->R;
@@ -106,16 +136,9 @@ int glrm_setup_tiled(glrm_handle* h) {
     HIPCK(hipMalloc((void**)&h->activebuf, (size_t)nl1 * 4));
     HIPCK(hipMalloc((void**)&h->ntrialbuf, (size_t)nl1 * 4));
     HIPCK(hipMalloc((void**)&h->nactive, 4));
-    if (h->n_losses > 1) { // per-column losses: give every wave columns of ONE loss kind (no divergent loss branches)
-      std::vector<int32_t> perm((size_t)h->nl);
-      for (int64_t f = 0; f < h->nl; ++f) perm[f] = (int32_t)f;
-      const glrm_loss* lt = h->losses_h.data() + h->cb;
-      std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return lt[x].kind < lt[y].kind; });
-      HIPCK(hipMalloc((void**)&h->colperm, (size_t)nl1 * 4));
-      HIPCK(hipMemcpyAsync(h->colperm, perm.data(), (size_t)h->nl * 4, hipMemcpyHostToDevice, st));
-      HIPCK(hipStreamSynchronize(st)); // perm is a local
-    }
+    if ((rc0 = make_segperm(h, false, &h->colperm))) return rc0;
   }
+  if (h->tiled_row && (rc0 = make_segperm(h, true, &h->rowperm))) return rc0;
   return GLRM_OK;
 }
 
@@ -223,7 +246,10 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
     if (!a.reg_single) a.regs += s0;
     a.trials += s0; a.accepts += s0;
   }
-  if (rows) return launch_tiled(h, loss, 0, a);
+  if (rows) {
+    a.segperm = h->rng_e >= 0 ? nullptr : h->rowperm; // a sub-range sweep keeps the natural order
+    return launch_tiled(h, loss, 0, a);
+  }
   a.nsup = h->nsup;
   a.tiles_per_sup = h->tiles_per_sup;
   a.part = h->part; a.gsum = h->gsum; a.trial = h->trialbuf; a.jold = h->joldbuf;

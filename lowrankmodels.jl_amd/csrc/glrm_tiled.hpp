@@ -56,8 +56,9 @@ struct TiledArgs {
   int eval_only;         // col_reduce: obj = sum of losses, nothing else
   int64_t dense_len;     // ptr == nullptr (dense problem): every segment has this many observations
   double fixed_alpha;    // > 0: one prox-gradient step with this global step size, no line search
-  const int32_t* segperm; // column passes: lane-group slot -> local segment (nullptr = identity).  Heterogeneous models sort
-                          // the columns by loss kind so that the 16 groups of a wave evaluate the same loss formula.
+  const int32_t* segperm; // lane-group slot -> local segment (nullptr = identity).  Which segment a group works on changes no sum:
+                          // columns are handed out sorted by (loss kind, length), rows by length, so that the 16 groups of a wave
+                          // evaluate the same loss formula and finish their lists together.
 };
 
 template <int G>
@@ -281,8 +282,9 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_sweep_kernel(const TiledArgs
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % G, gi = lane / G;
-  const int64_t seg = (int64_t)blockIdx.x * SPB + wave * NGW + gi;
-  const bool have = seg < a.nseg;
+  const int64_t slot = (int64_t)blockIdx.x * SPB + wave * NGW + gi;
+  const bool have = slot < a.nseg;
+  const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[slot] : slot; // segments of similar length share a wave (skewed data)
   const int64_t beg = have ? a.ptr[seg] : 0, end = have ? a.ptr[seg + 1] : 0;
   const int64_t gseg = a.own_offset + (have ? seg : 0);
   double2* ownp = reinterpret_cast<double2*>(a.own + gseg * KP);
