@@ -179,3 +179,24 @@ def test_regularization_path_reuses_the_engine_handle():
     L.fit_b(r2, p, verbose=False, engine=eng)
     assert np.array_equal(g.X, r2.X) and np.array_equal(g.Y, r2.Y)
     g.close()
+
+
+def test_descriptor_cache_tracks_every_way_of_changing_a_model():
+    """The packed descriptors of a model are cached (a million Python objects are not re-read per fit! call); any construction or
+    modification of a loss / regularizer and any list mutation invalidates the cache."""
+    rng = np.random.default_rng(0)
+    g = L.GLRM(rng.standard_normal((30, 8)), L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.2), 2)
+    k0 = g._descriptor_key()
+    assert g._descriptor_key() is k0                       # cached object
+    g.rx[3].scale = 0.7                                    # attribute assignment on one regularizer
+    k1 = g._descriptor_key()
+    assert k1[0] == k0[0] and k1[1] != k0[1]               # same losses (hard key), different regularizers (soft key)
+    g.ry[2] = L.OneReg(0.3)                                # list element replaced
+    k2 = g._descriptor_key()
+    assert k2[1] != k1[1]
+    g.losses[1].mul_(3.0)                                  # loss scale: forces a new engine handle
+    assert g._descriptor_key()[0] != k2[0]
+    L.scale_regularizer_(g, 2.0)
+    k3 = g._descriptor_key()
+    g.rx = [L.ZeroReg()] * 30                              # a plain list: no tracking, the key is recomputed every time
+    assert g._descriptor_key()[1] != k3[1] and g._descriptor_key() is not g._descriptor_key()
