@@ -89,6 +89,10 @@ struct glrm_handle {
   unsigned long long* dcount = nullptr;
   int32_t *trials_r = nullptr, *accepts_r = nullptr, *trials_c = nullptr, *accepts_c = nullptr;
   int waves_row = 1, waves_col = 4;
+  int32_t *seglist_r = nullptr, *seglist_c = nullptr; // gather sweeps, skewed lengths: [short segments..., long segments (longest first)]
+  int64_t nlong_r = 0, nlong_c = 0;
+  hipStream_t side_stream = nullptr;  // the long segments' launch runs beside the short segments' launch
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int profile = 0;
   // hipGraph of one outer iteration (gather sweeps on a private stream): small fits are launch bound
   hipGraph_t iter_graph = nullptr;

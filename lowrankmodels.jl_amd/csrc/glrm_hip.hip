@@ -17,6 +17,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -53,6 +55,8 @@ struct SweepArgs {
   double min_stepsize;
   int32_t* trials;       // per local segment accumulators (nullable)
   int32_t* accepts;
+  const int32_t* seglist; // nullable: the launch covers segments seglist[0..nseg) instead of 0..nseg (skewed lengths: the few very
+                          // long segments get their own launch with 8 waves each)
 };
 
 
@@ -198,8 +202,9 @@ __global__ void __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64) sweep_kernel(co
   __shared__ __attribute__((aligned(16))) double red[WAVES == 1 ? 2 : WAVES * (KP + 2)];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform -> SGPR
-  const int64_t seg = WAVES == 1 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
-  if (seg >= a.nseg) return; // wave-uniform (WAVES==1) or block-uniform
+  const int64_t slot = WAVES == 1 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
+  if (slot >= a.nseg) return; // wave-uniform (WAVES==1) or block-uniform
+  const int64_t seg = a.seglist ? (int64_t)a.seglist[slot] : slot;
   const int j = lane % G, gi = lane / G;
   const int gg = (WAVES == 1 ? 0 : wave * NG) + gi;
   const int64_t beg = a.ptr[seg], len = a.ptr[seg + 1] - beg;
@@ -498,7 +503,7 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
                   h->trials_r, h->accepts_r, h->trials_c, h->accepts_c, h->part, h->gsum, h->trialbuf, h->joldbuf,
                   h->activebuf, h->ntrialbuf, h->nactive, h->dflag, h->Arow, h->Acol, h->part_r, h->gsum_r, h->trial_r,
                   h->jold_r, h->active_r, h->ntrial_r, h->ystart, h->mtrial, h->mpart_loss, h->mpart_G, h->mgtot,
-                  h->mobjold, h->mactive, h->mnactive, h->colperm, h->rowperm};
+                  h->mobjold, h->mactive, h->mnactive, h->colperm, h->rowperm, h->seglist_r, h->seglist_c};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->iter_exec) (void)hipGraphExecDestroy(h->iter_exec);
@@ -506,8 +511,41 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
   if (h->pinned_obj) (void)hipHostFree(h->pinned_obj);
   for (auto& e : h->pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& e : h->pool) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
   if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+}
+
+// Skewed lengths (a few very popular columns / very active rows): segments longer than max(2048, 4 x mean) are listed apart and
+// swept by an 8-wave launch of their own on a side stream, concurrently with the launch of the short ones; with one launch for all, the waves-per-segment choice follows the mean and the longest
+// segment becomes the tail of the sweep.  The split changes which kernel instance runs a segment, hence its summation grouping,
+// but it is a function of the segment lengths alone.
+static int split_long_segments(glrm_handle* h, bool rows) {
+  const int64_t nseg = rows ? h->ml : h->nl, nnz = rows ? h->nnz_r : h->nnz_c;
+  if (nseg < 8 || nnz <= 0 || (rows ? h->waves_row : h->waves_col) == 8 || !env_int("GLRM_HIP_SPLIT_LONG", 1)) return GLRM_OK;
+  std::vector<int64_t> ptr((size_t)nseg + 1);
+  HIPCK(hipMemcpyAsync(ptr.data(), rows ? h->rowptr : h->colptr, ((size_t)nseg + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  const double mean = (double)nnz / (double)nseg;
+  const int64_t thr = (int64_t)std::max(2048.0, 4.0 * mean);
+  std::vector<int32_t> shorts, longs;
+  for (int64_t s = 0; s < nseg; ++s) (ptr[s + 1] - ptr[s] > thr ? longs : shorts).push_back((int32_t)s);
+  if (longs.empty() || (int64_t)longs.size() * 2 > nseg) return GLRM_OK;
+  std::stable_sort(longs.begin(), longs.end(), [&](int32_t x, int32_t y) { return ptr[x + 1] - ptr[x] > ptr[y + 1] - ptr[y]; }); // longest first
+  shorts.insert(shorts.end(), longs.begin(), longs.end());
+  int32_t** dst = rows ? &h->seglist_r : &h->seglist_c;
+  HIPCK(hipMalloc((void**)dst, (size_t)nseg * 4));
+  HIPCK(hipMemcpyAsync(*dst, shorts.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  (rows ? h->nlong_r : h->nlong_c) = (int64_t)longs.size();
+  if (!h->side_stream) {
+    HIPCK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+    HIPCK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    HIPCK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+  }
+  return GLRM_OK;
 }
 
 static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options* o) {
@@ -570,6 +608,10 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   HIPCK(hipMemsetAsync(h->accepts_c, 0, nl1 * 4, st));
   h->waves_row = pick_waves(o ? o->waves_row : 0, h->nnz_r, h->ml);
   h->waves_col = pick_waves(o ? o->waves_col : 0, h->nnz_c, h->nl);
+  if (!p->dense_A) {
+    if (!(o && o->waves_row) && (rc = split_long_segments(h, true))) return rc;
+    if (!(o && o->waves_col) && (rc = split_long_segments(h, false))) return rc;
+  }
   int rc2 = glrm_setup_multi(h, p);
   if (rc2) return rc2;
   if (!h->multi) rc2 = p->dense_A ? glrm_setup_dense(h, p) : glrm_setup_tiled(h);
@@ -839,7 +881,22 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
     rc = glrm_run_tiled(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
     if (rc) return rc;
   } else {
-    launch_sweep(h->G, h->R, rows ? h->waves_row : h->waves_col, loss, rows ? h->unroll_row : h->unroll_col, a, h->stream);
+    const int32_t* lst = rows ? h->seglist_r : h->seglist_c;
+    const int64_t nlong = rows ? h->nlong_r : h->nlong_c;
+    if (lst && !(rows && h->rng_e >= 0)) { // skewed lengths: short segments with the usual waves, the long ones with 8 waves each
+      const int64_t nall = a.nseg;
+      // fork: the few long segments (8 waves each) on the side stream, beside the short segments on the main stream; join
+      HIPCK(hipEventRecord(h->ev_fork, h->stream));
+      HIPCK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+      a.seglist = lst + (nall - nlong); a.nseg = nlong;
+      launch_sweep(h->G, h->R, 8, loss, 1, a, h->side_stream);
+      HIPCK(hipEventRecord(h->ev_join, h->side_stream));
+      a.seglist = lst; a.nseg = nall - nlong;
+      if (a.nseg > 0) launch_sweep(h->G, h->R, rows ? h->waves_row : h->waves_col, loss, rows ? h->unroll_row : h->unroll_col, a, h->stream);
+      HIPCK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    } else {
+      launch_sweep(h->G, h->R, rows ? h->waves_row : h->waves_col, loss, rows ? h->unroll_row : h->unroll_col, a, h->stream);
+    }
   }
   HIPCK(hipGetLastError());
   if (timed) {

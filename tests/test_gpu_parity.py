@@ -363,3 +363,18 @@ def test_set_regularizers_keeps_the_handle_and_matches_a_fresh_one():
             api.set_regularizers(h, np.repeat(new, 3), new)
         finally:
             api.destroy(h)
+
+
+def test_skewed_lengths_split_launch():
+    """A few very long segments next to many short ones: the gather sweeps give the long ones an 8-wave launch of their own on a
+    side stream (fork / join by events; also inside the captured hipGraph of glrm_hip_fit)."""
+    rng = np.random.default_rng(90)
+    m, n, k = 6000, 60, 8
+    A = rng.standard_normal((m, k)) @ rng.standard_normal((k, n)) / np.sqrt(k) + 0.1 * rng.standard_normal((m, n))
+    mask = rng.random((m, n)) < 0.02
+    mask[:, 0] = True                      # one fully observed column: 6000 entries against a mean of ~220
+    mask[5, :] = True                      # and one fully observed row
+    I, J = np.nonzero(mask)
+    X0, Y0 = rng.standard_normal((k, m)), rng.standard_normal((k, n))
+    g = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.NonNegConstraint(), k, obs=(I, J), X=X0, Y=Y0)
+    compare(g.problem_arrays(), np.asfortranarray(X0), np.asfortranarray(Y0), L.ProxGradParams(max_iter=15), tiled=1)
