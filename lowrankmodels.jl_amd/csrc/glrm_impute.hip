@@ -97,8 +97,9 @@ __global__ void error_metric_cols_kernel(const EvalArgs a, int64_t n, int standa
 __global__ void __launch_bounds__(ET) impute_kernel(const EvalArgs a) {
   extern __shared__ double sm[];
   double* us = sm + threadIdx.x;
-  const int64_t f = blockIdx.x;
-  const int64_t e = (int64_t)blockIdx.y * ET + threadIdx.x;
+  const int64_t nchunk = (a.m + ET - 1) / ET;             // 1-D grid: gridDim.y would overflow for m > 8.4e6
+  const int64_t f = (int64_t)blockIdx.x / nchunk;
+  const int64_t e = ((int64_t)blockIdx.x - f * nchunk) * ET + threadIdx.x;
   if (e >= a.m) return;
   const glrm_loss lo = a.losses[a.loss_single ? 0 : f];
   const LossDesc l = load_loss(a.losses, a.loss_single ? 0 : f);
@@ -148,6 +149,7 @@ extern "C" int glrm_hip_error_metric(glrm_handle* h, const double* X, const doub
   int64_t longest = 0;
   for (int64_t f = 0; f < h->n; ++f) longest = cp[f + 1] - cp[f] > longest ? cp[f + 1] - cp[f] : longest;
   a.chunk = 65536;
+  while ((longest + a.chunk - 1) / a.chunk > 65535) a.chunk *= 2; // gridDim.y
   a.nsplit = (int)((longest + a.chunk - 1) / a.chunk);
   if (a.nsplit < 1) a.nsplit = 1;
   if (hipMalloc((void**)&part, (size_t)h->n * a.nsplit * 16) != hipSuccess || hipMalloc((void**)&colerr, (size_t)h->n * 8) != hipSuccess)
@@ -180,7 +182,8 @@ extern "C" int glrm_hip_impute(glrm_handle* h, const double* X, const double* Y,
   if (hipMalloc((void**)&dA, (size_t)h->m * h->n * 8) != hipSuccess) return cleanup(fail(GLRM_ERR_OOM, "out of device memory for the m x n imputed matrix"));
   a.Ahat = dA;
   const size_t lds = (size_t)h->dmax * ET * 8;
-  hipLaunchKernelGGL(impute_kernel, dim3((unsigned)h->n, (unsigned)((h->m + ET - 1) / ET)), dim3(ET), lds, h->stream, a);
+  if ((h->m + ET - 1) / ET * h->n > 2147483647ll) return cleanup(fail(GLRM_ERR_UNSUPPORTED, "m x n too large for one impute launch"));
+  hipLaunchKernelGGL(impute_kernel, dim3((unsigned)((h->m + ET - 1) / ET * h->n)), dim3(ET), lds, h->stream, a);
   if (hipGetLastError() != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "impute kernel failed to launch"));
   if (hipMemcpyAsync(Ahat, dA, (size_t)h->m * h->n * 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
       hipStreamSynchronize(h->stream) != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "copy failed"));

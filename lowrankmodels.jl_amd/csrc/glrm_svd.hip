@@ -398,6 +398,7 @@ extern "C" int glrm_hip_init_svd(glrm_handle* h, double* X, double* Y, int32_t m
     int64_t longest = 0;
     for (int64_t f = 0; f < h->n; ++f) longest = std::max(longest, cp[f + 1] - cp[f]);
     ca.chunk = 16384;
+    while ((longest + ca.chunk - 1) / ca.chunk > 65535) ca.chunk *= 2; // gridDim.y
     ca.nsplit = (int)std::max<int64_t>(1, (longest + ca.chunk - 1) / ca.chunk);
     if (ca.nsplit > 1) {
       HIPCK(hipMalloc((void**)&w.cpart, (size_t)h->n * ca.nsplit * h->dmax * l * 8));
