@@ -200,3 +200,18 @@ def test_descriptor_cache_tracks_every_way_of_changing_a_model():
     k3 = g._descriptor_key()
     g.rx = [L.ZeroReg()] * 30                              # a plain list: no tracking, the key is recomputed every time
     assert g._descriptor_key()[1] != k3[1] and g._descriptor_key() is not g._descriptor_key()
+
+
+def test_simple_glrm_builders():
+    """src/simple_glrms.jl; test/runtests.jl:19-25 runs kmeans with inner_iter=10 on two separated clusters."""
+    rng = np.random.default_rng(0)
+    A = np.vstack([rng.standard_normal((100, 10)) + 5, rng.standard_normal((50, 10)) - 5])
+    g = L.kmeans(A, 2, rng=rng)
+    X, Y, ch = L.fit_b(g, L.ProxGradParams(max_iter=30, inner_iter=10), verbose=False, engine=O.oracle_api())
+    lab = np.argmax(X, axis=0)
+    assert len(set(lab[:100])) == 1 and len(set(lab[100:])) == 1 and lab[0] != lab[-1]      # 100 / 50 split recovered
+    for build, rx, ry in ((L.pca, L.ZeroReg, L.ZeroReg), (L.nnmf, L.NonNegConstraint, L.NonNegConstraint)):
+        m = build(A, 3, rng=rng)
+        assert isinstance(m.rx[0], rx) and isinstance(m.ry[0], ry) and isinstance(m.losses[0], L.QuadLoss)
+    q, r = L.qpca(A, 3, scale=0.5, rng=rng), L.rpca(A, 3, scale=2.0, rng=rng)
+    assert q.rx[0].scale == 0.5 and isinstance(r.losses[0], L.HuberLoss) and r.ry[0].scale == 2.0
