@@ -76,11 +76,12 @@ def prob_scale_(glrm, columns_to_scale=None, TOL=1e-3):
         l = glrm.losses[i]
         nomissing = _observed_values(glrm, i)
         if type(l) is _l.QuadLoss and len(nomissing) > 0:
-            v = float(np.var(A[:, i], ddof=1))
+            col = A[:, i][~np.isnan(A[:, i])]                 # var(skipmissing(glrm.A[:,i]))
+            v = float(np.var(col, ddof=1)) if len(col) > 1 else 0.0
             if v > TOL:
                 l.mul_(1 / (2 * v))
         elif type(l) is _l.HuberLoss and len(nomissing) > 0:
-            v = avgerror(l, A[:, i])
+            v = avgerror(l, A[:, i][~np.isnan(A[:, i])])      # avgerror collects skipmissing(a)
             if v > TOL:
                 l.mul_(1 / (2 * v))
         else:
