@@ -98,10 +98,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # GLRM_BENCH_BACKEND=gloo is a plumbing check of the multi-rank path on a box with fewer GPUs than ranks (ranks then share
+    # devices); the measured configuration is one rank per GPU over RCCL.
+    backend = os.environ.get("GLRM_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     value_model, loss_mix, reg = 0, 0, (1, 0, 1.0)  # QuadReg(1.0)
     if args.config == "C4":    # 10M x 100k rank 64, 1e9 observations, NonNegConstraint on X and Y

@@ -1,0 +1,38 @@
+"""-m gpu: the multi-rank path of bench.py with the HIP engine on ONE GPU: two ranks (gloo instead of RCCL, both on cuda:0) run the
+sharded fit -- row / column shard handles, pipelined X exchange on a side stream, all-gather of Y and of the per-column
+objectives -- and record the same objective, bit for bit, as a single rank on the same problem."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def run(cmd, env):
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+@pytest.mark.parametrize("x_chunks,gather", [(4, "allgather"), (1, "broadcast")])
+def test_two_ranks_on_one_gpu_equal_one_rank(x_chunks, gather):
+    common = ["--steps", "3", "--warmup", "2", "--cols", "2000", "--obs-per-row", "100", "--no-convergence-run", "--no-cpu-baseline", "--tiled", "2"]
+    env = dict(os.environ, GLRM_BENCH_BACKEND="gloo", GLRM_GATHER=gather)
+    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--rows-per-gpu", "30000", "--x-chunks", str(x_chunks)] + common, env)
+    one = run([sys.executable, "bench.py", "--rows-per-gpu", "60000"] + common, dict(os.environ))
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    assert two["config"]["observed"] == one["config"]["observed"] == 60000 * 100
+    assert two["objective"]["initial"] == one["objective"]["initial"]
+    assert two["objective"]["after_warmup_and_steps"] == one["objective"]["after_warmup_and_steps"]
