@@ -36,3 +36,14 @@ def test_two_ranks_on_one_gpu_equal_one_rank(x_chunks, gather):
     assert two["config"]["observed"] == one["config"]["observed"] == 60000 * 100
     assert two["objective"]["initial"] == one["objective"]["initial"]
     assert two["objective"]["after_warmup_and_steps"] == one["objective"]["after_warmup_and_steps"]
+
+
+def test_eight_ranks_on_one_gpu_equal_one_rank():
+    """The world size the scaling bench ends at: eight row / column shards (default auto kernel choice, pipelined X exchange)."""
+    common = ["--steps", "2", "--warmup", "2", "--cols", "4000", "--obs-per-row", "200", "--no-convergence-run", "--no-cpu-baseline"]
+    env = dict(os.environ, GLRM_BENCH_BACKEND="gloo", GLRM_GATHER="allgather")
+    eight = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                 "--master-port", str(free_port()), "bench.py", "--gpus", "8", "--rows-per-gpu", "25000"] + common, env)
+    one = run([sys.executable, "bench.py", "--rows-per-gpu", "200000"] + common, dict(os.environ))
+    assert eight["n_gpus"] == 8 and eight["config"]["observed"] == one["config"]["observed"] == 200000 * 200
+    assert eight["objective"] == one["objective"]
