@@ -37,10 +37,10 @@ def cpu_baseline(args, k, q, n):
     import numpy as np
     import oracle as O
     from lowrankmodels.jl_amd import _capi
-    cores = os.cpu_count() or 1
-    # enough rows for every thread to have work (a 20k-row sample starves a 256-thread host): 2 000 rows per thread,
-    # at least --cpu-sample-rows, at most 400k rows (2e8 observations, ~5 GB)
-    ms = int(min(max(args.cpu_sample_rows, 2000 * cores), 400_000, args.rows_per_gpu))
+    cores = O.usable_cores()  # affinity mask and cgroup CPU quota, not the hardware thread count of the host
+    # enough rows for every thread to have work: 10 000 rows per thread, at least --cpu-sample-rows, at most 400k rows
+    # (2e8 observations, ~5 GB)
+    ms = int(min(max(args.cpu_sample_rows, 10_000 * cores), 400_000, args.rows_per_gpu))
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(ms, n, k, q, seed=args.seed)
     one = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)

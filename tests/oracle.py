@@ -68,6 +68,25 @@ def set_threads(n):
     oracle_lib().glrm_cpu_set_threads(int(n))
 
 
+def usable_cores():
+    """CPUs this process may actually run on: the smaller of the affinity mask and the cgroup CPU quota (a container
+    that sees 256 hardware threads under a 16-CPU quota runs 256 OpenMP threads slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def _loss_struct(loss):
     from lowrankmodels.jl_amd import _capi
     k, r, s, p0, p1 = loss.descriptor()

@@ -81,5 +81,5 @@ def run(api, label, iters):
 run(_capi.hip_api(), "hip", a.iters)
 if a.cpu:
     import oracle as O
-    O.set_threads(os.cpu_count())
-    run(O.oracle_api(), f"cpu({os.cpu_count()}thr)", max(1, a.iters // 3))
+    O.set_threads(O.usable_cores())
+    run(O.oracle_api(), f"cpu({O.usable_cores()}thr)", max(1, a.iters // 3))
