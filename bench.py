@@ -238,9 +238,13 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_update": bpu, "updates_per_launch": dom_nnz, "avg_launch_ms": dom_ms,
+                         "traffic_GBps": traffic / (dom_ms * 1e-3) / 1e9 if traffic and dom_ms > 0 else None,
+                         "traffic_frac": traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and dom_ms > 0 else None,
                          "note": "algorithmic bytes assume every update fetches its own k-vector (SURVEY.md 8(d)); the LDS-tiled "
                                  "sweeps fetch a factor vector once per workgroup and tile, so frac > 1 means on-chip reuse, "
-                                 "and `traffic` (PMC) is what actually crossed the fabric"},
+                                 "and `traffic` (PMC) is what actually crossed the fabric "
+                                 "(traffic_frac = that over the measured launch time over the HBM peak; the tiled sweeps are "
+                                 "LDS / VALU co-limited, DESIGN.md 4.2)"},
             "kernels": {"row_sweep_ms": ms_x, "col_sweep_ms": ms_y,
                         "row_sweep_GBps_algorithmic": nnz_r * bpu / (ms_x * 1e-3) / 1e9 if ms_x > 0 else None,
                         "col_sweep_GBps_algorithmic": nnz_c * bpu / (ms_y * 1e-3) / 1e9 if ms_y > 0 else None,
