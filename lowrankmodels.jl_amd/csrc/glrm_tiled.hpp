@@ -150,6 +150,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
                                            bool active, int64_t& pos, int64_t end, int tile_begin, int tile_end,
                                            const LossDesc& segloss, int lane, int j) {
   constexpr int ROWB = tile_row_bytes<G, R>(), NT = NW * 64;
+  constexpr bool FOUR = G == 4 && LOSS != 0; // four observations per step (below)
   const double two_scale = 2 * segloss.scale;
   J = 0.0;
   if (GRAD) {
@@ -190,6 +191,65 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
       // derivative of the other one comes back with one DPP move.  ~30 % (gradient pass) / ~45 % (trial pass) fewer
       // VALU instructions than one observation per step.
       const bool odd = (j & 1) != 0;
+      if constexpr (FOUR) {
+        // Losses with transcendental or branchy formulas (everything but the uniform QuadLoss model): the whole batch of four
+        // observations per step, one loss evaluation per LANE.  Partial dot products of all four are reduce-scattered in two
+        // butterfly steps (same pairings as below, so the same bits), lane u evaluates observation u, and the four derivatives
+        // come back by quad broadcasts.  The opposing vectors are re-read from LDS for the gradient update instead of being
+        // kept live across the loss evaluation (which is what made this kernel spill).
+        const int c0 = group_bcast_i32<G>(cb, 0, lane), c1 = group_bcast_i32<G>(cb, 1, lane);
+        const int c2 = group_bcast_i32<G>(cb, 2, lane), c3 = group_bcast_i32<G>(cb, 3, lane);
+        const bool ok0 = c0 < (int)hi, ok1 = ok0 && c1 < (int)hi, ok2 = ok1 && c2 < (int)hi, ok3 = ok2 && c3 < (int)hi;
+        if (ok0) {
+          const char* base = lds + j * 16 - (int)lo * ROWB;
+          const char* rp[4] = {base + c0 * ROWB, base + (ok1 ? c1 : c0) * ROWB, base + (ok2 ? c2 : c0) * ROWB, base + (ok3 ? c3 : c0) * ROWB};
+          double p[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            p[u] = 0.0;
+#pragma unroll
+            for (int i = 0; i < R / 2; ++i) {
+              const double2 y = *reinterpret_cast<const double2*>(rp[u] + i * (2 * G * 8));
+              p[u] = fma(xv.v[i].x, y.x, p[u]);
+              p[u] = fma(xv.v[i].y, y.y, p[u]);
+            }
+          }
+          const bool hi2 = (j & 2) != 0;
+          const double qa = (odd ? p[1] : p[0]) + dpp_f64<DPP_XOR1>(odd ? p[0] : p[1]); // observation 0 + odd, lanes {j, j^1}
+          const double qb = (odd ? p[3] : p[2]) + dpp_f64<DPP_XOR1>(odd ? p[2] : p[3]); // observation 2 + odd
+          const double dot = (hi2 ? qb : qa) + dpp_f64<DPP_XOR2>(hi2 ? qa : qb);        // observation j
+          const bool mine = j == 0 || (j == 1 && ok1) || (j == 2 && ok2) || (j == 3 && ok3);
+          double L, dL;
+          if constexpr (LOSS == 1) {
+            loss_both<GRAD>(segloss, dot, ab, L, dL);
+          } else {
+            const LossDesc lo_ = load_loss(a.losses, mine ? cb : c0);
+            loss_both<GRAD>(lo_, dot, ab, L, dL);
+          }
+          if (!mine) {
+            L = 0.0;
+            dL = 0.0;
+          }
+          J += L; // every observation once
+          if (GRAD) {
+            asm volatile("" ::: "memory"); // the reads below are real re-reads, not the values of the first ones kept in VGPRs
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { // list order; observations past the tile window carry a zero derivative
+              const double d = group_bcast_f64<G>(dL, u, lane);
+#pragma unroll
+              for (int i = 0; i < R / 2; ++i) {
+                const double2 y = *reinterpret_cast<const double2*>(rp[u] + i * (2 * G * 8));
+                g.v[i].x = fma(d, y.x, g.v[i].x);
+                g.v[i].y = fma(d, y.y, g.v[i].y);
+              }
+            }
+          }
+          nproc = ok3 ? 4 : (ok2 ? 3 : (ok1 ? 2 : 1));
+          if (!ok3) done = true;
+        } else {
+          done = true;
+        }
+      } else {
 #pragma unroll
       for (int u0 = 0; u0 < G; u0 += 2) {
         const int c0 = group_bcast_i32<G>(cb, u0, lane);
@@ -258,6 +318,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
           done = true;
         }
       }
+      }
       pos += nproc;
       if (!done) { // the whole batch was consumed: continue with the prefetched one
         cb = next_ok ? cn : 0x7fffffff;
@@ -268,7 +329,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
       }
     }
   }
-  J = group_sum<G>(J) * (2.0 / G); // lanes hold parity-partial sums, each observation counted G/2 times
+  J = group_sum<G>(J) * (FOUR ? 1.0 : 2.0 / G); // two per step: lanes hold parity-partial sums, each observation counted G/2 times
 }
 
 // ------------------------------------------------------------------------------------------------
