@@ -46,6 +46,31 @@ __device__ __forceinline__ double group_sum(double v) {
   return v;
 }
 
+// value of lane u of the caller's group, in every lane of the group
+template <int G>
+__device__ __forceinline__ int group_bcast_i32(int v, int u, int lane) {
+  if constexpr (G == 1) {
+    return v;
+  } else if constexpr (G == 2) {
+    return u == 0 ? __builtin_amdgcn_mov_dpp(v, 0xA0, 0xF, 0xF, false)  // quad_perm:[0,0,2,2]
+                  : __builtin_amdgcn_mov_dpp(v, 0xF5, 0xF, 0xF, false); // quad_perm:[1,1,3,3]
+  } else if constexpr (G == 4) {
+    switch (u) { // compile-time after unrolling
+      case 0: return __builtin_amdgcn_mov_dpp(v, 0x00, 0xF, 0xF, false);
+      case 1: return __builtin_amdgcn_mov_dpp(v, 0x55, 0xF, 0xF, false);
+      case 2: return __builtin_amdgcn_mov_dpp(v, 0xAA, 0xF, 0xF, false);
+      default: return __builtin_amdgcn_mov_dpp(v, 0xFF, 0xF, 0xF, false);
+    }
+  } else {
+    return __shfl(v, (lane & ~(G - 1)) + u, 64);
+  }
+}
+template <int G>
+__device__ __forceinline__ double group_bcast_f64(double v, int u, int lane) {
+  const int lo = group_bcast_i32<G>(__double2loint(v), u, lane), hi = group_bcast_i32<G>(__double2hiint(v), u, lane);
+  return __hiloint2double(hi, lo);
+}
+
 // All-reduce over the 64/G groups of a wave for values that are replicated inside each group
 // (xor-butterfly on the group-index bits; ds_bpermute, only used once per pass).
 template <int G>

@@ -69,6 +69,7 @@ template <int G, int R, int WAVES, int LOSS, int U, bool GRAD>
 __device__ __forceinline__ double sweep_pass(const SweepArgs& a, const Vec<G, R>& xv, Vec<G, R>& g, int64_t beg,
                                              int64_t len, int gg, int j, const LossDesc& segloss) {
   constexpr int KP = G * R, NG = 64 / G, TG = NG * WAVES;
+  constexpr bool SCATTER = G == 4 && U == 4 && LOSS != LOSS_QUAD_UNIFORM;
   double J = 0.0;
   if (GRAD) {
 #pragma unroll
@@ -114,6 +115,51 @@ __device__ __forceinline__ double sweep_pass(const SweepArgs& a, const Vec<G, R>
       c[u] = idx[tn];
       av_next[u] = vals[tn];
     }
+    if constexpr (SCATTER) {
+      // Four observations per group and trip, one loss evaluation per LANE: the partial dot products are reduce-scattered in
+      // two butterfly steps (the pairings of group_sum, hence its bits), lane u evaluates observation u, and the derivatives
+      // come back by quad broadcasts.  The loop is wave-uniform, so every DPP source lane is active.
+      double p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        p[u] = 0.0;
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+          p[u] = fma(xv.v[i].x, y[u][i].x, p[u]);
+          p[u] = fma(xv.v[i].y, y[u][i].y, p[u]);
+        }
+      }
+      const bool odd = (j & 1) != 0, hi2 = (j & 2) != 0;
+      const double qa = (odd ? p[1] : p[0]) + dpp_f64<DPP_XOR1>(odd ? p[0] : p[1]);
+      const double qb = (odd ? p[3] : p[2]) + dpp_f64<DPP_XOR1>(odd ? p[2] : p[3]);
+      const double dot = (hi2 ? qb : qa) + dpp_f64<DPP_XOR2>(hi2 ? qa : qb); // observation u == j
+      const double am = hi2 ? (odd ? av[3] : av[2]) : (odd ? av[1] : av[0]);
+      const bool vm = hi2 ? (odd ? valid[3] : valid[2]) : (odd ? valid[1] : valid[0]);
+      double L, dL;
+      if constexpr (LOSS == LOSS_SEGMENT) {
+        loss_both<GRAD>(segloss, dot, am, L, dL);
+      } else {
+        const int cm = hi2 ? (odd ? ccur[3] : ccur[2]) : (odd ? ccur[1] : ccur[0]);
+        const LossDesc lo = load_loss(a.losses, cm);
+        loss_both<GRAD>(lo, dot, am, L, dL);
+      }
+      if (!vm) {
+        L = 0.0;
+        dL = 0.0;
+      }
+      J += L; // lane-partial: summed over the group after the loop
+      if (GRAD) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double d = group_bcast_f64<G>(dL, u, j);
+#pragma unroll
+          for (int i = 0; i < R / 2; ++i) {
+            g.v[i].x = fma(d, y[u][i].x, g.v[i].x);
+            g.v[i].y = fma(d, y[u][i].y, g.v[i].y);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       double dot = 0.0;
@@ -147,7 +193,9 @@ __device__ __forceinline__ double sweep_pass(const SweepArgs& a, const Vec<G, R>
         }
       }
     }
+    }
   }
+  if constexpr (SCATTER) J = group_sum<G>(J);
   J = across_groups_sum<G>(J);
   if (GRAD) {
 #pragma unroll
@@ -782,8 +830,10 @@ static void launch_sweep_loss(int loss, int unroll, const SweepArgs& a, hipStrea
       if (unroll == 2) GLRM_LAUNCH(LOSS_QUAD_UNIFORM, 2);
       else GLRM_LAUNCH(LOSS_QUAD_UNIFORM, 1);
       break;
-    case LOSS_SEGMENT: GLRM_LAUNCH(LOSS_SEGMENT, 1); break;
-    default: GLRM_LAUNCH(LOSS_PER_OBS, 1); break;
+    // G == 4: four observations per trip, one loss evaluation per lane (C5-family row sweep 169 -> 115 ms); the multi-wave
+    // sweeps of long same-loss segments are bound by the factor gather and keep the leaner one-observation body
+    case LOSS_SEGMENT: GLRM_LAUNCH(LOSS_SEGMENT, (G == 4 && WAVES == 1 ? 4 : 1)); break;
+    default: GLRM_LAUNCH(LOSS_PER_OBS, (G == 4 ? 4 : 1)); break;
   }
 #undef GLRM_LAUNCH
 }
