@@ -209,6 +209,17 @@ def test_moderate_sparse_shape_k32():
     compare(pa, X0, Y0, L.ProxGradParams(max_iter=12))
 
 
+def test_mixed_losses_k32_several_tiles():
+    """The C5 recipe at 1/2000 of the size: 2500 x 2000, rank 32, Quad / Logistic / OrdinalHinge columns, 100 observations per row.
+    2000 columns = 4 LDS tiles, so batches of four observations straddle tile windows and loss kinds in the row sweep."""
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(2500, 2000, 32, 100, value_model=0, loss_mix=1)
+    kinds = [L.QuadLoss().descriptor(), L.LogisticLoss().descriptor(), L.OrdinalHingeLoss(1, 5).descriptor()]
+    losses = np.array([kinds[f % 3] for f in range(2000)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 1.0)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(2500, 2000, 32, rowptr, colidx, rowvals, colptr, rowidx, colvals, losses, reg, reg)
+    compare(pa, 0.3 * X0, 0.3 * Y0, L.ProxGradParams(max_iter=10))
+
+
 def test_objective_entry_point():
     rng = np.random.default_rng(35)
     pa, X0, Y0 = random_problem(rng, 70, 30, 4, 0.5, rx=L.OneReg(0.3))
