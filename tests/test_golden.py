@@ -119,3 +119,9 @@ def test_line_search_invariants():
                 assert ok and a > params.min_stepsize, a
     finally:
         api.destroy(h)
+
+
+def test_usable_cores_is_bounded_by_the_host():
+    """bench.py's cpu_baseline thread count: affinity mask and cgroup quota, never more than the hardware threads."""
+    n = O.usable_cores()
+    assert isinstance(n, int) and 1 <= n <= (os.cpu_count() or 1)
