@@ -126,7 +126,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
                                            bool active, int64_t& pos, int64_t end, int tile_begin, int tile_end,
                                            const LossDesc& segloss, int lane, int j) {
   constexpr int ROWB = tile_row_bytes<G, R>(), NT = NW * 64;
-  constexpr bool FOUR = G == 4 && LOSS != 0; // four observations per step (below)
+  constexpr bool FOUR = (G == 4 || G == 8) && LOSS != 0; // the whole batch of G observations per step (below)
   const double two_scale = 2 * segloss.scale;
   J = 0.0;
   if (GRAD) {
@@ -168,20 +168,27 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
       // VALU instructions than one observation per step.
       const bool odd = (j & 1) != 0;
       if constexpr (FOUR) {
-        // Losses with transcendental or branchy formulas (everything but the uniform QuadLoss model): the whole batch of four
-        // observations per step, one loss evaluation per LANE.  Partial dot products of all four are reduce-scattered in two
-        // butterfly steps (same pairings as below, so the same bits), lane u evaluates observation u, and the four derivatives
-        // come back by quad broadcasts.  The opposing vectors are re-read from LDS for the gradient update instead of being
-        // kept live across the loss evaluation (which is what made this kernel spill).
-        const int c0 = group_bcast_i32<G>(cb, 0, lane), c1 = group_bcast_i32<G>(cb, 1, lane);
-        const int c2 = group_bcast_i32<G>(cb, 2, lane), c3 = group_bcast_i32<G>(cb, 3, lane);
-        const bool ok0 = c0 < (int)hi, ok1 = ok0 && c1 < (int)hi, ok2 = ok1 && c2 < (int)hi, ok3 = ok2 && c3 < (int)hi;
-        if (ok0) {
-          const char* base = lds + j * 16 - (int)lo * ROWB;
-          const char* rp[4] = {base + c0 * ROWB, base + (ok1 ? c1 : c0) * ROWB, base + (ok2 ? c2 : c0) * ROWB, base + (ok3 ? c3 : c0) * ROWB};
-          double p[4];
+        // Losses with transcendental or branchy formulas (everything but the uniform QuadLoss model), G = 4 or 8: the whole
+        // batch of G observations per step, one loss evaluation per LANE.  The partial dot products of all G observations are
+        // reduce-scattered in log2(G) butterfly steps (same pairings as below, so the same bits), lane u evaluates observation
+        // u, and the G derivatives come back by broadcasts.  The opposing vectors are re-read from LDS for the gradient update
+        // instead of being kept live across the loss evaluation (which is what made this kernel spill).
+        int c[G];
+        bool ok[G];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < G; ++u) {
+          c[u] = group_bcast_i32<G>(cb, u, lane);
+          ok[u] = (u == 0 || ok[u - 1]) && c[u] < (int)hi; // c == INT_MAX past the end of the segment
+        }
+        if (ok[0]) {
+          const char* base = lds + j * 16 - (int)lo * ROWB;
+          const char* rp[G];
+          double p[G];
+          bool mine = false;
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            rp[u] = base + (ok[u] ? c[u] : c[0]) * ROWB;
+            mine = (j == u) ? ok[u] : mine;
             p[u] = 0.0;
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) {
@@ -191,15 +198,23 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
             }
           }
           const bool hi2 = (j & 2) != 0;
-          const double qa = (odd ? p[1] : p[0]) + dpp_f64<DPP_XOR1>(odd ? p[0] : p[1]); // observation 0 + odd, lanes {j, j^1}
-          const double qb = (odd ? p[3] : p[2]) + dpp_f64<DPP_XOR1>(odd ? p[2] : p[3]); // observation 2 + odd
-          const double dot = (hi2 ? qb : qa) + dpp_f64<DPP_XOR2>(hi2 ? qa : qb);        // observation j
-          const bool mine = j == 0 || (j == 1 && ok1) || (j == 2 && ok2) || (j == 3 && ok3);
+          double q[G / 2]; // q[i]: observation 2i + odd, summed over lanes {j, j^1}
+#pragma unroll
+          for (int i = 0; i < G / 2; ++i) q[i] = (odd ? p[2 * i + 1] : p[2 * i]) + dpp_f64<DPP_XOR1>(odd ? p[2 * i] : p[2 * i + 1]);
+          double dot;
+          if constexpr (G == 4) {
+            dot = (hi2 ? q[1] : q[0]) + dpp_f64<DPP_XOR2>(hi2 ? q[0] : q[1]); // observation j
+          } else {
+            const bool hi4 = (j & 4) != 0;
+            const double r0 = (hi2 ? q[1] : q[0]) + dpp_f64<DPP_XOR2>(hi2 ? q[0] : q[1]); // observation (j & 3)
+            const double r1 = (hi2 ? q[3] : q[2]) + dpp_f64<DPP_XOR2>(hi2 ? q[2] : q[3]); // observation 4 + (j & 3)
+            dot = (hi4 ? r1 : r0) + swizzle_xor_f64<4>(hi4 ? r0 : r1);                     // observation j
+          }
           double L, dL;
           if constexpr (LOSS == 1) {
             loss_both<GRAD>(segloss, dot, ab, L, dL);
           } else {
-            const LossDesc lo_ = load_loss(a.losses, mine ? cb : c0);
+            const LossDesc lo_ = load_loss(a.losses, mine ? cb : c[0]);
             loss_both<GRAD>(lo_, dot, ab, L, dL);
           }
           if (!mine) {
@@ -210,7 +225,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
           if (GRAD) {
             asm volatile("" ::: "memory"); // the reads below are real re-reads, not the values of the first ones kept in VGPRs
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { // list order; observations past the tile window carry a zero derivative
+            for (int u = 0; u < G; ++u) { // list order; observations past the tile window carry a zero derivative
               const double d = group_bcast_f64<G>(dL, u, lane);
 #pragma unroll
               for (int i = 0; i < R / 2; ++i) {
@@ -220,8 +235,9 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
               }
             }
           }
-          nproc = ok3 ? 4 : (ok2 ? 3 : (ok1 ? 2 : 1));
-          if (!ok3) done = true;
+#pragma unroll
+          for (int u = 0; u < G; ++u) nproc += ok[u] ? 1 : 0;
+          if (!ok[G - 1]) done = true;
         } else {
           done = true;
         }

@@ -220,6 +220,21 @@ def test_mixed_losses_k32_several_tiles():
     compare(pa, 0.3 * X0, 0.3 * Y0, L.ProxGradParams(max_iter=10))
 
 
+@pytest.mark.parametrize("k", [40, 64])
+def test_mixed_losses_eight_lane_layout(k):
+    """k = 33...64 puts eight lanes on an observation; the non-quadratic step then takes the batch of eight observations at once."""
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(1200, 900, k, 60, value_model=0, loss_mix=1)
+    kinds = [L.QuadLoss().descriptor(), L.LogisticLoss().descriptor(), L.OrdinalHingeLoss(1, 5).descriptor()]
+    losses = np.array([kinds[f % 3] for f in range(900)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 1.0)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(1200, 900, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, losses, reg, reg)
+    compare(pa, 0.3 * X0, 0.3 * Y0, L.ProxGradParams(max_iter=10))
+    # one non-quadratic loss for every column: the segment-uniform variant
+    hub = np.array([L.HuberLoss(1.0, crossover=0.5).descriptor()], dtype=_capi.LOSS_DTYPE)
+    pa2 = _capi.ProblemArrays(1200, 900, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, hub, reg, reg)
+    compare(pa2, 0.3 * X0, 0.3 * Y0, L.ProxGradParams(max_iter=8))
+
+
 def test_objective_entry_point():
     rng = np.random.default_rng(35)
     pa, X0, Y0 = random_problem(rng, 70, 30, 4, 0.5, rx=L.OneReg(0.3))
