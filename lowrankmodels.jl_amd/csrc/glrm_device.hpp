@@ -98,7 +98,8 @@ __device__ __forceinline__ LossDesc load_loss(const glrm_loss* t, int64_t i) {
 __device__ __forceinline__ double sign_jl(double d) { return d > 0 ? 1.0 : (d < 0 ? -1.0 : d); }
 
 // evaluate(l,u,a) and grad(l,u,a) in one go (the gradient pass needs both).
-template <bool NEED_GRAD>
+// TRIG = false compiles the PeriodicLoss case out (NaN): see LOSS_*_NOTRIG in glrm_engine.hpp.
+template <bool NEED_GRAD, bool TRIG = true>
 __device__ __forceinline__ void loss_both(const LossDesc& l, double u, double a, double& L, double& dL) {
   const double s = l.scale;
   dL = 0.0;
@@ -128,9 +129,14 @@ __device__ __forceinline__ void loss_both(const LossDesc& l, double u, double a,
       break;
     }
     case GLRM_LOSS_PERIODIC: { // :216,218
-      const double T = l.p0, w = (a - u) * (2 * M_PI) / T;
-      L = s * (1 - cos(w));
-      if (NEED_GRAD) dL = -s * ((2 * M_PI) / T) * sin(w);
+      if constexpr (TRIG) {
+        const double T = l.p0, w = (a - u) * (2 * M_PI) / T;
+        L = s * (1 - cos(w));
+        if (NEED_GRAD) dL = -s * ((2 * M_PI) / T) * sin(w);
+      } else {
+        L = __builtin_nan("");
+        dL = L;
+      }
       break;
     }
     case GLRM_LOSS_POISSON: { // :237-241

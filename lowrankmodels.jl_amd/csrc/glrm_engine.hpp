@@ -12,7 +12,11 @@
 
 #include "../../include/glrm_hip.h"
 
-enum { LOSS_QUAD_UNIFORM = 0, LOSS_SEGMENT = 1, LOSS_PER_OBS = 2 };
+// kernel variants by loss model.  The *_NOTRIG variants are compiled without PeriodicLoss (its sin / cos with full range reduction
+// costs ~60 VGPRs of pressure in every kernel that merely CONTAINS the case); models without a PeriodicLoss column use them.
+enum { LOSS_QUAD_UNIFORM = 0, LOSS_SEGMENT = 1, LOSS_PER_OBS = 2, LOSS_SEGMENT_NOTRIG = 3, LOSS_PER_OBS_NOTRIG = 4 };
+constexpr int loss_mode(int loss) { return loss >= 3 ? loss - 2 : loss; }
+constexpr bool loss_trig(int loss) { return loss < 3; }
 
 extern thread_local char g_err[768];
 
@@ -80,6 +84,7 @@ struct glrm_handle {
   glrm_loss* losses = nullptr;
   int64_t n_losses = 0;
   bool loss_quad_uniform = false;
+  bool has_trig = false; // some column carries a PeriodicLoss
   glrm_reg *rx = nullptr, *ry = nullptr;
   int64_t n_rx = 0, n_ry = 0;
   double *alpharow = nullptr, *alphacol = nullptr;

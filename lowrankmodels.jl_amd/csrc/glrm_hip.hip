@@ -70,6 +70,8 @@ __device__ __forceinline__ double sweep_pass(const SweepArgs& a, const Vec<G, R>
                                              int64_t len, int gg, int j, const LossDesc& segloss) {
   constexpr int KP = G * R, NG = 64 / G, TG = NG * WAVES;
   constexpr bool SCATTER = G == 4 && U == 4 && LOSS != LOSS_QUAD_UNIFORM;
+  constexpr int LM = loss_mode(LOSS);
+  constexpr bool TRIG = loss_trig(LOSS);
   double J = 0.0;
   if (GRAD) {
 #pragma unroll
@@ -136,12 +138,12 @@ __device__ __forceinline__ double sweep_pass(const SweepArgs& a, const Vec<G, R>
       const double am = hi2 ? (odd ? av[3] : av[2]) : (odd ? av[1] : av[0]);
       const bool vm = hi2 ? (odd ? valid[3] : valid[2]) : (odd ? valid[1] : valid[0]);
       double L, dL;
-      if constexpr (LOSS == LOSS_SEGMENT) {
-        loss_both<GRAD>(segloss, dot, am, L, dL);
+      if constexpr (LM == LOSS_SEGMENT) {
+        loss_both<GRAD, TRIG>(segloss, dot, am, L, dL);
       } else {
         const int cm = hi2 ? (odd ? ccur[3] : ccur[2]) : (odd ? ccur[1] : ccur[0]);
         const LossDesc lo = load_loss(a.losses, cm);
-        loss_both<GRAD>(lo, dot, am, L, dL);
+        loss_both<GRAD, TRIG>(lo, dot, am, L, dL);
       }
       if (!vm) {
         L = 0.0;
@@ -174,11 +176,11 @@ __device__ __forceinline__ double sweep_pass(const SweepArgs& a, const Vec<G, R>
         const double d = dot - av[u];
         L = segloss.scale * (d * d);
         dL = 2 * d * segloss.scale;
-      } else if constexpr (LOSS == LOSS_SEGMENT) {
-        loss_both<GRAD>(segloss, dot, av[u], L, dL);
+      } else if constexpr (LM == LOSS_SEGMENT) {
+        loss_both<GRAD, TRIG>(segloss, dot, av[u], L, dL);
       } else {
         const LossDesc lo = load_loss(a.losses, ccur[u]);
-        loss_both<GRAD>(lo, dot, av[u], L, dL);
+        loss_both<GRAD, TRIG>(lo, dot, av[u], L, dL);
       }
       if (!valid[u]) {
         L = 0.0;
@@ -264,7 +266,7 @@ __global__ void __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64) sweep_kernel(co
   for (int i = 0; i < R / 2; ++i) x.v[i] = ownp[i * G + j];
   const RegDesc rd = load_reg(a.regs, a.reg_single ? 0 : seg);
   LossDesc segloss;
-  if constexpr (LOSS != LOSS_PER_OBS) segloss = load_loss(a.losses, a.loss_by_segment ? gseg : 0);
+  if constexpr (loss_mode(LOSS) != LOSS_PER_OBS) segloss = load_loss(a.losses, a.loss_by_segment ? gseg : 0);
   else segloss = LossDesc{0, 1.0, 0.0, 0.0};
 
   // pass 1: gradient + objective at the current point (proxgrad.jl:122-135 / :165-178)
@@ -640,6 +642,8 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   if ((rc = dev_copy_in(&h->rx, p->rx, p->n_rx, false, st))) return rc;
   if ((rc = dev_copy_in(&h->ry, p->ry, p->n_ry, false, st))) return rc;
   h->loss_quad_uniform = p->n_losses == 1 && p->losses[0].kind == GLRM_LOSS_QUAD;
+  h->has_trig = false;
+  for (int64_t i = 0; i < p->n_losses; ++i) h->has_trig = h->has_trig || p->losses[i].kind == GLRM_LOSS_PERIODIC;
   const int64_t ml1 = h->ml > 0 ? h->ml : 1, nl1 = h->nl > 0 ? h->nl : 1;
   HIPCK(hipMalloc((void**)&h->alpharow, ml1 * 8));
   HIPCK(hipMalloc((void**)&h->alphacol, nl1 * 8));
@@ -833,6 +837,8 @@ static void launch_sweep_loss(int loss, int unroll, const SweepArgs& a, hipStrea
     // G == 4: four observations per trip, one loss evaluation per lane (C5-family row sweep 169 -> 115 ms); the multi-wave
     // sweeps of long same-loss segments are bound by the factor gather and keep the leaner one-observation body
     case LOSS_SEGMENT: GLRM_LAUNCH(LOSS_SEGMENT, (G == 4 && WAVES == 1 ? 4 : 1)); break;
+    case LOSS_SEGMENT_NOTRIG: GLRM_LAUNCH(LOSS_SEGMENT_NOTRIG, (G == 4 && WAVES == 1 ? 4 : 1)); break;
+    case LOSS_PER_OBS_NOTRIG: GLRM_LAUNCH(LOSS_PER_OBS_NOTRIG, (G == 4 ? 4 : 1)); break;
     default: GLRM_LAUNCH(LOSS_PER_OBS, (G == 4 ? 4 : 1)); break;
   }
 #undef GLRM_LAUNCH
@@ -912,6 +918,7 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
   else if (h->n_losses == 1) { loss = LOSS_SEGMENT; a.loss_by_segment = 0; }
   else if (rows) { loss = LOSS_PER_OBS; a.loss_by_segment = 0; }
   else { loss = LOSS_SEGMENT; a.loss_by_segment = 1; }
+  if (!h->has_trig && loss != LOSS_QUAD_UNIFORM) loss += 2; // LOSS_*_NOTRIG: kernels compiled without the PeriodicLoss case
   glrm_handle::Ev ev{};
   const bool timed = h->profile && !eval_only;
   if (timed) {

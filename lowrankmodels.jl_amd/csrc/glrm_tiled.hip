@@ -179,6 +179,8 @@ static int launch_tiled_layout(int cfg, int loss, int kind, const TiledArgs& a, 
   switch (loss) {
     case LOSS_QUAD_UNIFORM: return GLRM_TL(0);
     case LOSS_SEGMENT: return GLRM_TL(1);
+    case LOSS_SEGMENT_NOTRIG: return GLRM_TL(3);
+    case LOSS_PER_OBS_NOTRIG: return GLRM_TL(4);
     default: return GLRM_TL(2);
   }
 #undef GLRM_TL

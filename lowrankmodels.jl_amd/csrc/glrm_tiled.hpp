@@ -211,11 +211,11 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
             dot = (hi4 ? r1 : r0) + swizzle_xor_f64<4>(hi4 ? r0 : r1);                     // observation j
           }
           double L, dL;
-          if constexpr (LOSS == 1) {
-            loss_both<GRAD>(segloss, dot, ab, L, dL);
+          if constexpr (loss_mode(LOSS) == 1) {
+            loss_both<GRAD, loss_trig(LOSS)>(segloss, dot, ab, L, dL);
           } else {
             const LossDesc lo_ = load_loss(a.losses, mine ? cb : c[0]);
-            loss_both<GRAD>(lo_, dot, ab, L, dL);
+            loss_both<GRAD, loss_trig(LOSS)>(lo_, dot, ab, L, dL);
           }
           if (!mine) {
             L = 0.0;
@@ -279,11 +279,11 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
             const double d = dot - av;
             L = segloss.scale * (d * d);
             dL = d * two_scale; // == (2*d)*scale bit for bit: doubling is exact
-          } else if constexpr (LOSS == 1) {
-            loss_both<GRAD>(segloss, dot, av, L, dL);
+          } else if constexpr (loss_mode(LOSS) == 1) {
+            loss_both<GRAD, loss_trig(LOSS)>(segloss, dot, av, L, dL);
           } else {
             const LossDesc lo_ = load_loss(a.losses, odd ? (ok1 ? c1 : c0) : c0);
-            loss_both<GRAD>(lo_, dot, av, L, dL);
+            loss_both<GRAD, loss_trig(LOSS)>(lo_, dot, av, L, dL);
           }
           if (odd && !ok1) {
             L = 0.0;
@@ -346,7 +346,7 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_sweep_kernel(const TiledArgs
   Vec<G, R> g, xn;
   const RegDesc rd = load_reg(a.regs, (a.reg_single || !have) ? 0 : seg);
   LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
-  if constexpr (LOSS != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
+  if constexpr (loss_mode(LOSS) != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
   const double l = (double)(end - beg) + 1.0;
 
   double Jold;
@@ -460,7 +460,7 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_col_pass_kernel(const TiledA
 #pragma unroll
   for (int i = 0; i < R / 2; ++i) x.v[i] = have ? xp[i * G + j] : make_double2(0.0, 0.0);
   LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
-  if constexpr (LOSS != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
+  if constexpr (loss_mode(LOSS) != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
   int64_t pos = have ? lower_bound_idx<G>(a.idx, beg, end, (int64_t)tb * TILE) : 0;
   double J;
   tiled_pass<G, R, NW, TILE, LOSS, GRAD>(a, lds, x, g, J, have, pos, end, tb, te, segloss, lane, j);
