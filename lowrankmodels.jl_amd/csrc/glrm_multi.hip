@@ -59,6 +59,19 @@ static int setup_split(glrm_handle* h) {
   return GLRM_OK;
 }
 
+// GDC = 8 when no embedding is wider (gradient registers per lane: 8 instead of 32); TRIG: see LOSS_*_NOTRIG in glrm_engine.hpp
+template <bool GRAD>
+static void launch_colpass(bool small, bool trig, dim3 grid, size_t lds, hipStream_t st, const SplitArgs& sa) {
+  constexpr int D = GLRM_MAX_EMBEDDING_DIM;
+  if (small) {
+    if (trig) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, true>), grid, dim3(512), lds, st, sa);
+    else hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, false>), grid, dim3(512), lds, st, sa);
+  } else {
+    if (trig) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, D, true>), grid, dim3(512), lds, st, sa);
+    else hipLaunchKernelGGL((multi_colpass_kernel<GRAD, D, false>), grid, dim3(512), lds, st, sa);
+  }
+}
+
 static int run_split_cols(glrm_handle* h, const MultiArgs& a) {
   SplitArgs sa{};
   sa.m = a;
@@ -76,16 +89,14 @@ static int run_split_cols(glrm_handle* h, const MultiArgs& a) {
   sa.point = a.own;
   if (a.mode == 1) { // losses only
     sa.round = -1;
-    if (small) hipLaunchKernelGGL((multi_colpass_kernel<false, 8>), grid, dim3(512), lds_pass, st, sa);
-    else hipLaunchKernelGGL((multi_colpass_kernel<false, GLRM_MAX_EMBEDDING_DIM>), grid, dim3(512), lds_pass, st, sa);
+    launch_colpass<false>(small, h->has_trig, grid, lds_pass, st, sa);
     hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
     HIPCK(hipGetLastError());
     return GLRM_OK;
   }
   sa.round = 0;
   HIPCK(hipMemsetAsync(h->mnactive, 0, 4, st));
-  if (small) hipLaunchKernelGGL((multi_colpass_kernel<true, 8>), grid, dim3(512), lds_pass, st, sa);
-  else hipLaunchKernelGGL((multi_colpass_kernel<true, GLRM_MAX_EMBEDDING_DIM>), grid, dim3(512), lds_pass, st, sa);
+  launch_colpass<true>(small, h->has_trig, grid, lds_pass, st, sa);
   hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
   HIPCK(hipGetLastError());
   if (a.mode == 2) return GLRM_OK;
@@ -97,8 +108,7 @@ static int run_split_cols(glrm_handle* h, const MultiArgs& a) {
     if (nact == 0) break;
     sa.round = round;
     HIPCK(hipMemsetAsync(h->mnactive, 0, 4, st));
-    if (small) hipLaunchKernelGGL((multi_colpass_kernel<false, 8>), grid, dim3(512), lds_pass, st, sa);
-    else hipLaunchKernelGGL((multi_colpass_kernel<false, GLRM_MAX_EMBEDDING_DIM>), grid, dim3(512), lds_pass, st, sa);
+    launch_colpass<false>(small, h->has_trig, grid, lds_pass, st, sa);
     hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
     HIPCK(hipGetLastError());
   }
@@ -140,14 +150,20 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
   if (a.nseg <= 0) return GLRM_OK;
   if (rows) {
     const size_t lds = multi_lds_doubles(true, 1, h->kp, h->dmax, a.lgP) * 8;
-    hipLaunchKernelGGL((multi_sweep_kernel<true, 1>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+    if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, true>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+    else hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
   } else {
     const int rc = setup_split(h); // decides once per handle whether the columns are long enough to split
     if (rc) return rc;
     if (h->col_nsplit > 1) return run_split_cols(h, a);
     const size_t lds = multi_lds_doubles(false, 8, h->kp, h->dmax, a.lgP) * 8;
-    if (h->dmax <= 8) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
-    else hipLaunchKernelGGL((multi_sweep_kernel<false, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+    if (h->dmax <= 8) {
+      if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, true>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+      else hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, false>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+    } else {
+      if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, GLRM_MAX_EMBEDDING_DIM, true>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+      else hipLaunchKernelGGL((multi_sweep_kernel<false, 8, GLRM_MAX_EMBEDDING_DIM, false>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+    }
   }
   HIPCK(hipGetLastError());
   return GLRM_OK;

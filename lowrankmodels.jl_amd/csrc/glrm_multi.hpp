@@ -108,13 +108,13 @@ __device__ inline double vloss_eval(const LossDesc& l, const double* u, int d, i
     case GLRM_LOSS_OVA: { // :424-430
       const LossDesc b = bin_loss_of(l);
       double loss = 0.0, L, dL;
-      for (int j = 0; j < d; ++j) { loss_both<false>(b, u[j], a == j ? 1.0 : 0.0, L, dL); loss += L; }
+      for (int j = 0; j < d; ++j) { loss_both<false, false>(b, u[j], a == j ? 1.0 : 0.0, L, dL); loss += L; }
       return s * loss;
     }
     case GLRM_LOSS_BVS: { // :461-467
       const LossDesc b = bin_loss_of(l);
       double loss = 0.0, L, dL;
-      for (int j = 0; j < d; ++j) { loss_both<false>(b, u[j], a > j ? 1.0 : 0.0, L, dL); loss += L; }
+      for (int j = 0; j < d; ++j) { loss_both<false, false>(b, u[j], a > j ? 1.0 : 0.0, L, dL); loss += L; }
       return s * loss;
     }
     case GLRM_LOSS_ORDISTIC: { // :499-505
@@ -148,12 +148,12 @@ __device__ inline double vloss_grad(const LossDesc& l, const double* u, int d, i
     }
     case GLRM_LOSS_OVA: {
       double L, dL;
-      loss_both<true>(bin_loss_of(l), u[j], a == j ? 1.0 : 0.0, L, dL);
+      loss_both<true, false>(bin_loss_of(l), u[j], a == j ? 1.0 : 0.0, L, dL);
       return s * dL;
     }
     case GLRM_LOSS_BVS: {
       double L, dL;
-      loss_both<true>(bin_loss_of(l), u[j], a > j ? 1.0 : 0.0, L, dL);
+      loss_both<true, false>(bin_loss_of(l), u[j], a > j ? 1.0 : 0.0, L, dL);
       return s * dL;
     }
     case GLRM_LOSS_ORDISTIC: { // :507-519
@@ -319,7 +319,7 @@ __device__ __forceinline__ double slot_reduce(double v, int lg, Op op) {
 //   Multinomial: sumexp_j of the reference is sum_j' exp(u_j' - max u) for every j, and exp(-M_j) = exp(u_j - max u);
 //   Ordistic:    the same with v_j = -u_j^2;
 //   MultinomialOrdinal: enforce_MNLOrdRules (:572-578) in closed form, u'_j = min(u_0, u_1 + TOL, ..., u_j + j TOL, -TOL) - j TOL.
-template <bool GRAD>
+template <bool GRAD, bool TRIG>
 __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double av, int dd, int sub, int lg, int slot_lane0, double* us,
                                   double& cg) {
   const double s = l.scale;
@@ -339,7 +339,7 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
     else if (kind == GLRM_LOSS_ORDISTIC) term = exp(-(u * u) - mx);
     else if (kind == GLRM_LOSS_OVA || kind == GLRM_LOSS_BVS) {
       const bool truth = kind == GLRM_LOSS_OVA ? a == sub : a > sub;
-      loss_both<GRAD>(bin_loss_of(l), u, truth ? 1.0 : 0.0, term, dLb);
+      loss_both<GRAD, false>(bin_loss_of(l), u, truth ? 1.0 : 0.0, term, dLb);
     }
   }
   const double se = slot_reduce(term, lg, OpSum());
@@ -367,7 +367,7 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
   cg = 0.0;
   double L = 0.0;
   if (dd == 1) {
-    loss_both<GRAD>(l, u0, av, L, cg);
+    loss_both<GRAD, TRIG>(l, u0, av, L, cg);
   } else if (vec) {
     switch (kind) {
       case GLRM_LOSS_MULTINOMIAL:
@@ -412,7 +412,7 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
 // up in lane j), the loss and its d-vector gradient are evaluated lane-parallel (vloss_lanes), and lane `sub` accumulates
 // component `sub` of the gradient.  Index / value loads run two wave-iterations ahead and (columns) the opposing row
 // one iteration ahead.  Slot partials are combined in slot order, wave partials in wave order.
-template <bool ROWS, int NW, bool GRAD, int GDC = GLRM_MAX_EMBEDDING_DIM>
+template <bool ROWS, int NW, bool GRAD, int GDC, bool TRIG>
 __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, const double* own, double* wbase, double* Gt, double* red,
                                     const LossDesc& lseg, int dseg) {
   constexpr int NT = NW * 64, GD = ROWS ? 1 : GDC; // GDC >= the largest embedding dimension of the problem
@@ -480,7 +480,7 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
       u0 = j == 0 ? r : u0;
     }
     double cg = 0.0;
-    const double L = obs_loss<GRAD>(l, u, u0, av, dd, sub, lg, lane - sub, us, cg);
+    const double L = obs_loss<GRAD, TRIG>(l, u, u0, av, dd, sub, lg, lane - sub, us, cg);
     lsum += L;
     if constexpr (GRAD) {
       const bool vec = valid && d > 1;
@@ -548,7 +548,8 @@ __host__ __device__ inline size_t multi_lds_doubles(bool rows, int nw, int kp, i
   return 3 * docap * S + 64 + 16 + (size_t)nw * sl * (dtcap * S + 64);
 }
 
-template <bool ROWS, int NW, int GDC = GLRM_MAX_EMBEDDING_DIM>
+// TRIG = false: the scalar-loss columns of the model hold no PeriodicLoss (LOSS_*_NOTRIG in glrm_engine.hpp)
+template <bool ROWS, int NW, int GDC, bool TRIG>
 __global__ void __launch_bounds__(NW * 64, NW == 1 ? 4 : 2) multi_sweep_kernel(const MultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NT = NW * 64;
@@ -580,11 +581,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 4 : 2) multi_sweep_kernel(c
   const glrm_reg rg = a.regs[a.reg_single ? 0 : s];
 
   if (a.mode == 1) { // losses only
-    const double tot = multi_pass<ROWS, NW, false, GDC>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
+    const double tot = multi_pass<ROWS, NW, false, GDC, TRIG>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
     if (tid == 0 && a.obj) a.obj[gseg] = tot;
     return;
   }
-  const double loss_old = multi_pass<ROWS, NW, true, GDC>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
+  const double loss_old = multi_pass<ROWS, NW, true, GDC, TRIG>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
   const double l1 = (double)(e - b) + 1;
   if (a.mode == 2) { // sparse_proxgrad.jl:72-78 / :94-99: scale the gradient, add, prox -- no line search
     const double st = a.fixed_alpha / l1;
@@ -608,7 +609,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 4 : 2) multi_sweep_kernel(c
     }
     __syncthreads();
     block_prox<NW>(ownB, S, k, DO, rg, stepsize, tmp);
-    const double nloss = multi_pass<ROWS, NW, false, GDC>(a, b, e, ownB, wbase, Gt, red, lseg, dseg);
+    const double nloss = multi_pass<ROWS, NW, false, GDC, TRIG>(a, b, e, ownB, wbase, Gt, red, lseg, dseg);
     const double nobj = nloss + block_reg_eval<NW>(ownB, S, k, DO, rg, red);
     ++ntr;
     if (nobj < obj) {
@@ -653,7 +654,7 @@ struct SplitArgs {
   unsigned int* nactive;
 };
 
-template <bool GRAD, int GDC>
+template <bool GRAD, int GDC, bool TRIG>
 __global__ void __launch_bounds__(512, (GRAD && GDC > 8) ? 2 : 4) multi_colpass_kernel(const SplitArgs sa) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NW = 8, NT = NW * 64;
@@ -678,7 +679,7 @@ __global__ void __launch_bounds__(512, (GRAD && GDC > 8) ? 2 : 4) multi_colpass_
   int64_t b = b0 + (int64_t)y * sa.chunk, e = b + sa.chunk;
   b = b < e0 ? b : e0;
   e = e < e0 ? e : e0;
-  const double tot = multi_pass<false, NW, GRAD, GDC>(a, b, e, own, wbase, Gt, red, lseg, dseg);
+  const double tot = multi_pass<false, NW, GRAD, GDC, TRIG>(a, b, e, own, wbase, Gt, red, lseg, dseg);
   if (tid == 0) sa.part_loss[s * sa.nsplit + y] = tot;
   if constexpr (GRAD) {
     double* pg = sa.part_G + ((size_t)s * sa.nsplit + y) * a.dmax * kp;
