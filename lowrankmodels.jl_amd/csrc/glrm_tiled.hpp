@@ -291,8 +291,9 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
           }
           J += L; // every observation is accumulated by G/2 lanes; the caller rescales the group sum by 2/G (exact)
           if (GRAD) {
-            const double dLo = dpp_f64<DPP_XOR1>(dL);
-            const double d0 = odd ? dLo : dL, d1 = odd ? dL : dLo; // list order: u0 first, then u0+1
+            // list order: u0 first, then u0+1.  Even lanes hold the derivative of u0, odd lanes that of u0+1: two quad
+            // broadcasts ([0,0,2,2] / [1,1,3,3]) instead of an exchange plus two selects
+            const double d0 = group_bcast_f64<2>(dL, 0, lane), d1 = group_bcast_f64<2>(dL, 1, lane);
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) {
               g.v[i].x = fma(d0, y0[i].x, g.v[i].x);
