@@ -105,3 +105,72 @@ def test_poisson_script_hip_equals_oracle():
     assert len(g1) == len(c1) and cases.rel_err(g1, c1) < 1e-5
     assert len(g2) == len(c2) and np.isfinite(g2[0]) == np.isfinite(c2[0]) and cases.rel_err(g2[1:], c2[1:]) < 1e-5
     assert abs(eg - ec) <= 1e-5 * max(1.0, abs(ec))
+
+
+# ---------------------------------------------------------------- test/prob_tests/BvSLoss.jl
+
+def bvs_script_data(rng, m=60, n=40, k=3, nlevels=5):
+    """test/prob_tests/BvSLoss.jl:9-45: ordinal data sampled from the bigger-vs-smaller model of a rank-k precursor with sorted
+    per-column thresholds."""
+    d = nlevels - 1
+    X_real, Y_real = rng.standard_normal((m, k)), rng.standard_normal((k, n))
+    T_real = np.sort(k * rng.standard_normal((d, n)), axis=0)
+    signedsums = np.array([[1.0 if i < j else -1.0 for j in range(nlevels)] for i in range(d)])
+    XY = X_real @ Y_real
+    A = np.zeros((m, n))
+    for i in range(m):
+        for j in range(n):
+            u = XY[i, j] + T_real[:, j]
+            w = np.exp(-(u @ signedsums))
+            A[i, j] = 1 + np.searchsorted(np.cumsum(w / w.sum()), rng.random())
+    return np.clip(A, 1, nlevels)
+
+
+def bvs_script(engine, max_iter=40, X_perturb=0.0):
+    """BvSLoss.jl:47-82: fit, impute, init_svd!, fit again, impute, then mul!(glrm.ry, 3) and a last fit.  Returns the three
+    objective histories and the two misclassification rates."""
+    rng = np.random.default_rng(1)
+    m, n, k, nlevels = 60, 40, 3, 5
+    kfit, d = k + 1, nlevels - 1
+    A = bvs_script_data(rng, m, n, k, nlevels)
+    X0, Y0 = rng.standard_normal((kfit, m)), rng.standard_normal((kfit, n * d))
+    if X_perturb:
+        X0 = X0 * (1 + X_perturb * np.random.default_rng(2).standard_normal(X0.shape))
+    g = L.GLRM(A, L.BvSLoss(nlevels), L.lastentry1(L.QuadReg(.01)), L.OrdinalReg(L.QuadReg(.01)), kfit, scale=False, offset=False, X=X0, Y=Y0)
+    p = L.ProxGradParams(max_iter=max_iter)
+    _, _, ch1 = L.fit_b(g, p, verbose=False, engine=engine)
+    wrong1 = float(np.mean(L.impute(g, engine=engine) != A))
+    L.init_svd_(g, engine=engine)
+    _, _, ch2 = L.fit_b(g, p, verbose=False, engine=engine)
+    wrong2 = float(np.mean(L.impute(g, engine=engine) != A))
+    for r in g.ry:  # mul!(glrm.ry, 3), BvSLoss.jl:84
+        r.mul_(3)
+    _, _, ch3 = L.fit_b(g, p, verbose=False, engine=engine)
+    out = np.array(ch1.objective), np.array(ch2.objective), np.array(ch3.objective), wrong1, wrong2
+    g.close()
+    return out
+
+
+def test_bvs_script_on_the_oracle():
+    O.set_threads(4)
+    o1, o2, o3, wrong1, wrong2 = bvs_script(O.oracle_api())
+    for o in (o1, o2, o3):
+        assert np.all(np.isfinite(o[1:])) and o[-1] <= o[1]
+    assert wrong1 < 0.8 and wrong2 < 0.8  # "(Picking randomly, 80 % of entries would be wrong.)"
+
+
+@pytest.mark.gpu
+def test_bvs_script_hip_equals_oracle():
+    from lowrankmodels.jl_amd import _capi
+    O.set_threads(4)
+    c = bvs_script(O.oracle_api(), max_iter=15)
+    g = bvs_script(_capi.hip_api(), max_iter=15)
+    pert = bvs_script(O.oracle_api(), max_iter=15, X_perturb=1e-13)
+    # first fit: compared on the prefix where the oracle itself is stable under a 1e-13 perturbation of the start
+    # (the initial objective is Inf: OrdinalReg at a random Y, so the comparison starts at iteration 1)
+    unstable = np.flatnonzero(np.abs(pert[0][1:] - c[0][1:]) > 1e-9 * np.abs(c[0][1:]))
+    T = 1 + (int(unstable[0]) if len(unstable) else len(c[0]) - 1)
+    assert T >= 4 and len(g[0]) == len(c[0]) and cases.rel_err(g[0][1:T], c[0][1:T]) < 1e-5
+    # later stages start from that fit's result: same quality, not the same digits
+    assert abs(g[3] - c[3]) <= 0.05 and abs(g[4] - c[4]) <= 0.05 and g[4] < 0.8
+    assert abs(g[1][-1] - c[1][-1]) <= 0.05 * abs(c[1][-1]) and abs(g[2][-1] - c[2][-1]) <= 0.05 * abs(c[2][-1])
