@@ -1,28 +1,76 @@
 #!/usr/bin/env python
 """bench.py -- observed-entry updates/sec of the GLRM proximal-gradient hot path on MI355X.
 
-A "step" is one outer iteration of fit!(glrm, ProxGradParams) (X half-step over every observed entry of the
-rank's rows, Y half-step over every observed entry of its columns, objective) on BASELINE.json configs[1]:
-1M x 10k, rank 32, QuadLoss, 5 % observed (5e8 observations), QuadReg on X and Y, fp64 -- generated in HBM by
-the counter-based generator (synthetic).  N > 1: one process per GPU (torch.distributed, nccl = RCCL), weak
-scaling in m (each rank owns 1M rows and n/N columns; X and Y replicated; all-gather of the updated factor
-after each half-step).  One observed-entry update = one (i,j) consumed by one factor half-step, so an outer
-iteration performs |Omega_rows| + |Omega_cols| updates.
+A "step" is one outer iteration of fit!(glrm, ProxGradParams) (src/algorithms/proxgrad.jl:107-217): the X half-step over
+every observed entry of the rank's rows, the Y half-step over every observed entry of its columns, the recorded objective.
+One observed-entry update = one (i,j) consumed by one factor half-step, so an outer iteration performs
+|Omega_rows| + |Omega_cols| updates.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+Default workload = the configuration BASELINE.json's north star is quoted on (configs[3], "C4"): 10M x 100k, rank 64, QuadLoss,
+1e9 observed entries, NonNegConstraint on X and Y, fp64, generated in HBM by the counter-based generator.  It fits one MI355X
+(24 GB of index lists + 5.2 GB of factors).  --gpus N shards THAT problem (strong scaling: m/N rows and n/N columns per rank,
+X and Y replicated, one all-gather of the updated factor after each half-step; --scaling weak keeps --rows rows per rank).
+Other configs: --config C2 | C3 | C5.
+
+    python bench.py                                  # C4 on one GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+The JSON line carries
+  roofline      the bound of the dominant kernel (the longest half-step): every candidate limiter of that kernel family is
+                priced and the largest fraction is `frac`
+  cpu_baseline  the CPU oracle (oracle/, test infrastructure) on the host cores, on a bounded sample of the same recipe
+  to_ref_objective   iterations / seconds until the GPU's recorded objective is <= J_ref (1 + 1e-5), where J_ref is what the CPU
+                oracle reaches with default ProxGradParams() and its own stop rule on a scaled-down problem of the same recipe
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import re
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+# MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling); L2 ~34.5 TB/s aggregate; LDS ~150 TB/s aggregate for
+# ds_read_b64/b128; Infinity Cache 256 MiB.  fp64 matrix peak: 78.6 TFLOP/s (datasheet; the guide's table has no fp64 row).
+HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0
+LDS_PEAK_GBS = 150000.0
+MFMA_F64_PEAK_TFLOPS = 78.6
+MALL_BYTES = 256 * 2 ** 20
+
+CONFIGS = {
+    # name: rows, cols, rank, observations per row, value model, loss mix, regularizer descriptor (kind, wrap, scale)
+    # jref: the scaled-down problem of the same recipe on which the CPU oracle runs to its own stop (to_ref_objective)
+    "C2": dict(rows=1_000_000, cols=10_000, k=32, q=500, value_model=0, loss_mix=0, reg=(1, 0, 1.0), jref=(40_000, 2_000, 100),
+               text="BASELINE configs[1] (C2): {m} x {n}, rank {k}, QuadLoss, 5% observed, QuadReg(1.0) on X and Y"),
+    "C3": dict(rows=1_000_000, cols=10_000, k=32, q=10_000, value_model=0, loss_mix=0, reg=(0, 0, 1.0), jref=None,
+               text="BASELINE configs[2] (C3): {m} x {n}, rank {k}, QuadLoss, fully observed (dense hand-over, fp64 MFMA path), ZeroReg"),
+    "C4": dict(rows=10_000_000, cols=100_000, k=64, q=100, value_model=1, loss_mix=0, reg=(3, 0, 1.0), jref=(40_000, 4_000, 100),
+               text="BASELINE configs[3] (C4, the north-star target): {m} x {n}, rank {k}, QuadLoss, 0.1% observed, "
+                    "NonNegConstraint on X and Y (NNMF)"),
+    "C5": dict(rows=5_000_000, cols=50_000, k=32, q=1000, value_model=0, loss_mix=1, reg=(1, 0, 1.0), jref=(20_000, 6_000, 200),
+               text="BASELINE configs[4] (C5): {m} x {n}, rank {k}, Quad/Logistic/OrdinalHinge columns (f mod 3), 2% observed, QuadReg(1.0)"),
+}
+REG_NAME = {0: "ZeroReg", 1: "QuadReg(1.0)", 3: "NonNegConstraint"}
+# Starting point.  SURVEY.md 8(d) asked for the reference default X0, Y0 ~ N(0,1) (src/glrm.jl:31) everywhere.  Under NonNegConstraint that
+# start has objective Inf, the first trial of every row is accepted whatever its size, and at the C4 shape (100 observations per row,
+# rank 64) the fit -- reference, oracle and engine alike -- collapses to X = 0 within two iterations and stays there (objective =
+# sum of a^2): every later line search rejects its single trial.  The NNMF configs therefore start from |N(0,1)| / sqrt(k) (same
+# streams, non-negative, x.y of the size of the data), on which the fit keeps descending for 100+ iterations.
+INIT_NOTE = {True: "X0, Y0 = |N(0,1)| / sqrt(k) (the N(0,1) default collapses an NNMF of this shape to X = 0 in two iterations)",
+             False: "X0, Y0 ~ N(0,1) (reference default, src/glrm.jl:31)"}
+
+
+def nonneg_start(cfg):
+    return cfg["reg"][0] == 3
 
 
 def algorithmic_bytes_per_update(k):
@@ -30,61 +78,207 @@ def algorithmic_bytes_per_update(k):
     return 2 * (8 + 4 + 8 * k)
 
 
-def cpu_baseline(args, k, q, n):
-    """The oracle (CPU restatement of the reference, oracle/) timed on the host cores on a bounded sample of the
-    same workload: the first `sample_rows` rows x all n columns of the same generator."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+# ----------------------------------------------------------------------------- rooflines
+
+def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, segs_per_wg=256):
+    """Candidate limiters of ONE half-step (all its launches) of the given kernel family, each as achieved/peak.
+
+    family   'gather'  every update fetches the opposing k-vector from memory (csrc/glrm_hip.hip sweep_kernel)
+             'tiled'   the opposing factor is staged tile by tile in LDS (csrc/glrm_tiled.hpp)
+             'dense'   fully observed QuadLoss on the fp64 matrix cores (csrc/glrm_dense.hpp)
+             'general' multi-dimensional losses (csrc/glrm_multi.hpp)
+    nnz updates per launch, nseg own segments, nopp opposing vectors, ld padded rank, ms duration of the half-step.
+    P = 2 passes over the segment per half-step (gradient + first trial) is the compulsory minimum."""
+    t = ms * 1e-3
+    if t <= 0:
+        return None
+    P = 2
+    alg = nnz * P * (12 + 8 * k)                 # SURVEY 8(d): every update fetches its own k-vector
+    stream = nnz * P * 12 + 2 * nseg * ld * 8   # what no design can avoid: the (index, value) stream per pass + own factor r/w
+    opp = nopp * ld * 8
+    cands = []
+    if family == "dense":
+        flops = 6.0 * m * n * k                  # three m x n x k products per half-step (u, gradient, first trial): 12mnk per iteration
+        cands.append(dict(bound="mfma", achieved=flops / t / 1e12, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", per_launch=flops,
+                          what="6 m n k flop per half-step (SURVEY 8(d): 12 m n k per outer iteration)"))
+        cands.append(dict(bound="hbm", achieved=P * m * n * 8 / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=P * m * n * 8,
+                          what="A streamed once per pass, 2 passes"))
+    elif family == "tiled":
+        nwg = max(1, -(-nseg // segs_per_wg))
+        staged = nwg * P * opp                   # every workgroup stages the whole opposing factor once per pass
+        cands.append(dict(bound="hbm", achieved=(stream + opp) / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=stream + opp,
+                          what="compulsory HBM bytes: P x 12 B x |Omega| + own factor r/w + opposing factor once (tiles are re-read from L2)"))
+        cands.append(dict(bound="l2", achieved=staged / t / 1e9, peak=L2_PEAK_GBS, unit="GB/s", per_launch=staged,
+                          what="tile staging: workgroups x P x opposing factor bytes (L2 -> LDS)"))
+        cands.append(dict(bound="lds", achieved=nnz * P * 8 * ld / t / 1e9, peak=LDS_PEAK_GBS, unit="GB/s", per_launch=nnz * P * 8 * ld,
+                          what="LDS reads: one opposing vector (8 ld bytes) per update and pass"))
+    else:
+        if opp > MALL_BYTES or family == "general":  # the opposing factor cannot stay on chip: the gathers are HBM traffic
+            cands.append(dict(bound="hbm", achieved=alg / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=alg,
+                              what="SURVEY 8(d) algorithmic bytes: P x (12 + 8k) per update (random k-vector gathers from HBM)"))
+        else:  # the opposing factor fits the Infinity Cache / L2: HBM sees the streams, the gathers are cache traffic
+            cands.append(dict(bound="hbm", achieved=(stream + opp) / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=stream + opp,
+                              what="compulsory HBM bytes: P x 12 B x |Omega| + own factor r/w + opposing factor once"))
+            cands.append(dict(bound="l2", achieved=nnz * P * 8 * k / t / 1e9, peak=L2_PEAK_GBS, unit="GB/s", per_launch=nnz * P * 8 * k,
+                              what="k-vector gathers served by L2 / Infinity Cache (opposing factor %.0f MB <= 256 MiB); priced at the "
+                                   "L2 peak, the Infinity-Cache path behind it is slower" % (opp / 1e6)))
+    for c in cands:
+        c["frac"] = c["achieved"] / c["peak"]
+    best = max(cands, key=lambda c: c["frac"])
+    return dict(best=best, candidates=cands, algorithmic_GBps=alg / t / 1e9)
+
+
+# ----------------------------------------------------------------------------- CPU legs (rank 0, N = 1 only)
+
+def _oracle_problem(ms, n, k, q, cfg, seed):
     import numpy as np
     import oracle as O
-    from lowrankmodels.jl_amd import _capi
+    from lowrankmodels.jl_amd import _capi, synth
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(ms, n, k, q, seed=seed, value_model=cfg["value_model"],
+                                                                            loss_mix=cfg["loss_mix"])
+    if nonneg_start(cfg):
+        X0, Y0 = np.asfortranarray(np.abs(X0) * (1.0 / k ** 0.5)), np.asfortranarray(np.abs(Y0) * (1.0 / k ** 0.5))
+    reg = np.array([cfg["reg"]], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(ms, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, synth.loss_table(n, cfg["loss_mix"]), reg, reg)
+    return pa, X0, Y0
+
+
+def cpu_baseline(args, cfg, k, q, n):
+    """The oracle (CPU restatement of the reference, oracle/) timed on the host cores on a bounded sample of the same recipe: the
+    first `ms` rows x all n columns of the same generator (columns are therefore ms/m as long as in the full problem)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
     cores = O.usable_cores()  # affinity mask and cgroup CPU quota, not the hardware thread count of the host
-    # enough rows for every thread to have work: 10 000 rows per thread, at least --cpu-sample-rows, at most 400k rows
-    # (2e8 observations, ~5 GB)
-    ms = int(min(max(args.cpu_sample_rows, 10_000 * cores), 400_000, args.rows_per_gpu))
+    target_obs = (2.5e6 if k <= 32 else 1.2e6) * cores  # ~10-20 s of CPU work at the oracle's rate
+    ms = int(min(max(args.cpu_sample_rows, target_obs / q), args.rows))
+    ms = max(ms - ms % 8, 8)
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(ms, n, k, q, seed=args.seed)
-    one = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
-    reg = np.array([(1, 0, 1.0)], dtype=_capi.REG_DTYPE)
-    pa = _capi.ProblemArrays(ms, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, one, reg, reg)
+    pa, X0, Y0 = _oracle_problem(ms, n, k, q, cfg, args.seed)
     api = O.oracle_api()
     O.set_threads(cores)
     h = api.create(pa)
     api.set_factors(h, X0, Y0)
     api.reset_stepsizes(h, 1.0)
-    iters = 0
-    api.step_x(h, 0.01); api.step_y(h, 0.01)  # warm-up iteration
-    t0 = time.time()
+    for _ in range(2):  # warm-up iterations: past the first line searches from the random start, like the GPU's warm-up
+        api.step_x(h, 0.01); api.step_y(h, 0.01)
+    iters, t0 = 0, time.time()
     while iters < 3 or (time.time() - t0 < 10.0 and iters < 500):
         api.step_x(h, 0.01)
         api.step_y(h, 0.01)
         iters += 1
     dt = time.time() - t0
     api.destroy(h)
-    ups = iters * (int(rowptr[-1]) + int(colptr[-1])) / dt
-    return {"value": ups, "unit": "observed-entry updates/s", "cores": cores, "kind": "port",
-            "sample": f"first {ms} rows x all {n} columns of the same generator ({int(rowptr[-1])} observations), "
-                      f"{iters} outer iterations after 1 warm-up, OpenMP over rows then columns"}
+    nobs = int(pa.rowptr[-1]) + int(pa.colptr[-1])
+    return {"value": iters * nobs / dt, "unit": "observed-entry updates/s", "cores": cores, "kind": "port",
+            "sample": f"first {ms} rows x all {n} columns of the same generator and recipe ({int(pa.rowptr[-1])} observations, "
+                      f"rank {k}), {iters} outer iterations after 2 warm-up, OpenMP over rows then columns; "
+                      "the reference itself is Julia and cannot run here (no oracle/_ref)"}
 
+
+def jref_leg(args, cfg, api, device):
+    """SURVEY.md 8(d), second leg of the metric.  On a scaled-down problem of the same recipe (same generator, rank, density, losses,
+    regularizers) the CPU oracle runs default ProxGradParams() to its own stop (src/algorithms/proxgrad.jl:210-213): J_ref =
+    ch.objective[end].  The HIP engine then runs the same problem from the same X0, Y0 with the stop rule off and reports the first
+    iteration whose recorded objective is <= J_ref (1 + 1e-5), and the wall-clock to it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle as O
+    from lowrankmodels.jl_amd.params import ProxGradParams
+    k = cfg["k"]
+    ms, n, q = cfg["jref"]
+    pa, X0, Y0 = _oracle_problem(ms, n, k, q, cfg, args.seed)
+    cores = O.usable_cores()
+    O.set_threads(cores)
+    oapi = O.oracle_api()
+    prm = ProxGradParams()
+    Xc, Yc = X0.copy(order="F"), Y0.copy(order="F")
+    h = oapi.create(pa)
+    t0 = time.time()
+    obj_cpu, _ = oapi.fit(h, prm, Xc, Yc)
+    t_cpu = time.time() - t0
+    oapi.destroy(h)
+    j_ref = float(obj_cpu[-1])
+    Xg, Yg = X0.copy(order="F"), Y0.copy(order="F")
+    h = api.create(pa, device_id=device.index or 0)
+    prm_gpu = ProxGradParams(max_iter=max(len(obj_cpu) + 20, 30), abs_tol=-1e300, rel_tol=-1e300)  # stop rule off (no decrease is ever below these)
+    t0 = time.time()
+    obj_gpu, sec_gpu = api.fit(h, prm_gpu, Xg, Yg)
+    t_gpu = time.time() - t0
+    api.destroy(h)
+    hit = np.flatnonzero(obj_gpu <= j_ref * (1 + 1e-5))
+    it = int(hit[0]) if len(hit) else None
+    return {"problem": f"{ms} x {n}, rank {k}, {q} observations per row ({int(pa.rowptr[-1])} observed), same generator / losses / regularizers",
+            "J_ref": j_ref, "cpu_iterations_to_own_stop": len(obj_cpu) - 1, "cpu_seconds": t_cpu, "cpu_cores": cores,
+            "gpu_first_iteration_at_or_below_J_ref": it, "gpu_seconds_to_J_ref": float(sec_gpu[it]) if it is not None else None,
+            "gpu_objective_there": float(obj_gpu[it]) if it is not None else None, "gpu_fit_wall_s_incl_transfers": t_gpu,
+            "rule": "first GPU iteration with objective <= J_ref (1 + 1e-5); J_ref = oracle, default ProxGradParams(), own stop rule"}
+
+
+# ----------------------------------------------------------------------------- PMC traffic (rank 0, N = 1 only)
+
+def pmc_traffic(args, kernel_re):
+    """HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
+    WRITE_SIZE in SEPARATE passes (TCC slots), FETCH_SIZE doubled on gfx950 (128-B requests tallied at 64 B); both counters are in KiB.
+    Each pass re-runs this script as a child (same config, 2 timed steps) under `rocprofv3 --pmc <counter>`; the mean over the
+    dispatches of the kernel in that child is used.  Returns (bytes per launch or None, note)."""
+    rp = shutil.which("rocprofv3")
+    if rp is None:
+        return None, "rocprofv3 not found"
+    out = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="glrm_pmc_", dir="/tmp")
+        cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+               "--config", args.config, "--rows", str(args.rows), "--steps", "2", "--warmup", str(max(args.warmup, 1)), "--tiled", str(args.tiled),
+               "--no-cpu-baseline", "--no-convergence-run", "--no-jref", "--pmc", "off", "--seed", str(args.seed),
+               "--cols", str(args.cols), "--obs-per-row", str(args.obs_per_row), "--rank", str(args.k)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
+            try:
+                p.communicate(timeout=args.pmc_timeout)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, 9)
+                p.communicate()
+                return None, f"PMC pass {ctr} timed out after {args.pmc_timeout} s"
+            vals = []
+            for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(path)):
+                    if r.get("Counter_Name") == ctr and re.search(kernel_re, r.get("Kernel_Name", "")):
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None, f"PMC pass {ctr}: no dispatch matching /{kernel_re}/ in the counter CSV (exit {p.returncode})"
+            out[ctr] = (sum(vals) / len(vals), len(vals))
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    fetch, write = out["FETCH_SIZE"][0] * 1024.0 * 2.0, out["WRITE_SIZE"][0] * 1024.0
+    return fetch + write, (f"in-run rocprofv3 --pmc passes of this config: 2 x FETCH_SIZE ({out['FETCH_SIZE'][0]:.4g} KiB, gfx950 correction) + "
+                           f"WRITE_SIZE ({out['WRITE_SIZE'][0]:.4g} KiB), mean over {out['FETCH_SIZE'][1]} dispatches matching /{kernel_re}/")
+
+
+# ----------------------------------------------------------------------------- main
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows-per-gpu", type=int, default=1_000_000)
-    ap.add_argument("--cols", type=int, default=10_000)
-    ap.add_argument("--rank", dest="k", type=int, default=32)
-    ap.add_argument("--obs-per-row", type=int, default=500)
+    ap.add_argument("--config", default="C4", choices=sorted(CONFIGS))
+    ap.add_argument("--rows", type=int, default=0, help="rows of the whole problem (strong scaling) or per rank (--scaling weak); 0 = the config's")
+    ap.add_argument("--rows-per-gpu", type=int, default=0, help="alias: rows per rank with --scaling weak")
+    ap.add_argument("--cols", type=int, default=0, help="override the config's column count (scaled-down runs and tests)")
+    ap.add_argument("--obs-per-row", type=int, default=0, help="override the config's observations per row")
+    ap.add_argument("--rank", dest="k", type=int, default=0, help="override the config's rank")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--seed", type=int, default=20260926)
     ap.add_argument("--waves-row", type=int, default=0)
     ap.add_argument("--waves-col", type=int, default=0)
     ap.add_argument("--tiled", type=int, default=0, help="0 auto, 1 gather sweeps only, 2 LDS-tiled sweeps")
     ap.add_argument("--x-chunks", type=int, default=4, help="N > 1: row chunks of the X half-step whose all-gather overlaps the next chunk")
-    ap.add_argument("--config", default="C2", choices=["C2", "C3", "C4", "C5"],
-                    help="BASELINE.json config family: C2 (default, the bench line), C4 = rank-64 NNMF 0.1 %% observed, "
-                         "C5 = mixed Quad/Logistic/OrdinalHinge columns 2 %% observed (use --rows-per-gpu to scale)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
+    ap.add_argument("--no-jref", action="store_true")
+    ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"], help="HBM traffic of the dominant kernel from rocprofv3 PMC child passes")
+    ap.add_argument("--pmc-timeout", type=int, default=240)
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000)
     args = ap.parse_args()
 
@@ -110,20 +304,21 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    value_model, loss_mix, reg = 0, 0, (1, 0, 1.0)  # QuadReg(1.0)
-    if args.config == "C4":    # 10M x 100k rank 64, 1e9 observations, NonNegConstraint on X and Y
-        args.cols, args.k, args.obs_per_row, value_model, reg = 100_000, 64, 100, 1, (3, 0, 1.0)
-    elif args.config == "C3":  # 1M x 10k rank 32, fully observed QuadLoss, ZeroReg: the dense MFMA path (single GPU)
-        args.obs_per_row, reg = args.cols, (0, 0, 1.0)
-        if world != 1:
-            raise SystemExit("--config C3 runs on one GPU (the dense hand-over takes the whole matrix)")
-    elif args.config == "C5":  # 5M x 50k rank 32, 2 % observed, Quad/Logistic/OrdinalHinge columns, QuadReg
-        args.cols, args.k, args.obs_per_row, loss_mix = 50_000 - 50_000 % (1000 * 1), 32, 1000, 1
-    k, q, n = args.k, args.obs_per_row, args.cols
-    m = args.rows_per_gpu * world  # weak scaling in m
-    if n % world or n % q:
-        raise SystemExit("cols must be divisible by the number of GPUs and by obs-per-row")
-    rbs = [args.rows_per_gpu * r for r in range(world + 1)]
+    cfg = dict(CONFIGS[args.config])
+    if args.cols or args.obs_per_row or args.k:
+        cfg.update(cols=args.cols or cfg["cols"], q=args.obs_per_row or cfg["q"], k=args.k or cfg["k"])
+        cfg["text"] = "scaled-down " + cfg["text"].replace("5% observed", "{pct:.3g}% observed").replace("0.1% observed", "{pct:.3g}% observed").replace("2% observed", "{pct:.3g}% observed")
+    k, q, n, reg = cfg["k"], cfg["q"], cfg["cols"], cfg["reg"]
+    if args.rows_per_gpu:
+        args.rows, args.scaling = args.rows_per_gpu, "weak"
+    if not args.rows:
+        args.rows = cfg["rows"]
+    m = args.rows * world if args.scaling == "weak" else args.rows
+    if args.config == "C3" and world != 1:
+        raise SystemExit("--config C3 runs on one GPU (the dense hand-over takes the whole matrix)")
+    if n % world or n % q or m % world:
+        raise SystemExit("rows and cols must be divisible by the number of GPUs, cols by the observations per row")
+    rbs = [m // world * r for r in range(world + 1)]
     cbs = [n // world * r for r in range(world + 1)]
 
     api = _capi.hip_api()
@@ -132,7 +327,7 @@ def main():
         w = synth.DenseDeviceWorkload(m, n, k, seed=args.seed, rx=reg, ry=reg, device=device)
     else:
         w = synth.DeviceWorkload(m, n, k, q, rows=(rbs[rank], rbs[rank + 1]), cols=(cbs[rank], cbs[rank + 1]), seed=args.seed,
-                                 value_model=value_model, loss_mix=loss_mix, rx=reg, ry=reg, device=device)
+                                 value_model=cfg["value_model"], loss_mix=cfg["loss_mix"], rx=reg, ry=reg, device=device)
     t_gen = time.time() - t_gen
     t_create = time.time()
     sf = ShardedFit(api, w.problem(), rbs, cbs, device=device, stream=torch.cuda.current_stream().cuda_stream,
@@ -141,10 +336,15 @@ def main():
     nnz_r, nnz_c = w.nnz_rows, w.nnz_cols
     w.free_sources()
     t_create = time.time() - t_create
-    X0, Y0 = w.init_factors(sf.ld)
-    sf.dX.copy_(X0); sf.dY.copy_(Y0)
-    del X0, Y0
-    api.reset_stepsizes(sf.h, 1.0)
+    def load_start():
+        X0, Y0 = w.init_factors(sf.ld)
+        if nonneg_start(cfg):
+            X0.abs_().mul_(1.0 / k ** 0.5); Y0.abs_().mul_(1.0 / k ** 0.5)
+        sf.dX.copy_(X0); sf.dY.copy_(Y0)
+        del X0, Y0
+        api.reset_stepsizes(sf.h, 1.0)
+
+    load_start()
 
     class P:  # reference defaults, stop rule disabled (fixed number of outer iterations)
         stepsize, inner_iter_X, inner_iter_Y, min_stepsize = 1.0, 1, 1, 0.01
@@ -177,15 +377,11 @@ def main():
         tot_r, tot_c = nnz_r, nnz_c
     st = api.kernel_stats(sf.h)
 
-    # Second leg of the metric (iters-to-ref-objective): the reference's own run -- default ProxGradParams(), stop rule
-    # of src/algorithms/proxgrad.jl:210-213, from the same X0, Y0 -- timed end to end.  Parity makes the iteration count
-    # the reference's iteration count; the objective reached is what the reference would record.
+    # The reference's own run at full size -- default ProxGradParams(), stop rule of src/algorithms/proxgrad.jl:210-213, from the same
+    # X0, Y0 -- timed end to end on the GPU (the CPU-derived J_ref leg is `to_ref_objective`).
     conv = None
     if not args.no_convergence_run:
-        X0, Y0 = w.init_factors(sf.ld)
-        sf.dX.copy_(X0); sf.dY.copy_(Y0)
-        del X0, Y0
-        api.reset_stepsizes(sf.h, 1.0)
+        load_start()
         fence()
         tc = time.perf_counter()
         hist = [sf.initial_objective()]
@@ -200,64 +396,86 @@ def main():
         conv = {"iterations": len(hist) - 1, "seconds": time.perf_counter() - tc, "objective_initial": hist[0],
                 "objective_final": hist[-1], "stop_rule": "reference defaults: abs_tol=1e-5*|Omega|, rel_tol=1e-4, max_iter=100"}
 
+    nseg_r, nseg_c = rbs[1] - rbs[0], cbs[1] - cbs[0]
+    flags = st["tiled"]
+    sf.close()
+    del sf
+    torch.cuda.empty_cache()
+
     if rank == 0:
         updates_per_step = tot_r + tot_c
         value = args.steps * updates_per_step / elapsed
-        bpu = algorithmic_bytes_per_update(k)
         ms_x = st["ms_x"] / max(args.steps, 1)  # per outer iteration (the X half-step may run as several chunk launches)
         ms_y = st["ms_y"] / max(args.steps, 1)
-        tiled_row, tiled_col = bool(st["tiled"] & 1), bool(st["tiled"] & 2)
-        # dominant kernel = the longest single kernel.  The gather column sweep and both row sweeps are one kernel per
-        # half-step; the LDS-tiled column sweep is four launches (pass, reduce, trial pass, decide) of which the two
-        # passes are about half the half-step each, so there the row sweep kernel is the longest.
-        dom = "row_sweep" if (ms_x >= ms_y or tiled_col) else "col_sweep"
-        dom_ms, dom_nnz = (ms_y, nnz_c) if dom == "col_sweep" else (ms_x, nnz_r)
-        dom_tiled = tiled_col if dom == "col_sweep" else tiled_row
-        dom_name = {("row_sweep", True): "tiled_sweep_kernel (X half-step, LDS-tiled)", ("row_sweep", False): "sweep_kernel<WAVES=1> (X half-step, gather)",
-                    ("col_sweep", False): "sweep_kernel<WAVES=4> (Y half-step, gather)", ("col_sweep", True): "tiled_col_pass_kernel x2 + reduce/decide (Y half-step)"}[(dom, dom_tiled)]
-        achieved = dom_nnz * bpu / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
+        fam_r = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 1 else "gather"
+        fam_c = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 2 else "gather"
+        ld = st["ld"]
+        tile = 150 * 1024 // (ld * 8 + 16)
+        rl_r = kernel_roofline(fam_r, nnz=nnz_r, nseg=nseg_r, nopp=n, k=k, ld=ld, ms=ms_x, m=nseg_r, n=n, tile=tile)
+        rl_c = kernel_roofline(fam_c, nnz=nnz_c, nseg=nseg_c, nopp=m, k=k, ld=ld, ms=ms_y, m=m, n=nseg_c, tile=tile)
+        # dominant kernel = the longer half-step
+        dom = "row" if ms_x >= ms_y else "col"
+        rl, dom_ms, dom_nnz, dom_fam = (rl_r, ms_x, nnz_r, fam_r) if dom == "row" else (rl_c, ms_y, nnz_c, fam_c)
+        kname = {("row", "gather"): ("sweep_kernel (X half-step, k-vector gather)", "sweep_kernel"),
+                 ("col", "gather"): ("sweep_kernel (Y half-step, k-vector gather)", "sweep_kernel"),
+                 ("row", "tiled"): ("tiled_sweep_kernel (X half-step, LDS-tiled)", "tiled_sweep_kernel"),
+                 ("col", "tiled"): ("tiled_col_pass_kernel x2 + col_reduce/col_decide (Y half-step, LDS-tiled)", "tiled_col_pass_kernel"),
+                 ("row", "dense"): ("dense_pass_kernel (X half-step, fp64 MFMA)", "dense_pass_kernel"),
+                 ("col", "dense"): ("dense_pass_kernel (Y half-step, fp64 MFMA)", "dense_pass_kernel"),
+                 ("row", "general"): ("multi_sweep_kernel (X half-step)", "multi_sweep_kernel"),
+                 ("col", "general"): ("multi_colpass_kernel (Y half-step)", "multi_colpass_kernel")}[(dom, dom_fam)]
+        traffic, traffic_src = None, "not collected"
+        if world == 1 and args.pmc != "off":
             try:
-                traffic = json.load(open(tpath)).get(f"{dom}_k{k}_{'tiled' if dom_tiled else 'gather'}_bytes_per_launch")
-            except Exception:
-                traffic = None
-        nseg_r, nseg_c = rbs[1] - rbs[0], cbs[1] - cbs[0]
+                kre = kname[1]
+                if dom_fam == "gather":  # row and column sweeps are instantiations of one template: tell them apart by WAVES
+                    wv = st["waves_row"] if dom == "row" else st["waves_col"]
+                    kre = r"(?<!tiled_)sweep_kernel<\d+, \d+, %d, \d+, \d+, false>" % wv
+                traffic, traffic_src = pmc_traffic(args, kre)
+                if traffic is not None and dom_fam == "gather" and st["waves_row"] == st["waves_col"]:
+                    traffic_src += " (row and column sweeps run the same instantiation here: the mean is over both)"
+            except Exception as e:  # the bench line must survive a profiler problem
+                traffic, traffic_src = None, f"PMC pass failed: {e!r}"
+        best = rl["best"] if rl else None
+        roof = None
+        if best:
+            roof = {"bound": best["bound"], "kernel": kname[0], "achieved": best["achieved"], "peak": best["peak"], "unit": best["unit"],
+                    "frac": best["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                    "per_launch": best["per_launch"], "per_launch_is": best["what"], "updates_per_launch": dom_nnz,
+                    "avg_launch_ms": dom_ms, "candidates": [{kk: c[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "what")} for c in rl["candidates"]],
+                    "survey_8d_algorithmic_GBps": rl["algorithmic_GBps"],
+                    "traffic_GBps": traffic / (dom_ms * 1e-3) / 1e9 if traffic and dom_ms > 0 else None,
+                    "traffic_frac_of_hbm_peak": traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and dom_ms > 0 else None,
+                    "note": "frac = the largest achieved/peak among the limiters that apply to this kernel family (candidates); "
+                            "durations are HIP events on the launch stream around every sweep of the timed region"}
         out = {
             "metric": "observed-entry updates/sec", "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[1] (C2): {m} x {n}, rank {k}, QuadLoss, {100.0 * q / n:.3g}% observed "
-                                    f"({tot_r} observations), QuadReg(1.0) on X and Y, ProxGradParams defaults, stop rule off")
-                       if args.config == "C2" else f"{args.config}-family: {m} x {n}, rank {k}, {tot_r} observations, "
-                       f"{'NonNegConstraint' if reg[0] == 3 else 'QuadReg(1.0)'} on X and Y, {'mixed Quad/Logistic/OrdinalHinge' if loss_mix else 'QuadLoss'}",
-                       "m": m, "n": n, "k": k, "observed": tot_r, "parallelism": f"rows/cols sharded over {world} GPU(s), X,Y replicated",
-                       "waves_row": st["waves_row"], "waves_col": st["waves_col"],
-                       "row_sweep": "lds-tiled" if tiled_row else "gather", "col_sweep": "lds-tiled" if tiled_col else "gather"},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_update": bpu, "updates_per_launch": dom_nnz, "avg_launch_ms": dom_ms,
-                         "traffic_GBps": traffic / (dom_ms * 1e-3) / 1e9 if traffic and dom_ms > 0 else None,
-                         "traffic_frac": traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and dom_ms > 0 else None,
-                         "note": "algorithmic bytes assume every update fetches its own k-vector (SURVEY.md 8(d)); the LDS-tiled "
-                                 "sweeps fetch a factor vector once per workgroup and tile, so frac > 1 means on-chip reuse, "
-                                 "and `traffic` (PMC) is what actually crossed the fabric "
-                                 "(traffic_frac = that over the measured launch time over the HBM peak; the tiled sweeps are "
-                                 "LDS / VALU co-limited, DESIGN.md 4.2)"},
+            "config": {"workload": cfg["text"].format(m=m, n=n, k=k, pct=100.0 * q / n) + f" ({tot_r} observations), ProxGradParams defaults, stop rule off",
+                       "name": args.config, "m": m, "n": n, "k": k, "observed": tot_r,
+                       "full_size": m == CONFIGS[args.config]["rows"] and n == CONFIGS[args.config]["cols"] and k == CONFIGS[args.config]["k"], "start": INIT_NOTE[nonneg_start(cfg)], "regularizer": REG_NAME.get(reg[0], str(reg)),
+                       "parallelism": f"rows/cols sharded over {world} GPU(s) ({args.scaling} scaling), X,Y replicated",
+                       "waves_row": st["waves_row"], "waves_col": st["waves_col"], "row_sweep": fam_r, "col_sweep": fam_c},
+            "roofline": roof,
             "kernels": {"row_sweep_ms": ms_x, "col_sweep_ms": ms_y,
-                        "row_sweep_GBps_algorithmic": nnz_r * bpu / (ms_x * 1e-3) / 1e9 if ms_x > 0 else None,
-                        "col_sweep_GBps_algorithmic": nnz_c * bpu / (ms_y * 1e-3) / 1e9 if ms_y > 0 else None,
+                        "row_sweep": None if not rl_r else {kk: rl_r["best"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac")},
+                        "col_sweep": None if not rl_c else {kk: rl_c["best"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac")},
                         "mean_trials_per_row": st["trials_x"] / max(args.steps * nseg_r, 1),
                         "mean_trials_per_col": st["trials_y"] / max(args.steps * nseg_c, 1)},
             "objective": {"initial": obj0, "after_warmup_and_steps": objs[-1] if objs else None},
             "to_reference_stop": conv,
             "setup_s": {"generate": t_gen, "create": t_create},
         }
-        if world == 1 and not args.no_cpu_baseline and args.config == "C2":
-            out["cpu_baseline"] = cpu_baseline(args, k, q, n)
+        if world == 1 and not args.no_jref and args.config != "C3":
+            try:
+                out["to_ref_objective"] = jref_leg(args, cfg, api, device)
+            except Exception as e:
+                out["to_ref_objective"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            c3 = args.config == "C3"  # the oracle has no dense hand-over: its list path on the same fully observed recipe
+            out["cpu_baseline"] = cpu_baseline(args, cfg, k, q if not c3 else n, n)
         print(json.dumps(out), flush=True)
-    sf.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

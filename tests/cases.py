@@ -67,6 +67,20 @@ def case_kmeans(rng):
                 X=rng.standard_normal((k, m)), Y=rng.standard_normal((k, n))), L.ProxGradParams(max_iter=15, inner_iter=10)
 
 
+def case_c4(rng):
+    """BASELINE config 4 (the north-star target) at 1/60000 of the size: rank 64, QuadLoss, NonNegConstraint on X and Y
+    (src/regularizers.jl:101-114), every row observes q sorted columns (one per stratum, like the synthetic generator), values from
+    non-negative factors.  Two starts in the suite: this fixture starts from |N(0,1)|/sqrt(k) (the start bench.py uses at C4);
+    the N(0,1) default start of an NNMF of this shape collapses to X = 0 (tests/test_gpu_parity.py::test_c4_recipe covers both)."""
+    m, n, k, q = 150, 80, 64, 10
+    S = n // q
+    A = (rng.random((m, k)) / np.sqrt(k)) @ (rng.random((k, n)) / np.sqrt(k)) + 0.01 * rng.standard_normal((m, n))
+    I = np.repeat(np.arange(m), q)
+    J = (np.arange(q)[None, :] * S + rng.integers(0, S, (m, q))).ravel()
+    return dict(A=A, losses=L.QuadLoss(), rx=L.NonNegConstraint(), ry=L.NonNegConstraint(), k=k, obs=(I, J),
+                X=np.abs(rng.standard_normal((k, m))) / np.sqrt(k), Y=np.abs(rng.standard_normal((k, n))) / np.sqrt(k)), L.ProxGradParams(max_iter=30)
+
+
 def _levels(z, lo, hi):
     return np.clip(np.round((lo + hi) / 2 + z), lo, hi)
 
@@ -190,7 +204,7 @@ def build_multidim_case(name):
     return fn(np.random.default_rng(seed))
 
 
-GOLDEN_CASES = {"c1": (case_c1, 11), "nnmf": (case_nnmf, 12), "mixed": (case_mixed, 13), "kmeans": (case_kmeans, 14),
+GOLDEN_CASES = {"c1": (case_c1, 11), "c4": (case_c4, 15), "nnmf": (case_nnmf, 12), "mixed": (case_mixed, 13), "kmeans": (case_kmeans, 14),
                 "mnl_ordinal": (case_mnl_ordinal, 25), "loss_test": (case_loss_test, 26)}
 
 

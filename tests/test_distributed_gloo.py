@@ -60,6 +60,20 @@ def test_two_ranks_equal_one_rank(tmp_path, mode):
             assert cases.rel_err(o[:1], ch.objective[:1]) < 1e-12  # initial objective: column-blocked vs one accumulator
 
 
+@pytest.mark.parametrize("nproc", [2, 8])
+def test_c4_recipe_shards_equal_one_rank(tmp_path, nproc):
+    """The north-star recipe (rank 64, QuadLoss, NonNegConstraint on X and Y; tests/golden/c4.npz) on 2 and on 8 shards -- the world
+    size the scaling bench ends at; 150 rows / 80 columns over 8 ranks are ragged blocks."""
+    ranks = run_world(tmp_path, ["c4"], nproc)
+    O.set_threads(1)
+    kwargs, params = cases.build_golden_case("c4")
+    g = L.GLRM(**kwargs)
+    X, Y, ch = L.fit_b(g, params, verbose=False, engine=O.oracle_api())
+    for z in ranks:
+        assert np.array_equal(z["c4_X"], X) and np.array_equal(z["c4_Y"], Y)
+        assert np.array_equal(z["c4_obj"][1:], np.array(ch.objective[1:]))
+
+
 def test_three_ranks_ragged_blocks(tmp_path):
     """m, n not divisible by the world size -> ragged blocks -> one broadcast per owner."""
     ranks = run_world(tmp_path, ["nnmf"], 3)

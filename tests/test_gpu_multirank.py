@@ -25,25 +25,46 @@ def run(cmd, env):
     return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
 
 
+QUIET = ["--no-convergence-run", "--no-cpu-baseline", "--no-jref", "--pmc", "off"]
+
+
+def torchrun(n):
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), "bench.py", "--gpus", str(n)]
+
+
 @pytest.mark.parametrize("x_chunks,gather", [(4, "allgather"), (1, "broadcast")])
 def test_two_ranks_on_one_gpu_equal_one_rank(x_chunks, gather):
-    common = ["--steps", "3", "--warmup", "2", "--cols", "2000", "--obs-per-row", "100", "--no-convergence-run", "--no-cpu-baseline", "--tiled", "2"]
+    """Weak-scaling flags (--rows-per-gpu): two ranks x 30 000 rows = one rank x 60 000 rows of the C2 recipe."""
+    common = ["--config", "C2", "--steps", "3", "--warmup", "2", "--cols", "2000", "--obs-per-row", "100", "--tiled", "2"] + QUIET
     env = dict(os.environ, GLRM_BENCH_BACKEND="gloo", GLRM_GATHER=gather)
-    two = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-               "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--rows-per-gpu", "30000", "--x-chunks", str(x_chunks)] + common, env)
-    one = run([sys.executable, "bench.py", "--rows-per-gpu", "60000"] + common, dict(os.environ))
-    assert two["n_gpus"] == 2 and one["n_gpus"] == 1
+    two = run(torchrun(2) + ["--rows-per-gpu", "30000", "--x-chunks", str(x_chunks)] + common, env)
+    one = run([sys.executable, "bench.py", "--rows", "60000"] + common, dict(os.environ))
+    assert two["n_gpus"] == 2 and one["n_gpus"] == 1 and two["scaling"] == "weak"
     assert two["config"]["observed"] == one["config"]["observed"] == 60000 * 100
     assert two["objective"]["initial"] == one["objective"]["initial"]
     assert two["objective"]["after_warmup_and_steps"] == one["objective"]["after_warmup_and_steps"]
 
 
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_c4_recipe_strong_scaling_equals_one_rank(nranks):
+    """bench.py's default mode: the C4 recipe (rank 64, NonNegConstraint, non-negative start) as ONE fixed problem whose rows and
+    columns are cut into `nranks` shards (strong scaling) -- same recorded objectives, bit for bit, as the single-rank run."""
+    common = ["--config", "C4", "--rows", "48000", "--cols", "4000", "--obs-per-row", "100", "--steps", "3", "--warmup", "2"] + QUIET
+    env = dict(os.environ, GLRM_BENCH_BACKEND="gloo", GLRM_GATHER="allgather")
+    many = run(torchrun(nranks) + common, env)
+    one = run([sys.executable, "bench.py"] + common, dict(os.environ))
+    assert many["n_gpus"] == nranks and many["scaling"] == "strong" and many["config"]["k"] == 64
+    assert many["config"]["observed"] == one["config"]["observed"] == 48000 * 100
+    assert many["objective"] == one["objective"]
+    assert 0 < one["roofline"]["frac"] <= 1.0 and one["roofline"]["bound"] in ("hbm", "l2", "lds", "mfma")
+
+
 def test_eight_ranks_on_one_gpu_equal_one_rank():
     """The world size the scaling bench ends at: eight row / column shards (default auto kernel choice, pipelined X exchange)."""
-    common = ["--steps", "2", "--warmup", "2", "--cols", "4000", "--obs-per-row", "200", "--no-convergence-run", "--no-cpu-baseline"]
+    common = ["--config", "C2", "--steps", "2", "--warmup", "2", "--cols", "4000", "--obs-per-row", "200"] + QUIET
     env = dict(os.environ, GLRM_BENCH_BACKEND="gloo", GLRM_GATHER="allgather")
-    eight = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-                 "--master-port", str(free_port()), "bench.py", "--gpus", "8", "--rows-per-gpu", "25000"] + common, env)
-    one = run([sys.executable, "bench.py", "--rows-per-gpu", "200000"] + common, dict(os.environ))
+    eight = run(torchrun(8) + ["--rows-per-gpu", "25000"] + common, env)
+    one = run([sys.executable, "bench.py", "--rows", "200000"] + common, dict(os.environ))
     assert eight["n_gpus"] == 8 and eight["config"]["observed"] == one["config"]["observed"] == 200000 * 200
     assert eight["objective"] == one["objective"]

@@ -209,6 +209,40 @@ def test_moderate_sparse_shape_k32():
     compare(pa, X0, Y0, L.ProxGradParams(max_iter=12))
 
 
+def _c4_problem(m, n, q, k=64):
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, q, value_model=1)
+    one = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(3, 0, 1.0)], dtype=_capi.REG_DTYPE)  # NonNegConstraint, src/regularizers.jl:101-114
+    return _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, one, reg, reg), X0, Y0
+
+
+@pytest.mark.parametrize("start", ["nonneg", "randn"])
+def test_c4_recipe(start):
+    """BASELINE config 4 (the north-star target: rank 64, QuadLoss, NonNegConstraint on X and Y, 100 sorted observations per row,
+    non-negative value model) at 20 000 x 2 000, both kernel families against the oracle.  `nonneg` is bench.py's start
+    (|N(0,1)|/sqrt(k)); `randn` is the reference default (src/glrm.jl:31), whose objective starts at Inf and which collapses to
+    X = 0 on this shape -- the engine has to follow the reference there too (Inf handling, then trials that all reject)."""
+    pa, X0, Y0 = _c4_problem(20000, 2000, 100)
+    if start == "nonneg":
+        X0, Y0 = np.asfortranarray(np.abs(X0) / 8.0), np.asfortranarray(np.abs(Y0) / 8.0)
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=12))
+    if start == "randn":
+        o, X, Y, st = cases.run_engine(hip(), pa, X0, Y0, L.ProxGradParams(max_iter=12))
+        assert np.isinf(o[0]) and np.count_nonzero(X) == 0  # the collapse is the reference's behaviour, not an engine artefact
+
+
+def test_c4_recipe_sparse_rows_full_density():
+    """The same recipe at the full problem's density (0.1 % observed: 100 observations per row over 100 000 columns, so the LDS tiles
+    see ~0.3 observations per row and the auto choice must stay on the gather sweeps), 3 000 rows."""
+    pa, X0, Y0 = _c4_problem(3000, 100000, 100)
+    X0, Y0 = np.asfortranarray(np.abs(X0) / 8.0), np.asfortranarray(np.abs(Y0) / 8.0)
+    h = hip().create(pa)
+    st = hip().kernel_stats(h)
+    hip().destroy(h)
+    assert st["tiled"] == 0 and st["ld"] == 64
+    compare(pa, X0, Y0, L.ProxGradParams(max_iter=6), tiled=0)
+
+
 def test_mixed_losses_k32_several_tiles():
     """The C5 recipe at 1/2000 of the size: 2500 x 2000, rank 32, Quad / Logistic / OrdinalHinge columns, 100 observations per row.
     2000 columns = 4 LDS tiles, so batches of four observations straddle tile windows and loss kinds in the row sweep."""
