@@ -49,7 +49,7 @@ def build_all(force=False, verbose=True):
             for cmd, pr in procs:
                 if pr.wait() != 0:
                     raise subprocess.CalledProcessError(pr.returncode, cmd)
-            link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+            link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", out]
             if verbose:
                 print("[build]", " ".join(link), flush=True)
             subprocess.run(link, check=True)

@@ -16,6 +16,7 @@
 // No CPU fallback lives here; the CPU restatement (oracle/) is a separate, test-only library.
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 
@@ -879,8 +880,31 @@ static int drain_events(glrm_handle* h) {
   return GLRM_OK;
 }
 
+// roctx ranges around every half-step (rocprofv3 --marker-trace shows "glrm step_x" / "glrm step_y" / "glrm col_losses" on the host
+// timeline).  libroctx64 is looked up at run time so that the engine has no link-time dependency on the tracer; GLRM_HIP_ROCTX=0
+// switches the ranges off.
+struct RoctxApi {
+  int (*push)(const char*) = nullptr;
+  int (*pop)() = nullptr;
+  RoctxApi() {
+    if (!env_int("GLRM_HIP_ROCTX", 1)) return;
+    void* lib = dlopen("libroctx64.so", RTLD_LAZY | RTLD_LOCAL);
+    if (!lib) lib = dlopen("libroctx64.so.4", RTLD_LAZY | RTLD_LOCAL);
+    if (!lib) return;
+    push = (int (*)(const char*))dlsym(lib, "roctxRangePushA");
+    pop = (int (*)())dlsym(lib, "roctxRangePop");
+    if (!push || !pop) push = nullptr, pop = nullptr;
+  }
+};
+struct RoctxRange {
+  static RoctxApi& api() { static RoctxApi a; return a; }
+  explicit RoctxRange(const char* name) { if (api().push) api().push(name); }
+  ~RoctxRange() { if (api().pop) api().pop(); }
+};
+
 // which: 0 = row sweep (X half-step), 1 = column sweep (Y half-step)
 static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_only) {
+  RoctxRange range(eval_only ? "glrm col_losses" : (which == 0 ? "glrm step_x" : "glrm step_y"));
   int rc = ensure_owned(h);
   if (rc) return rc;
   SweepArgs a{};

@@ -144,6 +144,7 @@ class GLRM:
         self._rowvals = self._gather(np.repeat(np.arange(m, dtype=np.int64), np.diff(rowptr)), colidx.astype(np.int64), checknan)
         self._colvals = self._gather(rowidx.astype(np.int64), np.repeat(np.arange(n, dtype=np.int64), np.diff(colptr)), False)
         self._handle_cache = None
+        self._split_cache = None
         if scale:   # equilibrate_variance!(glrm) BEFORE add_offset!, src/glrm.jl:73-78
             from .scaling import equilibrate_variance_
             equilibrate_variance_(self)
@@ -273,4 +274,5 @@ def copy_estimate(g):  # conveniencemethods.jl:16-20: shares problem data, copie
     c = _copy.copy(g)
     c.X, c.Y = g.X.copy(order="F"), g.Y.copy(order="F")
     c._handle_cache = None
+    c._split_cache = None  # the cached split captures the model it was built for (its X / Y): the copy builds its own
     return c

@@ -752,6 +752,11 @@ int glrm_cpu_set_regularizers(glrm_cpu_handle* h, const glrm_reg* rx, int64_t n_
   if (n_rx != h->n_rx || n_ry != h->n_ry) return fail(GLRM_ERR_INVALID, "regularizer counts must match the handle");
   memcpy(h->rx, rx, (size_t)n_rx * sizeof(glrm_reg));
   memcpy(h->ry, ry, (size_t)n_ry * sizeof(glrm_reg));
+  /* a wrapper (lastentry1 / lastentry_unpenalized / OrdinalReg / MNLOrdinalReg) moves a scalar-path handle to the general path, like
+   * at create (add_offset! after a first fit!, src/modify_glrm.jl:20-25); the HIP engine does the same (glrm_hip_set_regularizers) */
+  for (int64_t i = 0; i < n_rx; ++i) if (rx[i].wrap) h->multi = 1;
+  for (int64_t i = 0; i < n_ry; ++i) if (ry[i].wrap) h->multi = 1;
+  if (h->multi && h->dense_faithful) return fail(GLRM_ERR_UNSUPPORTED, "dense-faithful mode covers the scalar path only");
   return GLRM_OK;
 }
 

@@ -1,4 +1,7 @@
-"""GLRM(df, k, datatypes) (reference: src/fit_dataframe.jl:12-79,83-205): a model for a table with :real / :bool / :ord / :cat
+"""TEST-SIDE helper (not part of the product: SURVEY.md section 2 marks the DataFrame constructor out of scope; it lives here only
+because the replayed reference scripts -- test/hello_world.jl -- build their models with it).
+
+GLRM(df, k, datatypes) (reference: src/fit_dataframe.jl:12-79,83-205): a model for a table with :real / :bool / :ord / :cat
 columns -- levels mapped to numbers, one loss per column from a loss map, OrdinalReg on multi-dimensional ordinal columns, an
 unpenalized offset, prob_scale!.  The table is a pandas DataFrame (or anything pandas.DataFrame accepts)."""
 from __future__ import annotations
@@ -7,10 +10,10 @@ import copy as _copy
 
 import numpy as np
 
-from .glrm import GLRM
-from .losses import BvSLoss, HuberLoss, LogisticLoss, MultinomialLoss, MultinomialOrdinalLoss, OrdisticLoss, OvALoss, QuadLoss
-from .regularizers import OrdinalReg, QuadReg
-from .scaling import prob_scale_
+from lowrankmodels.jl_amd.glrm import GLRM
+from lowrankmodels.jl_amd.losses import BvSLoss, HuberLoss, LogisticLoss, MultinomialLoss, MultinomialOrdinalLoss, OrdisticLoss, OvALoss, QuadLoss
+from lowrankmodels.jl_amd.regularizers import OrdinalReg, QuadReg
+from .prob_scale import prob_scale_
 
 probabilistic_losses = {"real": QuadLoss, "bool": LogisticLoss, "ord": MultinomialOrdinalLoss, "cat": MultinomialLoss}
 robust_losses = {"real": HuberLoss, "bool": LogisticLoss, "ord": BvSLoss, "cat": OvALoss}

@@ -1,9 +1,9 @@
-"""pca / qpca / nnmf / kmeans / rpca model builders (reference: src/simple_glrms.jl:1-42): five-line constructors on top of GLRM."""
+"""TEST-SIDE helper (out of scope for the product): pca / qpca / nnmf / kmeans / rpca model builders (reference: src/simple_glrms.jl:1-42): five-line constructors on top of GLRM."""
 from __future__ import annotations
 
-from .glrm import GLRM
-from .losses import HuberLoss, QuadLoss
-from .regularizers import NonNegConstraint, QuadReg, UnitOneSparseConstraint, ZeroReg
+from lowrankmodels.jl_amd.glrm import GLRM
+from lowrankmodels.jl_amd.losses import HuberLoss, QuadLoss
+from lowrankmodels.jl_amd.regularizers import NonNegConstraint, QuadReg, UnitOneSparseConstraint, ZeroReg
 
 
 def pca(A, k, **kwargs):

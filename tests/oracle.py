@@ -12,6 +12,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_LIB = os.path.join(ORACLE_DIR, "libglrm_oracle.so")
+SANITIZED_LIB = os.environ.get("GLRM_ORACLE_LIB")  # `make -C oracle asan-check` runs the CPU suite on the ASan / UBSan build
 
 
 def build_oracle(force=False):
@@ -30,7 +31,7 @@ _lib = None
 def oracle_lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(build_oracle())
+        _lib = C.CDLL(SANITIZED_LIB if SANITIZED_LIB else build_oracle())
         _lib.glrm_cpu_loss_evaluate.restype = C.c_double
         _lib.glrm_cpu_loss_evaluate.argtypes = [C.c_void_p, C.c_double, C.c_double]
         _lib.glrm_cpu_loss_grad.restype = C.c_double

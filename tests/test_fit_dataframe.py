@@ -4,6 +4,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
+import extras as E
 import lowrankmodels.jl_amd as L
 import oracle as O
 
@@ -24,7 +25,7 @@ def table(rng, m=60):
 def test_model_from_table():
     rng = np.random.default_rng(0)
     df = table(rng)
-    g = L.glrm_from_dataframe(df, 3, ["real", "bool", "ord", "cat"], rng=rng)
+    g = E.glrm_from_dataframe(df, 3, ["real", "bool", "ord", "cat"], rng=rng)
     assert [type(l).__name__ for l in g.losses] == ["QuadLoss", "LogisticLoss", "MultinomialOrdinalLoss", "MultinomialLoss"]
     assert g.losses[2].max == 4 and g.losses[3].max == 3 and g.Y.shape == (3, 1 + 1 + 3 + 3)
     assert isinstance(g.ry[2], L.OrdinalReg) and isinstance(g.ry[0], L.lastentry_unpenalized) and isinstance(g.rx[0], L.lastentry1)
@@ -49,12 +50,12 @@ def test_model_from_table():
 def test_argument_checks():
     df = table(np.random.default_rng(1), 20)
     with pytest.raises(ValueError):
-        L.glrm_from_dataframe(df, 2, ["real", "bool", "ord"])
+        E.glrm_from_dataframe(df, 2, ["real", "bool", "ord"])
     with pytest.raises(ValueError):
-        L.glrm_from_dataframe(df, 2, ["real", "bool", "ord", "text"])
+        E.glrm_from_dataframe(df, 2, ["real", "bool", "ord", "text"])
     with pytest.raises(ValueError):
-        L.glrm_from_dataframe(df, 2, ["real", "bool", "bool", "cat"])      # 'grade' has four levels
+        E.glrm_from_dataframe(df, 2, ["real", "bool", "bool", "cat"])      # 'grade' has four levels
     with pytest.raises(ValueError):
-        L.glrm_from_dataframe(df, 2, ["real", "real", "ord", "cat"])       # 'smoker' is not numeric
-    g = L.glrm_from_dataframe(df, 2, ["real", "bool", "ord", "cat"], loss_map=L.robust_losses, offset=False, prob_scale=False)
+        E.glrm_from_dataframe(df, 2, ["real", "real", "ord", "cat"])       # 'smoker' is not numeric
+    g = E.glrm_from_dataframe(df, 2, ["real", "bool", "ord", "cat"], loss_map=E.robust_losses, offset=False, prob_scale=False)
     assert [type(l).__name__ for l in g.losses] == ["HuberLoss", "LogisticLoss", "BvSLoss", "OvALoss"] and isinstance(g.ry[2], L.OrdinalReg)

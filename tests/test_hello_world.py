@@ -7,6 +7,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
+import extras as E
 import lowrankmodels.jl_amd as L
 import oracle as O
 from lowrankmodels.jl_amd import _capi
@@ -37,7 +38,7 @@ def hello_world(api, rng):
     I, J = np.nonzero(~np.isnan(S))
     g = L.GLRM(S, L.QuadLoss(), L.QuadReg(), L.QuadReg(), 2, obs=(I, J), rng=rng)                # explicitly encoded missing entries
     out.append(L.fit_b(g, p, verbose=False, engine=api)[2])
-    g = L.glrm_from_dataframe(pd.DataFrame(A), 3, data_types, rng=rng)                            # "successfully fit dataframe"
+    g = E.glrm_from_dataframe(pd.DataFrame(A), 3, data_types, rng=rng)                            # "successfully fit dataframe"
     out.append(L.fit_b(g, p, verbose=False, engine=api)[2])
     Ahat = L.impute(g, engine=api)                                                                # "successfully imputed entries"
     assert Ahat.shape == A.shape and np.all(np.isfinite(Ahat))

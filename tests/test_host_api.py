@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
+import extras as E
 import lowrankmodels.jl_amd as L
 import oracle as O
 
@@ -206,12 +207,45 @@ def test_simple_glrm_builders():
     """src/simple_glrms.jl; test/runtests.jl:19-25 runs kmeans with inner_iter=10 on two separated clusters."""
     rng = np.random.default_rng(0)
     A = np.vstack([rng.standard_normal((100, 10)) + 5, rng.standard_normal((50, 10)) - 5])
-    g = L.kmeans(A, 2, rng=rng)
+    g = E.kmeans(A, 2, rng=rng)
     X, Y, ch = L.fit_b(g, L.ProxGradParams(max_iter=30, inner_iter=10), verbose=False, engine=O.oracle_api())
     lab = np.argmax(X, axis=0)
     assert len(set(lab[:100])) == 1 and len(set(lab[100:])) == 1 and lab[0] != lab[-1]      # 100 / 50 split recovered
-    for build, rx, ry in ((L.pca, L.ZeroReg, L.ZeroReg), (L.nnmf, L.NonNegConstraint, L.NonNegConstraint)):
+    for build, rx, ry in ((E.pca, L.ZeroReg, L.ZeroReg), (E.nnmf, L.NonNegConstraint, L.NonNegConstraint)):
         m = build(A, 3, rng=rng)
         assert isinstance(m.rx[0], rx) and isinstance(m.ry[0], ry) and isinstance(m.losses[0], L.QuadLoss)
-    q, r = L.qpca(A, 3, scale=0.5, rng=rng), L.rpca(A, 3, scale=2.0, rng=rng)
+    q, r = E.qpca(A, 3, scale=0.5, rng=rng), E.rpca(A, 3, scale=2.0, rng=rng)
     assert q.rx[0].scale == 0.5 and isinstance(r.losses[0], L.HuberLoss) and r.ry[0].scale == 2.0
+
+
+def test_add_offset_after_a_first_fit_reuses_the_handle_on_the_general_path():
+    """fit!, then add_offset! (src/modify_glrm.jl:20-25), then fit! again on the SAME model: the cached engine handle only gets new
+    regularizer descriptors (set_regularizers) and must move to the general path that knows lastentry1 / lastentry_unpenalized --
+    on the oracle engine too (it is the checker of that flow for the HIP engine)."""
+    rng = np.random.default_rng(77)
+    m, n, k = 60, 25, 4
+    A = rng.standard_normal((m, 3)) @ rng.standard_normal((3, n)) + 2.0
+    X0, Y0 = rng.standard_normal((k, m)), rng.standard_normal((k, n))
+    p = L.ProxGradParams(max_iter=8)
+    g = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.1), k, X=X0.copy(), Y=Y0.copy())
+    L.fit_b(g, p, verbose=False, engine=O.oracle_api())
+    Xw, Yw = g.X.copy(), g.Y.copy()
+    L.add_offset_(g)
+    L.fit_b(g, p, verbose=False, engine=O.oracle_api())      # cached handle + set_regularizers
+    assert np.all(g.X[-1] == 1.0)
+    f = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.1), k, X=Xw.copy(), Y=Yw.copy(), offset=True)
+    L.fit_b(f, p, verbose=False, engine=O.oracle_api())      # fresh handle created with the wrappers
+    assert np.array_equal(g.X, f.X) and np.array_equal(g.Y, f.Y)
+
+
+def test_copy_estimate_builds_its_own_train_test_split():
+    """copy_estimate shares the problem data and copies X, Y (src/conveniencemethods.jl:16-20): a train / test split taken from the
+    copy carries the COPY's factors even after the original has cached a split of its own."""
+    rng = np.random.default_rng(78)
+    A = rng.standard_normal((30, 12))
+    g = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.QuadReg(0.1), 3, X=rng.standard_normal((3, 30)), Y=rng.standard_normal((3, 12)))
+    L.get_train_and_test(g, 0.2, rng=np.random.default_rng(1), engine=O.oracle_api(), fused=False)  # caches a split on g
+    c = L.copy_estimate(g)
+    c.X[...] = 7.0
+    train, test = L.get_train_and_test(c, 0.2, rng=np.random.default_rng(1), engine=O.oracle_api(), fused=False)
+    assert np.all(train.X == 7.0) and np.all(test.X == 7.0) and not np.any(g.X == 7.0)

@@ -5,6 +5,7 @@ import math
 import numpy as np
 import pytest
 
+import extras as E
 import lowrankmodels.jl_amd as L
 import oracle as O
 
@@ -62,7 +63,19 @@ def test_prob_scale():
     rng = np.random.default_rng(3)
     A = np.column_stack([rng.standard_normal(30) * 2, rng.standard_normal(30), rng.random(30) < 0.5])
     g = L.GLRM(A, [L.QuadLoss(), L.HuberLoss(), L.LogisticLoss(3.0)], L.QuadReg(), L.QuadReg(), 2)
-    L.prob_scale_(g)
+    E.prob_scale_(g)
     assert g.losses[0].scale == pytest.approx(1 / (2 * np.var(A[:, 0], ddof=1)))
     assert g.losses[1].scale == pytest.approx(1 / (2 * L.avgerror(L.HuberLoss(), A[:, 1])))
     assert g.losses[2].scale == 1.0   # mul!(l, 1): `*`/mul! SET the scale (src/losses.jl:61-64)
+
+
+def test_prob_scale_small_variance_column_is_rescaled():
+    """TOL of prob_scale! is the module constant 1e-12 (src/regularizers.jl:25), not the 1e-3 keyword defaults of the MNL ordinal
+    rules: a real column in small units (variance ~1e-4) is rescaled."""
+    rng = np.random.default_rng(4)
+    A = np.column_stack([0.01 * rng.standard_normal(40), rng.standard_normal(40)])
+    v = np.var(A[:, 0], ddof=1)
+    assert 1e-12 < v < 1e-3
+    g = L.GLRM(A, [L.QuadLoss(), L.QuadLoss()], L.QuadReg(), L.QuadReg(), 2)
+    E.prob_scale_(g)
+    assert g.losses[0].scale == pytest.approx(1 / (2 * v)) and g.losses[0].scale > 1000
