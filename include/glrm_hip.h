@@ -53,7 +53,7 @@ typedef enum glrm_status {
   GLRM_ERR_INVALID = -1,     /* bad argument / inconsistent sizes (reference: error(...) src/glrm.jl:39-43) */
   GLRM_ERR_UNSUPPORTED = -2, /* loss / regularizer kind or rank not implemented by the engine */
   GLRM_ERR_HIP = -3,         /* HIP runtime error */
-  GLRM_ERR_COMM = -4,        /* reserved (collectives live in the host layer) */
+  GLRM_ERR_COMM = -4,        /* inter-GPU exchange failed (peer copy / RCCL) in the glrm_hip_multi_* entry points */
   GLRM_ERR_OOM = -5,         /* device or host allocation failed */
   GLRM_ERR_NONFINITE = -6    /* NaN observation (src/glrm.jl:63-71) or bad Bool label (src/losses.jl:104) */
 } glrm_status;
@@ -298,6 +298,44 @@ int glrm_hip_impute(glrm_handle* h, const double* X, const double* Y, const glrm
 /* Fixed-order sum of n device doubles (independent of the number of shards); synchronises. */
 int glrm_hip_sum(glrm_handle* h, const void* dvec, int64_t n, double* out);
 int glrm_hip_synchronize(glrm_handle* h);
+
+/* ---- multi-GPU whole-fit API: ONE host process drives N devices (what a Julia `fit!` can ccall) ------------------------
+ *
+ * The reference's own parallel contract is "rows independent, then columns independent" inside one address space
+ * (src/algorithms/proxgrad_multithread.jl:118,163).  glrm_hip_multi_create takes the SAME single-shard problem description as
+ * glrm_hip_create (host arrays: the two Omega views or dense_A), cuts rows and columns into n_shards contiguous blocks balanced
+ * by observation count, uploads block s to device_ids[s] and keeps a replica of X and Y on every device.  glrm_hip_multi_fit is
+ * fit!(glrm, ProxGradParams) (src/algorithms/proxgrad.jl:34-220) on that layout: every shard runs the X half-step of its rows on
+ * its own device from its own host thread and stream, the updated row blocks are exchanged (all-gather), then the same for the
+ * columns; the recorded objective is a fixed-order sum of the gathered per-column values, so objective[], X and Y are bit-identical
+ * to glrm_hip_fit on one device for every n_shards.
+ *
+ * Exchange (glrm_multi_options.exchange): 0 = direct -- every device pushes its block to each peer with hipMemcpyPeerAsync on a
+ * copy stream per (source, destination) pair, i.e. all 7 xGMI links of a GPU carry one 1/N slice at once; 1 = RCCL ncclAllGather
+ * in place (librccl is loaded at run time; needs distinct devices and equal blocks, otherwise the direct path is used).
+ * device_ids may repeat (several shards on one device: the layout of the multi-GPU fit on a box with fewer GPUs).
+ */
+typedef struct glrm_multi glrm_multi;
+
+typedef struct glrm_multi_options {
+  int32_t n_shards;          /* >= 1 */
+  int32_t exchange;          /* 0 direct peer copies (default), 1 RCCL all-gather */
+  const int32_t* device_ids; /* n_shards HIP device ordinals; NULL = 0, 1, ..., n_shards-1 */
+  int32_t x_chunks;          /* >= 2: the X half-step runs in row chunks whose exchange overlaps the sweep of the next chunk; 0/1 off */
+  int32_t reserved;          /* must be 0 */
+} glrm_multi_options;
+
+int glrm_hip_multi_create(glrm_multi** out, const glrm_problem* p, const glrm_options* o, const glrm_multi_options* mo);
+/* Same arguments and results as glrm_hip_fit. */
+int glrm_hip_multi_fit(glrm_multi* mh, const glrm_params* prm, double* X, double* Y, double* objective, double* seconds,
+                       int64_t cap, int64_t* n_recorded);
+/* Replace the regularizer descriptors (n_rx = 1 or m, n_ry = 1 or n, like at create): regularization_path / scale_regularizer!
+ * between warm-started fits, Omega and A stay on the devices. */
+int glrm_hip_multi_set_regularizers(glrm_multi* mh, const glrm_reg* rx, int64_t n_rx, const glrm_reg* ry, int64_t n_ry);
+/* row_bounds / col_bounds: n_shards+1 entries each (may be NULL); exchange_used: 0 direct, 1 RCCL;
+ * exchange_ms: summed wall time between the end of a half-step's sweeps and the arrival of the last block, last fit */
+int glrm_hip_multi_info(glrm_multi* mh, int64_t* row_bounds, int64_t* col_bounds, int32_t* exchange_used, double* exchange_ms);
+void glrm_hip_multi_destroy(glrm_multi* mh); /* NULL is a no-op */
 
 /* ---- introspection ------------------------------------------------------------------- */
 

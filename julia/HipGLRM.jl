@@ -1,10 +1,20 @@
-# HipGLRM.jl -- the reference-side binding: a new `AbstractParams` subtype plus one `fit!` method that
-# `ccall`s libglrm_hip.so (include/glrm_hip.h).  Drop this file next to LowRankModels.jl and
-# `include("HipGLRM.jl")`; every driver that forwards `params=` (fit!, cross_validate, cv_by_iter,
-# regularization_path, precision_at_k, the ScikitLearn wrappers) then runs on the MI355X engine.
+# HipGLRM.jl -- the reference-side binding: a new `AbstractParams` subtype plus one `fit!` method that `ccall`s libglrm_hip.so
+# (include/glrm_hip.h).  `include("HipGLRM.jl")` next to LowRankModels.jl; every driver that forwards `params=` (fit!,
+# cross_validate, cv_by_iter, regularization_path, precision_at_k, the ScikitLearn wrappers -- src/fit.jl:8-12,
+# src/cross_validate.jl:10,142,184,243) then runs on the MI355X engine.  Host code stays in Julia; nothing here computes.
 #
-# NOT EXECUTED IN THIS REPOSITORY'S CI: no `julia` binary exists in the build image or on the GPU box
-# (SURVEY.md F2).  It is pure marshalling; the same C entry points are exercised from Python/ctypes.
+#   fit!(glrm, HipProxGradParams())                       one GPU            glrm_hip_create + glrm_hip_fit
+#   fit!(glrm, HipProxGradParams(ngpus = 8))              eight GPUs, ONE Julia process: glrm_hip_multi_create + glrm_hip_multi_fit
+#                                                         (the library shards rows / columns, replicates X, Y and exchanges the
+#                                                         updated blocks over xGMI after every half-step)
+# * a fully observed single-QuadLoss model hands `glrm.A` over as the dense matrix it is (column-major, `dense_colmajor = 1`):
+#   the half-steps then run on the fp64 matrix cores and no index list is built (BASELINE config 3: 80 GB instead of 2 x 120 GB);
+# * the engine handle (Omega views and A on the device) is cached per model, so warm starts, `cv_by_iter`'s `max_iter = 1` loop
+#   (src/cross_validate.jl:164-175) and `regularization_path` do not re-upload; new regularizers only replace descriptors;
+# * loss / regularizer types outside include/glrm_hip.h fall back to the reference solver.
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: no `julia` binary exists in the build image or on the GPU box (SURVEY.md F2).  It is pure
+# marshalling; the same C entry points are exercised from C (examples/c_abi_example.c, examples/c_abi_multi.c) and Python/ctypes.
 module HipGLRM
 
 using LowRankModels
@@ -15,7 +25,7 @@ import LowRankModels: fit!, GLRM, AbstractParams, ConvergenceHistory, update_ch!
                       ZeroReg, QuadReg, OneReg, NonNegConstraint, UnitOneSparseConstraint,
                       lastentry1, lastentry_unpenalized, OrdinalReg, MNLOrdinalReg, ProxGradParams
 
-export HipProxGradParams, hip_init_svd!, hip_error_metric, hip_impute
+export HipProxGradParams, hip_release!
 
 const LIB = get(ENV, "GLRM_HIP_LIB", "libglrm_hip.so")
 
@@ -35,17 +45,23 @@ struct CParams
     abs_tol::Float64; rel_tol::Float64; min_stepsize::Float64
 end
 struct COptions; device_id::Int32; profile::Int32; waves_row::Int32; waves_col::Int32; stream::Ptr{Cvoid}; caller_stream::Int32; tiled::Int32; end
+struct CMultiOptions; n_shards::Int32; exchange::Int32; device_ids::Ptr{Int32}; x_chunks::Int32; reserved::Int32; end
 
-"The 7 ProxGradParams fields (src/algorithms/proxgrad.jl:4-12) + the device ordinal."
+"The 7 ProxGradParams fields (src/algorithms/proxgrad.jl:4-12) + where to run: `device_id` (one GPU) or `ngpus` / `device_ids`."
 mutable struct HipProxGradParams <: AbstractParams
     stepsize::Float64; max_iter::Int; inner_iter_X::Int; inner_iter_Y::Int
-    abs_tol::Float64; rel_tol::Float64; min_stepsize::Float64; device_id::Int
+    abs_tol::Float64; rel_tol::Float64; min_stepsize::Float64
+    device_id::Int; ngpus::Int; device_ids::Vector{Int32}; exchange::Symbol; x_chunks::Int; dense::Bool
 end
 function HipProxGradParams(stepsize::Number=1.0; max_iter::Int=100, inner_iter_X::Int=1, inner_iter_Y::Int=1,
                            inner_iter::Int=1, abs_tol::Number=0.00001, rel_tol::Number=0.0001,
-                           min_stepsize::Number=0.01*stepsize, device_id::Int=-1)
+                           min_stepsize::Number=0.01*stepsize, device_id::Int=-1, ngpus::Int=1,
+                           device_ids=Int32.(0:ngpus-1), exchange::Symbol=:direct, x_chunks::Int=4, dense::Bool=true)
+    length(device_ids) == ngpus || error("device_ids must list one device per shard")
+    exchange in (:direct, :rccl) || error("exchange must be :direct or :rccl")
     HipProxGradParams(Float64(stepsize), max_iter, max(inner_iter_X, inner_iter), max(inner_iter_Y, inner_iter),
-                      Float64(abs_tol), Float64(rel_tol), Float64(min_stepsize), device_id)
+                      Float64(abs_tol), Float64(rel_tol), Float64(min_stepsize), device_id, ngpus, Vector{Int32}(device_ids),
+                      exchange, x_chunks, dense)
 end
 
 closs(l::QuadLoss) = CLoss(0, 0, l.scale, 0, 0)
@@ -81,7 +97,8 @@ creg(r::MNLOrdinalReg) = wrapped(r, 8)
 creg(r::Regularizer) = nothing
 
 isclass(l) = l isa LogisticLoss || l isa WeightedHingeLoss
-value(l, a) = isclass(l) ? (a isa Bool ? Float64(a) : Float64(LowRankModels.myBool(a))) : Float64(a)
+value(l, a) = isclass(l) ? (a isa Bool ? Float64(a) : Float64(LowRankModels.myBool(Int(a)))) : Float64(a)   # src/losses.jl:104-106
+collapse(v) = all(==(v[1]), v) ? v[1:1] : v          # one descriptor when every column / row carries the same one
 
 # observed_features / observed_examples -> 0-based CSR / CSC, each built from ITS OWN list (order and duplicates kept)
 function flatten(lists, getval)
@@ -108,29 +125,58 @@ function descriptors(glrm::GLRM)
     n = size(glrm.A, 2)
     general = embedding_dim(glrm.losses) != n || any(c -> c.wrap != 0, crx) || any(c -> c.wrap != 0, cry)
     (general && glrm.k > 64) && return nothing
-    Vector{CLoss}(cl), Vector{CReg}(crx), Vector{CReg}(cry)
+    collapse(Vector{CLoss}(cl)), collapse(Vector{CReg}(crx)), collapse(Vector{CReg}(cry))
 end
 
-# f(handle) on an engine handle holding the model's Omega views and values; the handle lives for the call.
-# (A host that calls several entry points in a row -- init_svd!, fit!, error_metric -- keeps it instead.)
-function with_handle(f, glrm::GLRM, desc, device_id::Int=-1)
+# the dense hand-over applies when every entry is observed (the constructor's default UnitRanges) under one QuadLoss
+fully_observed(glrm) = (s = size(glrm.A); all(==(1:s[2]), glrm.observed_features) && all(==(1:s[1]), glrm.observed_examples))
+dense_ok(glrm, desc, p) = p.dense && glrm.A isa Matrix{Float64} && length(desc[1]) == 1 && desc[1][1].kind == 0 &&
+                          9 <= glrm.k <= 64 && fully_observed(glrm)
+
+# ---- engine handles, cached per model ---------------------------------------------------------------------------------
+mutable struct Entry; h::Ptr{Cvoid}; multi::Bool; hard::UInt64; soft::UInt64; end
+const CACHE = IdDict{Any,Entry}()
+destroy(e::Entry) = (e.h == C_NULL || ccall(e.multi ? (:glrm_hip_multi_destroy, LIB) : (:glrm_hip_destroy, LIB), Cvoid, (Ptr{Cvoid},), e.h); e.h = C_NULL)
+"Drop the device copy of a model's data (also done by the model's finalizer).  Call it after mutating `glrm.A` in place."
+hip_release!(glrm::GLRM) = (haskey(CACHE, glrm) && (destroy(CACHE[glrm]); delete!(CACHE, glrm)); glrm)
+# what the device copy depends on (data, Omega, losses, placement) / what set_regularizers can replace
+hardkey(glrm, desc, p, dense) = hash((objectid(glrm.A), size(glrm.A), glrm.k, objectid(glrm.observed_features), objectid(glrm.observed_examples),
+                                      sum(length, glrm.observed_features), sum(length, glrm.observed_examples), desc[1],
+                                      length(desc[2]), length(desc[3]), p.device_id, p.ngpus, p.device_ids, p.exchange, p.x_chunks, dense))
+softkey(desc) = hash((desc[2], desc[3]))
+
+function handle(glrm::GLRM, desc, p::HipProxGradParams)
     losses, rx, ry = desc
-    A = glrm.A; m, n = size(A)
-    rowptr, colidx, rowvals = flatten(glrm.observed_features, (e, j) -> value(glrm.losses[j], A[e, j]))
-    colptr, rowidx, colvals = flatten(glrm.observed_examples, (j, e) -> value(glrm.losses[j], A[e, j]))
-    h = Ref{Ptr{Cvoid}}(C_NULL)
-    GC.@preserve losses rx ry rowptr colidx rowvals colptr rowidx colvals begin
-        prob = CProblem(m, n, glrm.k, 0, 0, m, 0, n, pointer(rowptr), pointer(colidx), pointer(rowvals),
-                        pointer(colptr), pointer(rowidx), pointer(colvals), pointer(losses), n,
-                        pointer(rx), m, pointer(ry), n, C_NULL, 0, 0, 0)
-        opt = COptions(device_id, 0, 0, 0, C_NULL, 0, 0)
-        check(ccall((:glrm_hip_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{CProblem}, Ref{COptions}), h, prob, opt))
-    end                                     # create copied everything: the host arrays may go
-    try
-        return f(h[])
-    finally
-        ccall((:glrm_hip_destroy, LIB), Cvoid, (Ptr{Cvoid},), h[])
+    dense = dense_ok(glrm, desc, p); multi = p.ngpus > 1
+    hard, soft = hardkey(glrm, desc, p, dense), softkey(desc)
+    e = get(CACHE, glrm, nothing)
+    if e !== nothing && e.hard == hard
+        if e.soft != soft                   # scale_regularizer! / regularization_path: Omega and A stay on the device
+            check(ccall(multi ? (:glrm_hip_multi_set_regularizers, LIB) : (:glrm_hip_set_regularizers, LIB), Cint,
+                        (Ptr{Cvoid}, Ptr{CReg}, Int64, Ptr{CReg}, Int64), e.h, rx, length(rx), ry, length(ry)))
+            e.soft = soft
+        end
+        return e.h
     end
+    e === nothing ? finalizer(hip_release!, glrm) : destroy(e)
+    A = glrm.A; m, n = size(A); h = Ref{Ptr{Cvoid}}(C_NULL)
+    rowptr, colidx, rowvals = dense ? (Int64[], Int32[], Float64[]) : flatten(glrm.observed_features, (e, j) -> value(glrm.losses[j], A[e, j]))
+    colptr, rowidx, colvals = dense ? (Int64[], Int32[], Float64[]) : flatten(glrm.observed_examples, (j, e) -> value(glrm.losses[j], A[e, j]))
+    nul(v) = dense ? Ptr{eltype(v)}(C_NULL) : pointer(v)
+    GC.@preserve losses rx ry rowptr colidx rowvals colptr rowidx colvals A p begin
+        prob = CProblem(m, n, glrm.k, 0, 0, m, 0, n, nul(rowptr), nul(colidx), nul(rowvals), nul(colptr), nul(rowidx), nul(colvals),
+                        pointer(losses), length(losses), pointer(rx), length(rx), pointer(ry), length(ry),
+                        dense ? pointer(A) : Ptr{Float64}(C_NULL), dense ? m : 0, dense ? 1 : 0, 0)   # Julia's A is column-major
+        opt = COptions(p.device_id, 0, 0, 0, C_NULL, 0, 0)
+        if multi
+            mo = CMultiOptions(p.ngpus, p.exchange == :rccl ? 1 : 0, pointer(p.device_ids), p.x_chunks, 0)
+            check(ccall((:glrm_hip_multi_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{CProblem}, Ref{COptions}, Ref{CMultiOptions}), h, prob, opt, mo))
+        else
+            check(ccall((:glrm_hip_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{CProblem}, Ref{COptions}), h, prob, opt))
+        end
+    end                                     # create copied everything: the host arrays may go
+    CACHE[glrm] = Entry(h[], multi, hard, soft)
+    h[]
 end
 
 function fit!(glrm::GLRM, p::HipProxGradParams; ch::ConvergenceHistory=ConvergenceHistory("HipProxGradGLRM"),
@@ -140,13 +186,12 @@ function fit!(glrm::GLRM, p::HipProxGradParams; ch::ConvergenceHistory=Convergen
     X = glrm.X isa Matrix{Float64} ? glrm.X : Matrix{Float64}(glrm.X); Y = glrm.Y    # Y is k x embedding_dim(glrm.losses)
     cap = p.max_iter + 1
     obj = zeros(cap); sec = zeros(cap); nrec = Ref{Int64}(0)
-    with_handle(glrm, desc, p.device_id) do h
-        prm = CParams(p.stepsize, p.max_iter, p.inner_iter_X, p.inner_iter_Y, p.abs_tol, p.rel_tol, p.min_stepsize)
-        verbose && println("Fitting GLRM")
-        check(ccall((:glrm_hip_fit, LIB), Cint,
-                    (Ptr{Cvoid}, Ref{CParams}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}),
-                    h, prm, X, Y, obj, sec, cap, nrec))
-    end
+    h = handle(glrm, desc, p)
+    prm = CParams(p.stepsize, p.max_iter, p.inner_iter_X, p.inner_iter_Y, p.abs_tol, p.rel_tol, p.min_stepsize)
+    verbose && println("Fitting GLRM")
+    check(ccall(p.ngpus > 1 ? (:glrm_hip_multi_fit, LIB) : (:glrm_hip_fit, LIB), Cint,
+                (Ptr{Cvoid}, Ref{CParams}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}),
+                h, prm, X, Y, obj, sec, cap, nrec))
     X === glrm.X || copyto!(glrm.X, X)
     for i in 1:nrec[]
         update_ch!(ch, i == 1 ? 0.0 : sec[i] - sec[i-1], obj[i])
@@ -155,63 +200,12 @@ function fit!(glrm::GLRM, p::HipProxGradParams; ch::ConvergenceHistory=Convergen
     return glrm.X, glrm.Y, ch
 end
 
-# ---- the entry points around fit! (src/initialize.jl:35-132, src/evaluate_fit.jl:107-168, src/impute_and_err.jl) ----
-
-struct CDomain; kind::Int32; reserved::Int32; lo::Float64; hi::Float64; end
-cdomain(d::LowRankModels.RealDomain) = CDomain(0, 0, 0, 0)
-cdomain(d::LowRankModels.BoolDomain) = CDomain(1, 0, 0, 0)
-cdomain(d::LowRankModels.OrdinalDomain) = CDomain(2, 0, d.min, d.max)
-cdomain(d::LowRankModels.PeriodicDomain) = CDomain(3, 0, d.T, 0)
-cdomain(d::LowRankModels.CountDomain) = CDomain(4, 0, 0, d.max_count)
-cdomain(d::LowRankModels.CategoricalDomain) = CDomain(5, 0, d.min, d.max)
-
-"init_svd!(glrm) on the device (the engine's subspace iteration in place of Arpack's svds); falls back to the reference."
-function hip_init_svd!(glrm::GLRM; device_id::Int=-1, tol=1e-10, max_iter=0, seed=1)
+# a single-device handle for the other entry points (julia/HipGLRMExtras.jl); nothing if the model is outside the engine
+function with_handle(f, glrm::GLRM, device_id::Int=-1)
     desc = descriptors(glrm)
-    desc === nothing && return LowRankModels.init_svd!(glrm)
-    X = Matrix{Float64}(undef, size(glrm.X)); Y = Matrix{Float64}(undef, size(glrm.Y))
-    with_handle(glrm, desc, device_id) do h
-        check(ccall((:glrm_hip_init_svd, LIB), Cint,
-                    (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32, Float64, UInt64, Ptr{Float64}, Ptr{Int32}),
-                    h, X, Y, max_iter, tol, seed, C_NULL, C_NULL))
-    end
-    copyto!(glrm.X, X); copyto!(glrm.Y, Y)
-    glrm
-end
-
-"error_metric(glrm, X, Y, domains; standardize) evaluated on the device; usable as `error_fn` of cross_validate."
-function hip_error_metric(glrm::GLRM, X::Matrix{Float64}, Y::Matrix{Float64},
-                          domains=[l.domain for l in glrm.losses]; standardize=false, device_id::Int=-1)
-    desc = descriptors(glrm)
-    desc === nothing && return LowRankModels.error_metric(glrm, X, Y, domains; standardize=standardize)
-    doms = CDomain[cdomain(d) for d in domains]; out = Ref{Float64}(0.0)
-    with_handle(glrm, desc, device_id) do h
-        check(ccall((:glrm_hip_error_metric, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{CDomain}, Int32, Ref{Float64}),
-                    h, X, Y, doms, standardize ? 1 : 0, out))
-    end
-    out[]
-end
-
-"impute(glrm): the m x n matrix of imputed values (Bool columns as 1.0 / 0.0)."
-function hip_impute(glrm::GLRM; device_id::Int=-1)
-    desc = descriptors(glrm)
-    desc === nothing && return LowRankModels.impute(glrm)
-    m, n = size(glrm.A); Ahat = Matrix{Float64}(undef, m, n)
-    doms = CDomain[cdomain(l.domain) for l in glrm.losses]
-    with_handle(glrm, desc, device_id) do h
-        check(ccall((:glrm_hip_impute, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{CDomain}, Ptr{Float64}),
-                    h, Matrix{Float64}(glrm.X), glrm.Y, doms, Ahat))
-    end
-    Ahat
-end
-
-# Train / test split of a fold on the device: `tags` labels the entries of observed_features in flatten_observations order,
-# `ctags` the entries of observed_examples; see cross_validate in lowrankmodels.jl_amd/crossval.py for the complete driver.
-function hip_subset(parent::Ptr{Cvoid}, tags::Vector{UInt8}, ctags::Vector{UInt8}, fold::Integer; invert::Bool)
-    child = Ref{Ptr{Cvoid}}(C_NULL)
-    check(ccall((:glrm_hip_subset, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{UInt8}, Int32, Int32, Ref{Ptr{Cvoid}}),
-                parent, tags, ctags, fold, invert ? 1 : 0, child))
-    child[]
+    desc === nothing && return nothing
+    p = HipProxGradParams(device_id=device_id, dense=false)      # list handle: init_svd / impute / subset work on the Omega views
+    Some(f(handle(glrm, desc, p)))
 end
 
 end # module

@@ -71,6 +71,10 @@ class COptions(C.Structure):
                 ("stream", C.c_void_p), ("caller_stream", C.c_int32), ("tiled", C.c_int32)]
 
 
+class CMultiOptions(C.Structure):
+    _fields_ = [("n_shards", C.c_int32), ("exchange", C.c_int32), ("device_ids", C.c_void_p), ("x_chunks", C.c_int32), ("reserved", C.c_int32)]
+
+
 class CKernelStats(C.Structure):
     _fields_ = [
         ("launches_x", C.c_int64), ("launches_y", C.c_int64), ("ms_x", C.c_double), ("ms_y", C.c_double),
@@ -89,6 +93,7 @@ ABI_SYMBOLS = (
     "version", "last_error", "create", "destroy", "fit", "fit_sparse", "objective", "factor_ld", "bind_buffers",
     "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "gradstep_x", "gradstep_y", "col_losses", "row_penalties",
     "col_penalties", "set_regularizers", "subset", "init_svd", "error_metric", "impute", "sum", "synchronize", "kernel_stats",
+    "multi_create", "multi_fit", "multi_set_regularizers", "multi_info", "multi_destroy",
 )
 
 
@@ -165,6 +170,12 @@ class Api:
             "sum": (C.c_int, [H, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
             "synchronize": (C.c_int, [H]),
             "kernel_stats": (C.c_int, [H, C.POINTER(CKernelStats), C.c_int]),
+            "multi_create": (C.c_int, [C.POINTER(H), C.POINTER(CProblem), C.POINTER(COptions), C.POINTER(CMultiOptions)]),
+            "multi_fit": (C.c_int, [H, C.POINTER(CParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                    C.POINTER(C.c_int64)]),
+            "multi_set_regularizers": (C.c_int, [H, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
+            "multi_info": (C.c_int, [H, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+            "multi_destroy": (None, [H]),
         }
         self._f = {}
         for name, (res, args) in sig.items():
@@ -185,10 +196,8 @@ class Api:
             raise GLRMError(rc, self.last_error())
 
     # -- lifecycle --------------------------------------------------------------------
-    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=None, tiled=0):
-        """``stream=None``: the handle creates a private stream.  ``stream=<int>``: launch on exactly that
-        hipStream_t -- 0 is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns
-        for the default stream), so kernels stay ordered with the caller's other work on it."""
+    @staticmethod
+    def _cproblem(prob):
         p = CProblem()
         p.m, p.n, p.k, p.flags = prob.m, prob.n, prob.k, prob.flags
         p.row_begin, p.row_end, p.col_begin, p.col_end = prob.row_begin, prob.row_end, prob.col_begin, prob.col_end
@@ -198,13 +207,59 @@ class Api:
         p.rx, p.n_rx = _ptr(prob.rx), len(prob.rx)
         p.ry, p.n_ry = _ptr(prob.ry), len(prob.ry)
         if prob.dense_A is not None:
-            if not self.dense_ok:
-                raise GLRMError(ERR_UNSUPPORTED, "this engine takes observation lists only")
             p.dense_A, p.dense_ld, p.dense_colmajor, p.dense_reserved = _ptr(prob.dense_A), prob.dense_ld, prob.dense_colmajor, 0
+        return p
+
+    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=None, tiled=0):
+        """``stream=None``: the handle creates a private stream.  ``stream=<int>``: launch on exactly that
+        hipStream_t -- 0 is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns
+        for the default stream), so kernels stay ordered with the caller's other work on it."""
+        if prob.dense_A is not None and not self.dense_ok:
+            raise GLRMError(ERR_UNSUPPORTED, "this engine takes observation lists only")
+        p = self._cproblem(prob)
         o = COptions(device_id, profile, waves_row, waves_col, (stream or None), 0 if stream is None else 1, tiled)
         h = C.c_void_p()
         self._ck(self._f["create"](C.byref(h), C.byref(p), C.byref(o)))
         return h
+
+    # -- one process, several devices (glrm_*_multi_*) -----------------------------------------
+    def multi_create(self, prob: "ProblemArrays", n_shards, device_ids=None, exchange=0, x_chunks=0, profile=0, waves_row=0,
+                     waves_col=0, tiled=0):
+        """The whole problem (host arrays), sharded by the library over ``device_ids`` (default 0..n_shards-1; ids may repeat)."""
+        if prob.dense_A is not None and not self.dense_ok:
+            raise GLRMError(ERR_UNSUPPORTED, "this engine takes observation lists only")
+        p = self._cproblem(prob)
+        o = COptions(-1, profile, waves_row, waves_col, None, 0, tiled)
+        ids = None if device_ids is None else np.ascontiguousarray(device_ids, dtype=np.int32)
+        if ids is not None and len(ids) != n_shards:
+            raise ValueError("device_ids must have n_shards entries")
+        mo = CMultiOptions(int(n_shards), int(exchange), _ptr(ids), int(x_chunks), 0)
+        h = C.c_void_p()
+        self._ck(self._f["multi_create"](C.byref(h), C.byref(p), C.byref(o), C.byref(mo)))
+        return h
+
+    def multi_fit(self, mh, params, X, Y):
+        cap = int(params.max_iter) + 1
+        obj, sec = np.zeros(cap), np.zeros(cap)
+        nrec = C.c_int64(0)
+        cp = CParams(params.stepsize, params.max_iter, params.inner_iter_X, params.inner_iter_Y, params.abs_tol,
+                     params.rel_tol, params.min_stepsize)
+        self._ck(self._f["multi_fit"](mh, C.byref(cp), _ptr(X), _ptr(Y), _ptr(obj), _ptr(sec), cap, C.byref(nrec)))
+        return obj[: nrec.value].copy(), sec[: nrec.value].copy()
+
+    def multi_set_regularizers(self, mh, rx, ry):
+        self._ck(self._f["multi_set_regularizers"](mh, _ptr(rx), len(rx), _ptr(ry), len(ry)))
+
+    def multi_info(self, mh, n_shards):
+        rb, cb = np.zeros(n_shards + 1, np.int64), np.zeros(n_shards + 1, np.int64)
+        ex, ms = C.c_int32(0), C.c_double(0.0)
+        self._ck(self._f["multi_info"](mh, _ptr(rb), _ptr(cb), C.byref(ex), C.byref(ms)))
+        return {"row_bounds": rb.tolist(), "col_bounds": cb.tolist(), "exchange": ex.value, "exchange_ms": ms.value}
+
+    def multi_destroy(self, mh):
+        if mh is not None and mh.value:
+            self._f["multi_destroy"](mh)
+            mh.value = None
 
     def destroy(self, h):
         if h is not None and h.value:

@@ -1,0 +1,497 @@
+// glrm_multigpu.hip -- glrm_hip_multi_*: fit!(glrm, ProxGradParams) on N devices driven by ONE host process.
+//
+// The reference parallelises the half-steps over threads of one address space ("rows independent, then columns independent",
+// src/algorithms/proxgrad_multithread.jl:118,163).  Here shard s = a contiguous block of rows + a contiguous block of columns on
+// device_ids[s]; X and Y are replicated on every device; after the X half-step each device pushes the row block it updated to
+// every peer, after the Y half-step its column block.  This is the entry point a single Julia process can
+// ccall; the one-process-per-GPU host (lowrankmodels.jl_amd/fit.py::ShardedFit over torch.distributed / RCCL) drives the same
+// step-level calls.
+//
+// Exchange algorithms
+//   direct (default)  hipMemcpyPeerAsync of the 1/N slice from its owner to every peer, one copy stream per (source, destination)
+//                     pair: xGMI is point-to-point (7 links per GPU), so all links of a GPU carry one slice at once and the
+//                     exchange takes slice_bytes / link_bandwidth instead of the (N-1) hops of a ring.
+//   rccl              ncclAllGather in place (equal blocks) or one ncclBroadcast per owner (ragged blocks) inside one group;
+//                     librccl.so is loaded at run time, needs distinct devices.
+// Each shard's step_* call is issued from its own host thread: the LDS-tiled column sweep reads back an active count per
+// line-search round, and those round trips must not serialise across devices.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "glrm_engine.hpp"
+
+namespace {
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- RCCL, resolved at run time ---------------------------------------------------------------------------------------
+struct Rccl {
+  typedef void* comm_t;
+  int (*CommInitAll)(comm_t*, int, const int*) = nullptr;
+  int (*CommDestroy)(comm_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, comm_t, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, comm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+  Rccl() {
+    void* lib = dlopen("librccl.so", RTLD_LAZY | RTLD_LOCAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_LAZY | RTLD_LOCAL);
+    if (!lib) return;
+    CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+    Broadcast = (decltype(Broadcast))dlsym(lib, "ncclBroadcast");
+    GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+    GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    ok = CommInitAll && CommDestroy && AllGather && Broadcast && GroupStart && GroupEnd;
+  }
+  static Rccl& get() { static Rccl r; return r; }
+};
+constexpr int NCCL_FLOAT64 = 8; // ncclFloat64 (rccl.h)
+
+} // namespace
+
+struct glrm_multi {
+  int n = 0;
+  int64_t m = 0, nn = 0, d = 0;
+  int k = 0, ld = 0;
+  std::vector<int> dev;
+  std::vector<glrm_handle*> sh;
+  std::vector<hipStream_t> st;                       // compute stream of shard s (device dev[s])
+  std::vector<double*> dX, dY, dObjCol, dObjRow;     // replica of shard s
+  std::vector<std::vector<hipStream_t>> cs;          // cs[s][t]: copy stream on dev[s] for pushes s -> t
+  std::vector<hipEvent_t> ev_done;                   // sweep of shard s finished (timing enabled: start of its exchange wait)
+  std::vector<hipEvent_t> ev_ready;                  // every incoming block of shard s has arrived
+  std::vector<std::vector<hipEvent_t>> ev_arr;       // ev_arr[s][t]: block of s landed on t
+  std::vector<int64_t> rbs, cbs, ybs;                // shard bounds: rows, columns, vectors of Y
+  int exchange = 0;                                  // in use: 0 direct, 1 rccl
+  std::vector<Rccl::comm_t> comms;
+  int x_chunks = 1;
+  bool dense = false;
+  bool profile = false;                              // glrm_options.profile: account the exposed exchange time of every exchange
+  double exchange_ms = 0.0;
+  int64_t n_rx = 0, n_ry = 0;
+};
+
+namespace {
+
+// Contiguous blocks balanced by observation count; equal-count blocks when they are within 2 % of that balance
+// (lowrankmodels.jl_amd/fit.py::partition -- the two hosts shard alike).
+std::vector<int64_t> partition(const int64_t* ptr, int64_t nseg, int parts) {
+  std::vector<int64_t> eq((size_t)parts + 1);
+  for (int i = 0; i <= parts; ++i) eq[i] = nseg * i / parts;
+  if (!ptr) return eq;
+  const int64_t nnz = ptr[nseg];
+  if (nnz <= 0) return eq;
+  if (nseg % parts == 0) {
+    int64_t worst = 0;
+    for (int i = 0; i < parts; ++i) worst = std::max(worst, ptr[eq[i + 1]] - ptr[eq[i]]);
+    if ((double)worst <= 1.02 * (double)nnz / parts + 1) return eq;
+  }
+  std::vector<int64_t> b((size_t)parts + 1);
+  for (int i = 0; i <= parts; ++i) {
+    const double target = (double)nnz * i / parts;
+    b[i] = std::lower_bound(ptr, ptr + nseg + 1, target, [](int64_t v, double t) { return (double)v < t; }) - ptr;
+  }
+  b[0] = 0;
+  b[parts] = nseg;
+  for (int i = 1; i <= parts; ++i) b[i] = std::max(b[i], b[i - 1]);
+  return b;
+}
+
+// fn(s) for every shard, each on its own host thread (shard 0 on the caller's); first failure wins.
+int run_all(glrm_multi* mh, const std::function<int(int)>& fn) {
+  const int n = mh->n;
+  std::vector<int> rc((size_t)n, 0);
+  std::vector<std::string> msg((size_t)n);
+  auto body = [&](int s) {
+    rc[s] = fn(s);
+    if (rc[s]) msg[s] = g_err; // thread-local message of the failing call
+  };
+  std::vector<std::thread> th;
+  for (int s = 1; s < n; ++s) th.emplace_back(body, s);
+  body(0);
+  for (auto& t : th) t.join();
+  for (int s = 0; s < n; ++s)
+    if (rc[s]) return fail(rc[s], "shard %d (device %d): %s", s, mh->dev[s], msg[s].c_str());
+  return GLRM_OK;
+}
+
+#define COMMCK(expr)                                                                                            \
+  do {                                                                                                          \
+    hipError_t e_ = (expr);                                                                                     \
+    if (e_ != hipSuccess) return fail(GLRM_ERR_COMM, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// Shard s owns buf[bounds[s]*unit .. bounds[s+1]*unit) (doubles) restricted to the sub-range [lo_s, hi_s) of its block given by
+// `sub` (fractions j/C of the block for the pipelined X exchange; 0/1 = the whole block).  Phase 1 (push): after the work already
+// queued on st[s], push that range to every destination.  Phase 2 (wait): st[t] waits for everything pushed to t so far.
+int exchange_push(glrm_multi* mh, std::vector<double*>& buf, const std::vector<int64_t>& bounds, int64_t unit, int only_dst, int cj,
+                  int cn) {
+  const int n = mh->n;
+  if (n == 1) return GLRM_OK;
+  for (int s = 0; s < n; ++s) {
+    COMMCK(hipSetDevice(mh->dev[s]));
+    COMMCK(hipEventRecord(mh->ev_done[s], mh->st[s]));
+  }
+  if (mh->exchange == 1) { // RCCL: one grouped collective over all communicators (always to every rank; x_chunks is off here)
+    Rccl& R = Rccl::get();
+    bool equal = true;
+    for (int s = 1; s < n; ++s) equal = equal && (bounds[s + 1] - bounds[s] == bounds[1] - bounds[0]);
+    int rc = R.GroupStart();
+    for (int s = 0; s < n && !rc; ++s) {
+      if (equal) {
+        const size_t cnt = (size_t)((bounds[1] - bounds[0]) * unit);
+        if (cnt) rc = R.AllGather(buf[s] + bounds[s] * unit, buf[s], cnt, NCCL_FLOAT64, mh->comms[s], mh->st[s]);
+      } else {
+        for (int r = 0; r < n && !rc; ++r) {
+          const size_t cnt = (size_t)((bounds[r + 1] - bounds[r]) * unit);
+          if (cnt) rc = R.Broadcast(buf[s] + bounds[r] * unit, buf[s] + bounds[r] * unit, cnt, NCCL_FLOAT64, r, mh->comms[s], mh->st[s]);
+        }
+      }
+    }
+    const int rc2 = R.GroupEnd();
+    if (rc || rc2) return fail(GLRM_ERR_COMM, "RCCL exchange failed: %s", R.GetErrorString ? R.GetErrorString(rc ? rc : rc2) : "?");
+    return GLRM_OK;
+  }
+  for (int s = 0; s < n; ++s) {
+    const int64_t blk = bounds[s + 1] - bounds[s];
+    const int64_t lo = bounds[s] + blk * cj / cn, hi = bounds[s] + blk * (cj + 1) / cn;
+    const size_t bytes = (size_t)((hi - lo) * unit) * 8;
+    COMMCK(hipSetDevice(mh->dev[s]));
+    for (int t = 0; t < n; ++t) {
+      if (t == s || (only_dst >= 0 && t != only_dst)) continue;
+      hipStream_t c = mh->cs[s][t];
+      COMMCK(hipStreamWaitEvent(c, mh->ev_done[s], 0));
+      if (bytes) {
+        if (mh->dev[s] == mh->dev[t]) COMMCK(hipMemcpyAsync(buf[t] + lo * unit, buf[s] + lo * unit, bytes, hipMemcpyDeviceToDevice, c));
+        else COMMCK(hipMemcpyPeerAsync(buf[t] + lo * unit, mh->dev[t], buf[s] + lo * unit, mh->dev[s], bytes, c));
+      }
+      COMMCK(hipEventRecord(mh->ev_arr[s][t], c));
+    }
+  }
+  return GLRM_OK;
+}
+
+int exchange_wait(glrm_multi* mh, int only_dst) {
+  const int n = mh->n;
+  if (n == 1 || mh->exchange == 1) return GLRM_OK; // RCCL collectives are ordered on the compute streams themselves
+  for (int t = 0; t < n; ++t) {
+    if (only_dst >= 0 && t != only_dst) continue;
+    COMMCK(hipSetDevice(mh->dev[t]));
+    for (int s = 0; s < n; ++s)
+      if (s != t) COMMCK(hipStreamWaitEvent(mh->st[t], mh->ev_arr[s][t], 0));
+    COMMCK(hipEventRecord(mh->ev_ready[t], mh->st[t]));
+  }
+  return GLRM_OK;
+}
+
+int exchange_all(glrm_multi* mh, std::vector<double*>& buf, const std::vector<int64_t>& bounds, int64_t unit, int only_dst = -1) {
+  int rc = exchange_push(mh, buf, bounds, unit, only_dst, 0, 1);
+  if (rc) return rc;
+  return exchange_wait(mh, only_dst);
+}
+
+// Exposed exchange time: what the compute stream of a shard spent between the end of its own (last) sweep and the arrival of the
+// last incoming block, max over shards.  Needs every stream drained, so it is only accounted with glrm_options.profile.
+void account_exchange(glrm_multi* mh) {
+  if (mh->n == 1 || mh->exchange == 1 || !mh->profile) return;
+  for (int t = 0; t < mh->n; ++t)
+    if (hipSetDevice(mh->dev[t]) != hipSuccess || hipStreamSynchronize(mh->st[t]) != hipSuccess) { (void)hipGetLastError(); return; }
+  float worst = 0.f;
+  for (int t = 0; t < mh->n; ++t) {
+    float ms = 0.f;
+    if (hipSetDevice(mh->dev[t]) == hipSuccess && hipEventElapsedTime(&ms, mh->ev_done[t], mh->ev_ready[t]) == hipSuccess) worst = std::max(worst, ms);
+    else (void)hipGetLastError();
+  }
+  mh->exchange_ms += worst;
+}
+
+int sum_on_shard0(glrm_multi* mh, double* vec, int64_t cnt, double* out) { return glrm_hip_sum(mh->sh[0], vec, cnt, out); }
+
+// loss + rx + ry at the replicated factors (objective(...), src/evaluate_fit.jl:4-23,91-104), fixed-order sums on shard 0
+int multi_objective(glrm_multi* mh, double* out) {
+  int rc;
+  double loss = 0, px = 0, py = 0;
+  if ((rc = run_all(mh, [&](int s) { return glrm_hip_col_losses(mh->sh[s]); }))) return rc;
+  if ((rc = exchange_all(mh, mh->dObjCol, mh->cbs, 1, 0))) return rc;
+  if ((rc = sum_on_shard0(mh, mh->dObjCol[0], mh->nn, &loss))) return rc;
+  if ((rc = run_all(mh, [&](int s) { return glrm_hip_row_penalties(mh->sh[s]); }))) return rc;
+  if ((rc = exchange_all(mh, mh->dObjRow, mh->rbs, 1, 0))) return rc;
+  if ((rc = sum_on_shard0(mh, mh->dObjRow[0], mh->m, &px))) return rc;
+  if ((rc = run_all(mh, [&](int s) { return glrm_hip_col_penalties(mh->sh[s]); }))) return rc;
+  if ((rc = exchange_all(mh, mh->dObjCol, mh->cbs, 1, 0))) return rc;
+  if ((rc = sum_on_shard0(mh, mh->dObjCol[0], mh->nn, &py))) return rc;
+  *out = loss + (px + py);
+  return GLRM_OK;
+}
+
+} // namespace
+
+extern "C" void glrm_hip_multi_destroy(glrm_multi* mh) {
+  if (!mh) return;
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  for (int s = 0; s < (int)mh->sh.size(); ++s) {
+    if (mh->sh[s]) glrm_hip_destroy(mh->sh[s]);
+  }
+  for (int s = 0; s < mh->n && s < (int)mh->dev.size(); ++s) {
+    if (hipSetDevice(mh->dev[s]) != hipSuccess) continue;
+    if (s < (int)mh->comms.size() && mh->comms[s]) (void)Rccl::get().CommDestroy(mh->comms[s]);
+    for (double* p : {s < (int)mh->dX.size() ? mh->dX[s] : nullptr, s < (int)mh->dY.size() ? mh->dY[s] : nullptr,
+                      s < (int)mh->dObjCol.size() ? mh->dObjCol[s] : nullptr, s < (int)mh->dObjRow.size() ? mh->dObjRow[s] : nullptr})
+      if (p) (void)hipFree(p);
+    if (s < (int)mh->cs.size())
+      for (hipStream_t c : mh->cs[s])
+        if (c) (void)hipStreamDestroy(c);
+    if (s < (int)mh->ev_arr.size())
+      for (hipEvent_t e : mh->ev_arr[s])
+        if (e) (void)hipEventDestroy(e);
+    if (s < (int)mh->ev_done.size() && mh->ev_done[s]) (void)hipEventDestroy(mh->ev_done[s]);
+    if (s < (int)mh->ev_ready.size() && mh->ev_ready[s]) (void)hipEventDestroy(mh->ev_ready[s]);
+    if (s < (int)mh->st.size() && mh->st[s]) (void)hipStreamDestroy(mh->st[s]);
+  }
+  (void)hipSetDevice(prev);
+  delete mh;
+}
+
+static int multi_create_impl(glrm_multi* mh, const glrm_problem* p, const glrm_options* o, const glrm_multi_options* mo) {
+  const int n = mh->n;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GLRM_ERR_HIP, "no HIP device is visible (this engine has no CPU fallback)");
+  mh->dev.resize(n);
+  bool distinct = true;
+  for (int s = 0; s < n; ++s) {
+    mh->dev[s] = mo->device_ids ? mo->device_ids[s] : s;
+    if (mh->dev[s] < 0 || mh->dev[s] >= ndev) return fail(GLRM_ERR_INVALID, "device_ids[%d] = %d out of range (%d devices)", s, mh->dev[s], ndev);
+    for (int t = 0; t < s; ++t) distinct = distinct && mh->dev[t] != mh->dev[s];
+  }
+  mh->m = p->m; mh->nn = p->n; mh->k = p->k;
+  mh->dense = p->dense_A != nullptr;
+  mh->profile = o && o->profile;
+  mh->rbs = partition(mh->dense ? nullptr : p->rowptr, p->m, n);
+  mh->cbs = partition(mh->dense ? nullptr : p->colptr, p->n, n);
+  // vectors of Y owned by each column (get_yidxs, src/losses.jl:76-93)
+  std::vector<int64_t> ystart((size_t)p->n + 1, 0);
+  for (int64_t f = 0; f < p->n; ++f) {
+    const glrm_loss& l = p->n_losses == 1 ? p->losses[0] : p->losses[f];
+    ystart[f + 1] = ystart[f] + (l.dim > 1 ? l.dim : 1);
+  }
+  mh->d = ystart[p->n];
+  mh->ybs.resize((size_t)n + 1);
+  for (int s = 0; s <= n; ++s) mh->ybs[s] = ystart[mh->cbs[s]];
+  mh->n_rx = p->n_rx; mh->n_ry = p->n_ry;
+  mh->sh.assign(n, nullptr); mh->st.assign(n, nullptr);
+  mh->dX.assign(n, nullptr); mh->dY.assign(n, nullptr); mh->dObjCol.assign(n, nullptr); mh->dObjRow.assign(n, nullptr);
+  mh->ev_done.assign(n, nullptr); mh->ev_ready.assign(n, nullptr);
+  mh->cs.assign(n, std::vector<hipStream_t>(n, nullptr));
+  mh->ev_arr.assign(n, std::vector<hipEvent_t>(n, nullptr));
+  for (int s = 0; s < n; ++s) { // peer access (a no-op for shards that share a device)
+    HIPCK(hipSetDevice(mh->dev[s]));
+    for (int t = 0; t < n; ++t) {
+      if (mh->dev[t] == mh->dev[s]) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, mh->dev[s], mh->dev[t]) == hipSuccess && can) {
+        const hipError_t e = hipDeviceEnablePeerAccess(mh->dev[t], 0);
+        if (e != hipSuccess) (void)hipGetLastError(); // already enabled is fine; hipMemcpyPeerAsync stages through the host otherwise
+      }
+    }
+    HIPCK(hipStreamCreateWithFlags(&mh->st[s], hipStreamNonBlocking));
+    HIPCK(hipEventCreate(&mh->ev_done[s]));
+    HIPCK(hipEventCreate(&mh->ev_ready[s]));
+    for (int t = 0; t < n; ++t) {
+      if (t == s) continue;
+      HIPCK(hipStreamCreateWithFlags(&mh->cs[s][t], hipStreamNonBlocking));
+      HIPCK(hipEventCreateWithFlags(&mh->ev_arr[s][t], hipEventDisableTiming));
+    }
+  }
+  // shard handles, created concurrently (each uploads its own slices)
+  std::vector<std::vector<int64_t>> rp((size_t)n), cp((size_t)n);
+  int rc = run_all(mh, [&](int s) -> int {
+    glrm_problem q = *p;
+    q.row_begin = mh->rbs[s]; q.row_end = mh->rbs[s + 1];
+    q.col_begin = mh->cbs[s]; q.col_end = mh->cbs[s + 1];
+    if (!mh->dense) {
+      const int64_t r0 = p->rowptr[q.row_begin], c0 = p->colptr[q.col_begin];
+      rp[s].resize((size_t)(q.row_end - q.row_begin) + 1);
+      cp[s].resize((size_t)(q.col_end - q.col_begin) + 1);
+      for (size_t i = 0; i < rp[s].size(); ++i) rp[s][i] = p->rowptr[q.row_begin + (int64_t)i] - r0;
+      for (size_t i = 0; i < cp[s].size(); ++i) cp[s][i] = p->colptr[q.col_begin + (int64_t)i] - c0;
+      q.rowptr = rp[s].data(); q.colidx = p->colidx ? p->colidx + r0 : nullptr; q.rowvals = p->rowvals ? p->rowvals + r0 : nullptr;
+      q.colptr = cp[s].data(); q.rowidx = p->rowidx ? p->rowidx + c0 : nullptr; q.colvals = p->colvals ? p->colvals + c0 : nullptr;
+    }
+    if (p->n_rx != 1) { q.rx = p->rx + q.row_begin; q.n_rx = q.row_end - q.row_begin; }
+    if (p->n_ry != 1) { q.ry = p->ry + q.col_begin; q.n_ry = q.col_end - q.col_begin; }
+    glrm_options oo{};
+    if (o) oo = *o;
+    oo.device_id = mh->dev[s];
+    oo.stream = (void*)mh->st[s];
+    oo.caller_stream = 1;
+    return glrm_hip_create(&mh->sh[s], &q, &oo);
+  });
+  if (rc) return rc;
+  mh->ld = glrm_hip_factor_ld(mh->sh[0]);
+  for (int s = 0; s < n; ++s) {
+    HIPCK(hipSetDevice(mh->dev[s]));
+    const size_t xb = (size_t)mh->ld * mh->m * 8, yb = (size_t)mh->ld * mh->d * 8;
+    HIPCK(hipMalloc((void**)&mh->dX[s], xb));
+    HIPCK(hipMalloc((void**)&mh->dY[s], yb));
+    HIPCK(hipMalloc((void**)&mh->dObjCol[s], (size_t)mh->nn * 8));
+    HIPCK(hipMalloc((void**)&mh->dObjRow[s], (size_t)mh->m * 8));
+    HIPCK(hipMemsetAsync(mh->dX[s], 0, xb, mh->st[s]));
+    HIPCK(hipMemsetAsync(mh->dY[s], 0, yb, mh->st[s]));
+    HIPCK(hipMemsetAsync(mh->dObjCol[s], 0, (size_t)mh->nn * 8, mh->st[s]));
+    HIPCK(hipMemsetAsync(mh->dObjRow[s], 0, (size_t)mh->m * 8, mh->st[s]));
+    if ((rc = glrm_hip_bind_buffers(mh->sh[s], mh->dX[s], mh->dY[s], mh->dObjCol[s], mh->dObjRow[s]))) return rc;
+  }
+  mh->exchange = 0;
+  const int want = env_int("GLRM_HIP_EXCHANGE_RCCL", mo->exchange);
+  if (want == 1 && n > 1) {
+    Rccl& R = Rccl::get();
+    if (R.ok && distinct) {
+      mh->comms.assign(n, nullptr);
+      const int e = R.CommInitAll(mh->comms.data(), n, mh->dev.data());
+      if (e) return fail(GLRM_ERR_COMM, "ncclCommInitAll failed: %s", R.GetErrorString ? R.GetErrorString(e) : "?");
+      mh->exchange = 1;
+    } // else: direct path (shards sharing a device, or no librccl.so)
+  }
+  mh->x_chunks = (mo->x_chunks >= 2 && n > 1 && !mh->dense && mh->exchange == 0) ? mo->x_chunks : 1;
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_multi_create(glrm_multi** out, const glrm_problem* p, const glrm_options* o, const glrm_multi_options* mo) {
+  if (!out || !p || !mo) return fail(GLRM_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (mo->n_shards < 1 || mo->n_shards > 64) return fail(GLRM_ERR_INVALID, "n_shards must be in 1..64");
+  if (mo->reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_multi_options.reserved must be 0");
+  if (p->flags & GLRM_PROBLEM_DEVICE_ARRAYS) return fail(GLRM_ERR_UNSUPPORTED, "glrm_hip_multi_create takes host arrays (it slices them per device)");
+  if (p->m <= 0 || p->n <= 0 || p->k <= 0) return fail(GLRM_ERR_INVALID, "m, n, k must be positive");
+  if (!(p->row_begin == 0 && p->row_end == p->m && p->col_begin == 0 && p->col_end == p->n))
+    return fail(GLRM_ERR_INVALID, "glrm_hip_multi_create takes the whole problem (row/col ranges [0,m) x [0,n)); it shards it itself");
+  if (!p->dense_A && (!p->rowptr || !p->colptr)) return fail(GLRM_ERR_INVALID, "rowptr / colptr are NULL");
+  if (!p->losses || !(p->n_losses == 1 || p->n_losses == p->n) || !p->rx || !(p->n_rx == 1 || p->n_rx == p->m) || !p->ry ||
+      !(p->n_ry == 1 || p->n_ry == p->n))
+    return fail(GLRM_ERR_INVALID, "descriptor counts must be 1 or one per column / row");
+  if (!p->dense_A) {
+    if (p->rowptr[0] != 0 || p->colptr[0] != 0) return fail(GLRM_ERR_INVALID, "rowptr[0] / colptr[0] must be 0");
+    for (int64_t s = 0; s < p->m; ++s) if (p->rowptr[s + 1] < p->rowptr[s]) return fail(GLRM_ERR_INVALID, "rowptr is not monotone at %lld", (long long)s);
+    for (int64_t s = 0; s < p->n; ++s) if (p->colptr[s + 1] < p->colptr[s]) return fail(GLRM_ERR_INVALID, "colptr is not monotone at %lld", (long long)s);
+  }
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  glrm_multi* mh = new (std::nothrow) glrm_multi();
+  if (!mh) return fail(GLRM_ERR_OOM, "out of host memory");
+  mh->n = mo->n_shards;
+  const int rc = multi_create_impl(mh, p, o, mo);
+  if (rc) {
+    char keep[sizeof g_err];
+    memcpy(keep, g_err, sizeof keep);
+    glrm_hip_multi_destroy(mh);
+    memcpy(g_err, keep, sizeof keep);
+    (void)hipSetDevice(prev);
+    return rc;
+  }
+  (void)hipSetDevice(prev);
+  *out = mh;
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_multi_set_regularizers(glrm_multi* mh, const glrm_reg* rx, int64_t n_rx, const glrm_reg* ry, int64_t n_ry) {
+  if (!mh || !rx || !ry) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (n_rx != mh->n_rx || n_ry != mh->n_ry) return fail(GLRM_ERR_INVALID, "regularizer counts must match the create call");
+  for (int s = 0; s < mh->n; ++s) {
+    const glrm_reg* sx = n_rx == 1 ? rx : rx + mh->rbs[s];
+    const glrm_reg* sy = n_ry == 1 ? ry : ry + mh->cbs[s];
+    const int rc = glrm_hip_set_regularizers(mh->sh[s], sx, n_rx == 1 ? 1 : mh->rbs[s + 1] - mh->rbs[s], sy, n_ry == 1 ? 1 : mh->cbs[s + 1] - mh->cbs[s]);
+    if (rc) return rc;
+  }
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_multi_info(glrm_multi* mh, int64_t* row_bounds, int64_t* col_bounds, int32_t* exchange_used, double* exchange_ms) {
+  if (!mh) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (row_bounds) memcpy(row_bounds, mh->rbs.data(), ((size_t)mh->n + 1) * 8);
+  if (col_bounds) memcpy(col_bounds, mh->cbs.data(), ((size_t)mh->n + 1) * 8);
+  if (exchange_used) *exchange_used = mh->exchange;
+  if (exchange_ms) *exchange_ms = mh->exchange_ms;
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_multi_fit(glrm_multi* mh, const glrm_params* prm, double* X, double* Y, double* objective, double* seconds,
+                                  int64_t cap, int64_t* n_recorded) {
+  if (!mh || !prm || !X || !Y || !objective || !seconds || !n_recorded) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (prm->max_iter < 0 || cap < prm->max_iter + 1) return fail(GLRM_ERR_INVALID, "objective/seconds capacity must be >= max_iter+1");
+  if (prm->inner_iter_X < 1 || prm->inner_iter_Y < 1) return fail(GLRM_ERR_INVALID, "inner iteration counts must be >= 1");
+  double ynorm = 0.0; // norm(Y)==0 guard, proxgrad.jl:45-48
+  for (int64_t i = 0; i < (int64_t)mh->k * mh->d; ++i) ynorm += Y[i] * Y[i];
+  if (ynorm == 0.0) return fail(GLRM_ERR_INVALID, "Y is all zeros (the reference cannot start from Y == 0)");
+  int prev = 0;
+  (void)hipGetDevice(&prev);
+  struct Restore { int d; ~Restore() { (void)hipSetDevice(d); } } restore{prev};
+  int rc;
+  mh->exchange_ms = 0.0;
+  if ((rc = run_all(mh, [&](int s) {                                    // X = glrm.X; Y = glrm.Y (:43), alpharow / alphacol (:69-70)
+         int r = glrm_hip_set_factors(mh->sh[s], X, Y);
+         return r ? r : glrm_hip_reset_stepsizes(mh->sh[s], prm->stepsize);
+       })))
+    return rc;
+  int64_t nnz_rows = 0;
+  for (int s = 0; s < mh->n; ++s) nnz_rows += mh->sh[s]->nnz_r;
+  const double scaled_abs_tol = prm->abs_tol * (double)nnz_rows;       // :72
+  if ((rc = multi_objective(mh, &objective[0]))) return rc;           // :76
+  seconds[0] = 0.0;
+  int64_t nrec = 1;
+  double t = now_s();
+  for (int64_t i = 1; i <= prm->max_iter; ++i) {                       // :107
+    if (prm->inner_iter_X > 1 || prm->inner_iter_Y > 1)
+      if ((rc = run_all(mh, [&](int s) { return glrm_hip_reset_stepsizes(mh->sh[s], prm->stepsize); }))) return rc; // :112-115
+    for (int64_t in = 0; in + 1 < prm->inner_iter_X; ++in)              // inner sweeps touch own rows only: exchange once
+      if ((rc = run_all(mh, [&](int s) { return glrm_hip_step_x(mh->sh[s], prm->min_stepsize); }))) return rc;
+    if (mh->x_chunks > 1) { // last inner sweep in row chunks: the push of chunk j overlaps the sweep of chunk j+1
+      for (int j = 0; j < mh->x_chunks; ++j) {
+        if ((rc = run_all(mh, [&](int s) {
+               const int64_t ml = mh->rbs[s + 1] - mh->rbs[s];
+               return glrm_hip_step_x_range(mh->sh[s], ml * j / mh->x_chunks, ml * (j + 1) / mh->x_chunks, prm->min_stepsize);
+             })))
+          return rc;
+        if ((rc = exchange_push(mh, mh->dX, mh->rbs, mh->ld, -1, j, mh->x_chunks))) return rc;
+      }
+      if ((rc = exchange_wait(mh, -1))) return rc;
+      account_exchange(mh);
+    } else {
+      if ((rc = run_all(mh, [&](int s) { return glrm_hip_step_x(mh->sh[s], prm->min_stepsize); }))) return rc; // :117-158
+      if ((rc = exchange_all(mh, mh->dX, mh->rbs, mh->ld))) return rc;
+      account_exchange(mh);
+    }
+    for (int64_t in = 0; in < prm->inner_iter_Y; ++in)
+      if ((rc = run_all(mh, [&](int s) { return glrm_hip_step_y(mh->sh[s], prm->min_stepsize); }))) return rc; // :160-203
+    if ((rc = exchange_all(mh, mh->dY, mh->ybs, mh->ld))) return rc;
+    account_exchange(mh);
+    if ((rc = exchange_all(mh, mh->dObjCol, mh->cbs, 1, mh->exchange == 1 ? -1 : 0))) return rc;
+    double obj = 0.0;
+    if ((rc = sum_on_shard0(mh, mh->dObjCol[0], mh->nn, &obj))) return rc; // obj = sum(obj_by_col) :205 (synchronises shard 0)
+    const double dt = now_s() - t;
+    objective[nrec] = obj;
+    seconds[nrec] = seconds[nrec - 1] + dt;                            // update_ch! (src/convergence.jl:22-26)
+    ++nrec;
+    t = now_s();
+    const double dec = objective[nrec - 2] - obj;                      // :210
+    if (i > 10 && (dec < scaled_abs_tol || dec / obj < prm->rel_tol)) break; // :211-213
+  }
+  for (int s = 0; s < mh->n; ++s)
+    if ((rc = glrm_hip_synchronize(mh->sh[s]))) return rc;
+  if ((rc = glrm_hip_get_factors(mh->sh[0], X, Y))) return rc;
+  *n_recorded = nrec;
+  return GLRM_OK;
+}

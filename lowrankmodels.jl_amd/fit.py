@@ -101,6 +101,8 @@ def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, 
 
     if np.linalg.norm(glrm.Y) == 0:
         raise ValueError("Y is all zeros (the reference cannot start from Y == 0, src/algorithms/proxgrad.jl:45-48)")
+    if getattr(params, "ngpus", 1) > 1 and not sparse:
+        return _fit_multi_in_process(glrm, params, ch, verbose, api)
     h = _ensure_handle(glrm, api, params)[0]
     X = np.asfortranarray(glrm.X, dtype=np.float64)
     Y = np.asfortranarray(glrm.Y, dtype=np.float64)
@@ -126,6 +128,48 @@ def fit_b(glrm, params=None, *, ch=None, verbose=True, engine=None, group=None, 
         update_ch(ch, sec[i] - (sec[i - 1] if i else 0.0), float(obj[i]))
         if verbose and i >= 1 and i % 10 == 0 and not _should_stop(i, obj[i - 1], obj[i], scaled_abs_tol, params.rel_tol):
             print(f"Iteration {i}: objective value = {obj[i]}")
+    return glrm.X, glrm.Y, ch
+
+
+def _record(glrm, params, ch, verbose, obj, sec):
+    scaled_abs_tol = params.abs_tol * float(glrm._rowptr[-1])
+    for i in range(len(obj)):
+        update_ch(ch, sec[i] - (sec[i - 1] if i else 0.0), float(obj[i]))
+        if verbose and i >= 1 and i % 10 == 0 and not _should_stop(i, obj[i - 1], obj[i], scaled_abs_tol, params.rel_tol):
+            print(f"Iteration {i}: objective value = {obj[i]}")
+
+
+def _fit_multi_in_process(glrm, params, ch, verbose, api):
+    """``HipProxGradParams(ngpus=N)``: one process, N devices (include/glrm_hip.h, glrm_hip_multi_*).  The multi handle is cached on
+    the model like the single-device one (Omega / A stay on the devices across warm starts; new regularizers only replace the
+    descriptors)."""
+    from .regularizers import pack_regs
+    use_dense = api.dense_ok and glrm.dense_eligible() and getattr(params, "dense", True)
+    hard, soft = glrm._descriptor_key()
+    key = (id(api), "multi", params.ngpus, tuple(params.device_ids or ()), params.exchange, params.x_chunks, hard)
+    cache = glrm._handle_cache
+    if cache is not None and (cache[2] != key or cache[4] != use_dense):
+        glrm.close()
+        cache = None
+    if cache is None:
+        o = _engine_opts(params)
+        mh = api.multi_create(glrm.problem_arrays(dense=use_dense), params.ngpus, params.device_ids, 1 if params.exchange == "rccl" else 0,
+                              params.x_chunks, profile=o["profile"], waves_row=o["waves_row"], waves_col=o["waves_col"], tiled=o["tiled"])
+        glrm._handle_cache = (api, mh, key, soft, use_dense, "multi")
+    elif cache[3] != soft:
+        api.multi_set_regularizers(cache[1], pack_regs(glrm.rx), pack_regs(glrm.ry))
+        glrm._handle_cache = cache[:3] + (soft,) + tuple(cache[4:])
+    mh = glrm._handle_cache[1]
+    X = np.asfortranarray(glrm.X, dtype=np.float64)
+    Y = np.asfortranarray(glrm.Y, dtype=np.float64)
+    if verbose:
+        print("Fitting GLRM")
+    obj, sec = api.multi_fit(mh, params, X, Y)
+    if X is not glrm.X:
+        glrm.X[...] = X
+    if Y is not glrm.Y:
+        glrm.Y[...] = Y
+    _record(glrm, params, ch, verbose, obj, sec)
     return glrm.X, glrm.Y, ch
 
 

@@ -241,7 +241,10 @@ class GLRM:
         """Release the cached engine handle (device copies of Omega)."""
         if self._handle_cache is not None:
             api, h = self._handle_cache[:2]
-            api.destroy(h)
+            if len(self._handle_cache) > 5 and self._handle_cache[5] == "multi":  # glrm_hip_multi_* handle (HipProxGradParams(ngpus=N))
+                api.multi_destroy(h)
+            else:
+                api.destroy(h)
             self._handle_cache = None
 
     def __del__(self):

@@ -30,11 +30,21 @@ class HipProxGradParams(ProxGradParams):
     ``struct HipProxGradParams <: AbstractParams`` (julia/HipGLRM.jl); `fit!(glrm, params=p)`
     dispatches on it exactly like on the built-in solvers (src/fit.jl:8-12)."""
 
-    def __init__(self, stepsize=1.0, *, device_id=-1, profile=False, waves_row=0, waves_col=0, tiled=0, dense=True, **kw):
+    def __init__(self, stepsize=1.0, *, device_id=-1, profile=False, waves_row=0, waves_col=0, tiled=0, dense=True, ngpus=1,
+                 device_ids=None, exchange="direct", x_chunks=0, **kw):
         super().__init__(stepsize, **kw)
         self.device_id, self.profile = int(device_id), bool(profile)
         self.waves_row, self.waves_col, self.tiled = int(waves_row), int(waves_col), int(tiled)
         self.dense = bool(dense)  # fully observed QuadLoss models: run the half-steps on the matrix cores
+        # ngpus > 1: ONE process drives `ngpus` devices through glrm_hip_multi_* (rows / columns sharded by the library, X and Y
+        # replicated, direct peer-copy or RCCL exchange after every half-step) -- SURVEY.md section 8(b)'s `ngpus` field.
+        self.ngpus = int(ngpus)
+        self.device_ids = None if device_ids is None else [int(d) for d in device_ids]
+        if self.device_ids is not None and len(self.device_ids) != self.ngpus:
+            raise ValueError("device_ids must list one device per shard (ngpus entries)")
+        if exchange not in ("direct", "rccl"):
+            raise ValueError("exchange must be 'direct' or 'rccl'")
+        self.exchange, self.x_chunks = exchange, int(x_chunks)
 
 
 def Params(*args, **kwargs):  # src/fit.jl:5

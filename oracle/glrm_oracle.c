@@ -1727,3 +1727,154 @@ int glrm_cpu_impute(glrm_cpu_handle* h, const double* X, const double* Y, const 
   if (bad) return fail(GLRM_ERR_UNSUPPORTED, "a column's (domain, loss) pair has no imputation rule in the reference (src/impute_and_err.jl)");
   return GLRM_OK;
 }
+
+/* ------------------------------------------------------------------ multi-shard whole fit (twin of glrm_hip_multi_*)
+ * The same row / column sharding as the multi-GPU entry points of include/glrm_hip.h, in one address space: n_shards shard handles
+ * over SHARED X, Y and per-segment objective buffers, stepped one after the other.  Because rows (then columns) are independent
+ * (src/algorithms/proxgrad_multithread.jl:118,163) the result is bit-identical to glrm_cpu_fit; the initial objective is summed
+ * per column first (like every sharded host does), everything after it is the same sum(obj_by_col). */
+typedef struct glrm_cpu_multi {
+  int n;
+  glrm_cpu_handle** sh;
+  int64_t *rbs, *cbs;
+  int64_t m, nn, d, nnz_rows, n_rx, n_ry;
+  int k;
+  double *X, *Y, *objcol, *objrow;
+} glrm_cpu_multi;
+
+static void cpu_partition(const int64_t* ptr, int64_t nseg, int parts, int64_t* b) { /* lowrankmodels.jl_amd/fit.py::partition */
+  for (int i = 0; i <= parts; ++i) b[i] = nseg * i / parts;
+  if (!ptr || ptr[nseg] <= 0) return;
+  const int64_t nnz = ptr[nseg];
+  if (nseg % parts == 0) {
+    int64_t worst = 0;
+    for (int i = 0; i < parts; ++i) if (ptr[b[i + 1]] - ptr[b[i]] > worst) worst = ptr[b[i + 1]] - ptr[b[i]];
+    if ((double)worst <= 1.02 * (double)nnz / parts + 1) return;
+  }
+  for (int i = 0; i <= parts; ++i) {
+    const double target = (double)nnz * i / parts;
+    int64_t lo = 0, hi = nseg + 1; /* first index with ptr[idx] >= target */
+    while (lo < hi) { const int64_t mid = (lo + hi) / 2; if ((double)ptr[mid] < target) lo = mid + 1; else hi = mid; }
+    b[i] = lo;
+  }
+  b[0] = 0; b[parts] = nseg;
+  for (int i = 1; i <= parts; ++i) if (b[i] < b[i - 1]) b[i] = b[i - 1];
+}
+
+void glrm_cpu_multi_destroy(glrm_cpu_multi* mh) {
+  if (!mh) return;
+  if (mh->sh) for (int s = 0; s < mh->n; ++s) glrm_cpu_destroy(mh->sh[s]);
+  free(mh->sh); free(mh->rbs); free(mh->cbs); free(mh->X); free(mh->Y); free(mh->objcol); free(mh->objrow);
+  free(mh);
+}
+
+int glrm_cpu_multi_create(glrm_cpu_multi** out, const glrm_problem* p, const glrm_options* o, const glrm_multi_options* mo) {
+  if (!out || !p || !mo) return fail(GLRM_ERR_INVALID, "NULL argument");
+  *out = NULL;
+  if (mo->n_shards < 1 || mo->n_shards > 64) return fail(GLRM_ERR_INVALID, "n_shards must be in 1..64");
+  if (p->dense_A) return fail(GLRM_ERR_UNSUPPORTED, "the oracle takes observation lists only");
+  if (!(p->row_begin == 0 && p->row_end == p->m && p->col_begin == 0 && p->col_end == p->n) || !p->rowptr || !p->colptr)
+    return fail(GLRM_ERR_INVALID, "glrm_cpu_multi_create takes the whole problem; it shards it itself");
+  glrm_cpu_multi* mh = (glrm_cpu_multi*)calloc(1, sizeof *mh);
+  if (!mh) return fail(GLRM_ERR_OOM, "out of memory");
+  const int n = mh->n = mo->n_shards;
+  mh->m = p->m; mh->nn = p->n; mh->k = p->k; mh->n_rx = p->n_rx; mh->n_ry = p->n_ry;
+  mh->sh = (glrm_cpu_handle**)calloc((size_t)n, sizeof *mh->sh);
+  mh->rbs = (int64_t*)calloc((size_t)n + 1, 8);
+  mh->cbs = (int64_t*)calloc((size_t)n + 1, 8);
+  if (!mh->sh || !mh->rbs || !mh->cbs) { glrm_cpu_multi_destroy(mh); return fail(GLRM_ERR_OOM, "out of memory"); }
+  cpu_partition(p->rowptr, p->m, n, mh->rbs);
+  cpu_partition(p->colptr, p->n, n, mh->cbs);
+  mh->nnz_rows = p->rowptr[p->m];
+  for (int s = 0; s < n; ++s) {
+    glrm_problem q = *p;
+    q.row_begin = mh->rbs[s]; q.row_end = mh->rbs[s + 1]; q.col_begin = mh->cbs[s]; q.col_end = mh->cbs[s + 1];
+    const int64_t ml = q.row_end - q.row_begin, nl = q.col_end - q.col_begin, r0 = p->rowptr[q.row_begin], c0 = p->colptr[q.col_begin];
+    int64_t* rp = (int64_t*)malloc((size_t)(ml + 1) * 8);
+    int64_t* cp = (int64_t*)malloc((size_t)(nl + 1) * 8);
+    if (!rp || !cp) { free(rp); free(cp); glrm_cpu_multi_destroy(mh); return fail(GLRM_ERR_OOM, "out of memory"); }
+    for (int64_t i = 0; i <= ml; ++i) rp[i] = p->rowptr[q.row_begin + i] - r0;
+    for (int64_t i = 0; i <= nl; ++i) cp[i] = p->colptr[q.col_begin + i] - c0;
+    q.rowptr = rp; q.colidx = p->colidx + r0; q.rowvals = p->rowvals + r0;
+    q.colptr = cp; q.rowidx = p->rowidx + c0; q.colvals = p->colvals + c0;
+    if (p->n_rx != 1) { q.rx = p->rx + q.row_begin; q.n_rx = ml; }
+    if (p->n_ry != 1) { q.ry = p->ry + q.col_begin; q.n_ry = nl; }
+    const int rc = glrm_cpu_create(&mh->sh[s], &q, o);
+    free(rp); free(cp);
+    if (rc) { glrm_cpu_multi_destroy(mh); return rc; }
+  }
+  mh->d = mh->sh[0]->d;
+  mh->X = (double*)calloc((size_t)mh->k * mh->m, 8);
+  mh->Y = (double*)calloc((size_t)mh->k * mh->d, 8);
+  mh->objcol = (double*)calloc((size_t)mh->nn, 8);
+  mh->objrow = (double*)calloc((size_t)mh->m, 8);
+  if (!mh->X || !mh->Y || !mh->objcol || !mh->objrow) { glrm_cpu_multi_destroy(mh); return fail(GLRM_ERR_OOM, "out of memory"); }
+  for (int s = 0; s < n; ++s) glrm_cpu_bind_buffers(mh->sh[s], mh->X, mh->Y, mh->objcol, mh->objrow);
+  *out = mh;
+  return GLRM_OK;
+}
+
+int glrm_cpu_multi_set_regularizers(glrm_cpu_multi* mh, const glrm_reg* rx, int64_t n_rx, const glrm_reg* ry, int64_t n_ry) {
+  if (!mh || !rx || !ry) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (n_rx != mh->n_rx || n_ry != mh->n_ry) return fail(GLRM_ERR_INVALID, "regularizer counts must match the create call");
+  for (int s = 0; s < mh->n; ++s) {
+    const int rc = glrm_cpu_set_regularizers(mh->sh[s], n_rx == 1 ? rx : rx + mh->rbs[s], n_rx == 1 ? 1 : mh->rbs[s + 1] - mh->rbs[s],
+                                             n_ry == 1 ? ry : ry + mh->cbs[s], n_ry == 1 ? 1 : mh->cbs[s + 1] - mh->cbs[s]);
+    if (rc) return rc;
+  }
+  return GLRM_OK;
+}
+
+int glrm_cpu_multi_info(glrm_cpu_multi* mh, int64_t* row_bounds, int64_t* col_bounds, int32_t* exchange_used, double* exchange_ms) {
+  if (!mh) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (row_bounds) memcpy(row_bounds, mh->rbs, ((size_t)mh->n + 1) * 8);
+  if (col_bounds) memcpy(col_bounds, mh->cbs, ((size_t)mh->n + 1) * 8);
+  if (exchange_used) *exchange_used = 0;
+  if (exchange_ms) *exchange_ms = 0.0;
+  return GLRM_OK;
+}
+
+int glrm_cpu_multi_fit(glrm_cpu_multi* mh, const glrm_params* prm, double* X, double* Y, double* objective, double* seconds,
+                       int64_t cap, int64_t* n_recorded) {
+  if (!mh || !prm || !X || !Y || !objective || !seconds || !n_recorded) return fail(GLRM_ERR_INVALID, "NULL argument");
+  if (prm->max_iter < 0 || cap < prm->max_iter + 1) return fail(GLRM_ERR_INVALID, "objective/seconds capacity must be >= max_iter+1");
+  if (prm->inner_iter_X < 1 || prm->inner_iter_Y < 1) return fail(GLRM_ERR_INVALID, "inner iteration counts must be >= 1");
+  double ynorm = 0.0;
+  for (int64_t i = 0; i < (int64_t)mh->k * mh->d; ++i) ynorm += Y[i] * Y[i];
+  if (ynorm == 0.0) return fail(GLRM_ERR_INVALID, "Y is all zeros (the reference cannot start from Y == 0)");
+  const int n = mh->n;
+  int rc;
+  memcpy(mh->X, X, (size_t)mh->k * mh->m * 8);
+  memcpy(mh->Y, Y, (size_t)mh->k * mh->d * 8);
+#define ALL(call) do { for (int s_ = 0; s_ < n; ++s_) { glrm_cpu_handle* hs = mh->sh[s_]; if ((rc = (call))) return rc; } } while (0)
+  ALL(glrm_cpu_reset_stepsizes(hs, prm->stepsize));
+  const double scaled_abs_tol = prm->abs_tol * (double)mh->nnz_rows;
+  ALL(glrm_cpu_col_losses(hs));
+  const double loss = julia_sum(mh->objcol, mh->nn);
+  ALL(glrm_cpu_row_penalties(hs));
+  const double px = julia_sum(mh->objrow, mh->m);
+  ALL(glrm_cpu_col_penalties(hs));
+  const double py = julia_sum(mh->objcol, mh->nn);
+  objective[0] = loss + (px + py);
+  seconds[0] = 0.0;
+  int64_t nrec = 1;
+  double t = now_s();
+  for (int64_t i = 1; i <= prm->max_iter; ++i) {
+    if (prm->inner_iter_X > 1 || prm->inner_iter_Y > 1) ALL(glrm_cpu_reset_stepsizes(hs, prm->stepsize));
+    for (int64_t in = 0; in < prm->inner_iter_X; ++in) ALL(glrm_cpu_step_x(hs, prm->min_stepsize));
+    for (int64_t in = 0; in < prm->inner_iter_Y; ++in) ALL(glrm_cpu_step_y(hs, prm->min_stepsize));
+    const double obj = julia_sum(mh->objcol, mh->nn);
+    const double dt = now_s() - t;
+    objective[nrec] = obj;
+    seconds[nrec] = seconds[nrec - 1] + dt;
+    ++nrec;
+    t = now_s();
+    const double dec = objective[nrec - 2] - obj;
+    if (i > 10 && (dec < scaled_abs_tol || dec / obj < prm->rel_tol)) break;
+  }
+#undef ALL
+  memcpy(X, mh->X, (size_t)mh->k * mh->m * 8);
+  memcpy(Y, mh->Y, (size_t)mh->k * mh->d * 8);
+  *n_recorded = nrec;
+  return GLRM_OK;
+}

@@ -37,6 +37,65 @@ def test_oracle_thread_count_invariant(name):
     assert np.array_equal(o1, o4) and np.array_equal(X1, X4) and np.array_equal(Y1, Y4)
 
 
+def test_binary_twins_match_the_npz_fixtures():
+    """tests/golden/bin/<name>.bin (what julia/crosscheck.jl reads) carries exactly the inputs and oracle outputs of <name>.npz."""
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import fixture_bin as FB
+    for name in cases.GOLDEN_CASES:
+        pa, X0, Y0, params, z = cases.load_case(os.path.join(GOLDEN, name + ".npz"))
+        b = FB.read_bin(os.path.join(FB.BIN, name + ".bin"))
+        for f in ("rowptr", "colidx", "rowvals", "colptr", "rowidx", "colvals"):
+            assert np.array_equal(b[f], getattr(pa, f)), (name, f)
+        assert np.array_equal(b["X0"], X0) and np.array_equal(b["Y0"], Y0) and np.array_equal(b["objective"], z["objective"])
+        assert np.array_equal(b["X"], z["X"]) and np.array_equal(b["Y"], z["Y"])
+        assert np.array_equal(b["losses"][:, 0], np.broadcast_to(pa.losses["kind"], pa.n)) and len(b["rx"]) == pa.m
+        assert list(b["params"]) == [params.stepsize, params.max_iter, params.inner_iter_X, params.inner_iter_Y, params.abs_tol,
+                                     params.rel_tol, params.min_stepsize]
+
+
+def _reference_dumps():
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import fixture_bin as FB
+    if not os.path.isdir(FB.REF):
+        return []
+    return sorted(f[:-8] for f in os.listdir(FB.REF) if f.endswith(".ref.bin"))
+
+
+@pytest.mark.parametrize("name", _reference_dumps() or ["<none>"])
+def test_reference_dump_matches_the_oracle(name):
+    """Consumes tests/golden/ref/<name>.ref.bin -- the trajectory of the REAL LowRankModels.fit! on the fixture's inputs, written by
+    julia/crosscheck.jl -- and compares it with the oracle's: this is what lifts the oracle from "operators pinned" to "trajectory
+    pinned".  No dump is committed yet (no julia in the image): the test then skips, and DESIGN.md section 3 says "parity unpinned"."""
+    if name == "<none>":
+        pytest.skip("no reference dump under tests/golden/ref (run julia/crosscheck.jl where Julia and LowRankModels.jl exist)")
+    import fixture_bin as FB
+    obj, tim, X, Y = FB.read_ref(os.path.join(FB.REF, name + ".ref.bin"))
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    assert len(obj) == len(z["objective"]), "the reference stopped at a different iteration than the oracle"
+    assert cases.rel_err(obj, z["objective"]) < 1e-9  # same expression trees, same summation orders
+    assert cases.fro_err(X, z["X"]) < 1e-9 and cases.fro_err(Y, z["Y"]) < 1e-9
+
+
+def test_reference_dump_reader_roundtrip(tmp_path):
+    """The GLRMREF1 layout julia/crosscheck.jl writes, written here from the oracle's numbers and read back."""
+    import struct
+    import sys
+    sys.path.insert(0, GOLDEN)
+    import fixture_bin as FB
+    z = np.load(os.path.join(GOLDEN, "nnmf.npz"))
+    k, m = z["X"].shape
+    d = z["Y"].shape[1]
+    p = tmp_path / "nnmf.ref.bin"
+    with open(p, "wb") as f:
+        f.write(b"GLRMREF1" + struct.pack("<4q", len(z["objective"]), k, m, d))
+        f.write(z["objective"].astype("<f8").tobytes()); f.write(np.zeros(len(z["objective"])).tobytes())
+        f.write(np.asfortranarray(z["X"]).tobytes(order="F")); f.write(np.asfortranarray(z["Y"]).tobytes(order="F"))
+    obj, tim, X, Y = FB.read_ref(str(p))
+    assert np.array_equal(obj, z["objective"]) and np.array_equal(X, z["X"]) and np.array_equal(Y, z["Y"])
+
+
 def test_golden_case_builders_match_fixture_inputs():
     """The generating script and the stored inputs agree (guards against editing one without the other)."""
     for name in cases.GOLDEN_CASES:
