@@ -123,3 +123,40 @@ def test_c2_full_size_properties(scale):
     st = api.kernel_stats(h)
     assert st["nnz_rows"] == m * q and st["trials_x"] >= st["accepts_x"] > 0
     api.destroy(h)
+
+
+def test_c2_full_size_three_iterations_against_the_oracle():
+    """BASELINE configs[1] at FULL size, end to end: the initial objective and three complete outer iterations (every row, every
+    column, all line searches) of the HIP engine against the CPU oracle on the very same 5e8 observations (the device-generated
+    views are copied to the host, ~12 GB).  Tolerance 1e-5 relative (north star); the engine typically agrees to ~1e-12."""
+    import torch
+    m, n, k, q = 1_000_000, 10_000, 32, 500
+    api = _capi.hip_api()
+    w = synth.DeviceWorkload(m, n, k, q)
+    h = api.create(w.problem(), stream=torch.cuda.current_stream().cuda_stream)
+    ld = api.factor_ld(h)
+    dX, dY = w.init_factors(ld)
+    X0 = np.asfortranarray(dX.cpu().numpy().reshape(m, ld)[:, :k].T)
+    Y0 = np.asfortranarray(dY.cpu().numpy().reshape(n, ld)[:, :k].T)
+    host = [t.cpu().numpy() for t in (w.rowptr, w.colidx, w.rowvals, w.colptr, w.rowidx, w.colvals)]
+    w.free_sources()
+    del dX, dY
+    p = L.ProxGradParams(max_iter=3)
+    Xg, Yg = X0.copy(order="F"), Y0.copy(order="F")
+    obj_g, _ = api.fit(h, p, Xg, Yg)
+    st = api.kernel_stats(h)
+    api.destroy(h)
+    assert st["tiled"] == 3 and st["nnz_rows"] == m * q
+    one = np.array([synth.QUAD], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 1.0)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(m, n, k, host[0], host[1][:m * q], host[2][:m * q], host[3], host[4][:m * q], host[5][:m * q], one, reg, reg)
+    O.set_threads(O.usable_cores())
+    oapi = O.oracle_api()
+    ho = oapi.create(pa)
+    Xc, Yc = X0.copy(order="F"), Y0.copy(order="F")
+    obj_c, _ = oapi.fit(ho, p, Xc, Yc)
+    oapi.destroy(ho)
+    assert len(obj_g) == len(obj_c) == 4
+    rel = np.max(np.abs(obj_g - obj_c) / np.abs(obj_c))
+    assert rel < 1e-5, (obj_g, obj_c)
+    assert np.linalg.norm(Xg - Xc) / np.linalg.norm(Xc) < 1e-5 and np.linalg.norm(Yg - Yc) / np.linalg.norm(Yc) < 1e-5
