@@ -52,10 +52,14 @@ struct glrm_handle {
   int tG = 4, tR = 2;                 // lane layout of the tiled kernels (kp = tG*tR)
   int tile_cfg = 0;                   // 0: 8 waves + ~64 KB tile, 1: 16 waves + ~128 KB tile
   int nsup = 0, tiles_per_sup = 0;
+  int row_split = 0, tiles_per_sup_r = 0; // row sweep in super-tile passes (nsup_r super-tiles; buffers part_r ... ntrial_r below)
   double *part = nullptr, *gsum = nullptr, *trialbuf = nullptr, *joldbuf = nullptr;
   int32_t *activebuf = nullptr, *ntrialbuf = nullptr;
   unsigned int* nactive = nullptr;
   int* dflag = nullptr;
+  uint8_t* rowdescid = nullptr;       // heterogeneous tiled row sweep: id of the loss descriptor of every entry of the row view
+  glrm_loss* udesc = nullptr;         // the model's distinct loss descriptors (<= 256), device
+  int n_udesc = 0;
   int32_t *colperm = nullptr, *rowperm = nullptr; // tiled sweeps: segments sorted by (loss kind, length) / by length
   // general sweeps: multi-dimensional losses / wrapped regularizers (glrm_multi.hip)
   bool multi = false;

@@ -108,6 +108,37 @@ int glrm_setup_tiled(glrm_handle* h) {
     h->colidx = oidx;
     h->rowvals = ovals;
   }
+  if (h->tiled_row && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_UDESC", 1)) {
+    // distinct loss descriptors of the model; with at most 256 of them every entry of the row view carries a one-byte id and the
+    // row sweep reads descriptors from an LDS table (TiledArgs::descid)
+    std::vector<glrm_loss> uniq;
+    std::vector<uint8_t> colid((size_t)h->n);
+    bool ok = true;
+    for (int64_t f = 0; f < h->n && ok; ++f) {
+      const glrm_loss& l = h->losses_h[(size_t)f];
+      size_t u = 0;
+      for (; u < uniq.size(); ++u)
+        if (uniq[u].kind == l.kind && uniq[u].dim == l.dim && uniq[u].scale == l.scale && uniq[u].p0 == l.p0 && uniq[u].p1 == l.p1) break;
+      if (u == uniq.size()) {
+        if (uniq.size() == 256) { ok = false; break; }
+        uniq.push_back(l);
+      }
+      colid[(size_t)f] = (uint8_t)u;
+    }
+    if (ok) {
+      uint8_t* dcolid = nullptr;
+      HIPCK(hipMalloc((void**)&dcolid, (size_t)h->n));
+      HIPCK(hipMalloc((void**)&h->udesc, uniq.size() * sizeof(glrm_loss)));
+      HIPCK(hipMalloc((void**)&h->rowdescid, (size_t)h->nnz_r));
+      HIPCK(hipMemcpyAsync(dcolid, colid.data(), (size_t)h->n, hipMemcpyHostToDevice, st));
+      HIPCK(hipMemcpyAsync(h->udesc, uniq.data(), uniq.size() * sizeof(glrm_loss), hipMemcpyHostToDevice, st));
+      hipLaunchKernelGGL(entry_descid_kernel, dim3(4096), dim3(256), 0, st, h->colidx, h->nnz_r, dcolid, h->rowdescid);
+      HIPCK(hipGetLastError());
+      HIPCK(hipStreamSynchronize(st)); // colid / uniq are locals
+      (void)hipFree(dcolid);
+      h->n_udesc = (int)uniq.size();
+    }
+  }
   // super-tiles of ~32k rows: a function of (m, tile) only -- never of the shard layout -- so the partial-sum order
   // (and the result bits) do not depend on the GPU count, while long columns still spread over enough workgroups
   const int64_t ntiles = (h->m + T - 1) / T;
@@ -139,6 +170,33 @@ int glrm_setup_tiled(glrm_handle* h) {
     if ((rc0 = make_segperm(h, false, &h->colperm))) return rc0;
   }
   if (h->tiled_row && (rc0 = make_segperm(h, true, &h->rowperm))) return rc0;
+  // Row sweep in super-tile passes.  The one-kernel row sweep streams the WHOLE opposing factor through LDS per workgroup and pass;
+  // workgroups that started at different times are at different tiles, so once Y no longer fits the 4 MB L2 of an XCD every tile
+  // they stage comes from the Infinity Cache (~8 TB/s for the whole chip, profiles/r02_ubench_gather.txt) -- at 1M x 50k, k = 32
+  // that is 100 GB per half-step and 2/3 of its time.  In pass form (the column machinery: pass over one super-tile per workgroup,
+  // partials, reduce, trial passes, decide) the grid is ordered super-tile major, so the workgroups in flight all stage tiles of
+  // the same L2-sized super-tile.  Super-tile = ~2.5 MB of Y, a function of (n, tile, kp) only.
+  h->row_split = 0;
+  if (h->tiled_row) {
+    const int64_t ybytes = h->n * (int64_t)h->kp * 8;
+    const int want_split = env_int("GLRM_HIP_ROW_SPLIT", ybytes > (int64_t)3 * 1024 * 1024 ? 1 : 0);
+    if (want_split) {
+      const int64_t nt = (h->n + T - 1) / T;
+      int64_t tps = ((int64_t)5 * 512 * 1024) / ((int64_t)T * h->kp * 8);
+      tps = env_int("GLRM_HIP_ROW_TPS", (int)(tps < 1 ? 1 : tps));
+      h->tiles_per_sup_r = (int)tps;
+      h->nsup_r = (int)((nt + tps - 1) / tps);
+      const int64_t ml1 = h->ml > 0 ? h->ml : 1;
+      HIPCK(hipMalloc((void**)&h->part_r, (size_t)ml1 * h->nsup_r * (h->kp + 2) * 8));
+      HIPCK(hipMalloc((void**)&h->gsum_r, (size_t)ml1 * h->kp * 8));
+      HIPCK(hipMalloc((void**)&h->trial_r, (size_t)ml1 * h->kp * 8));
+      HIPCK(hipMalloc((void**)&h->jold_r, (size_t)ml1 * 8));
+      HIPCK(hipMalloc((void**)&h->active_r, (size_t)ml1 * 4));
+      HIPCK(hipMalloc((void**)&h->ntrial_r, (size_t)ml1 * 4));
+      if (!h->nactive) HIPCK(hipMalloc((void**)&h->nactive, 4));
+      h->row_split = 1;
+    }
+  }
   return GLRM_OK;
 }
 
@@ -152,7 +210,7 @@ static int set_lds(K kernel, int bytes) {
 template <int G, int R, int NW, int TILE, int LOSS>
 static int launch_tiled_inst(int kind, const TiledArgs& a, hipStream_t st) {
   constexpr int SPB = NW * (64 / G);
-  const int lds = TILE * tile_row_bytes<G, R>();
+  const int lds = TILE * tile_row_bytes<G, R>() + (loss_mode(LOSS) == 2 && a.descid ? a.n_udesc * 32 : 0);
   const unsigned gx = (unsigned)((a.nseg + SPB - 1) / SPB);
   int rc = GLRM_OK;
   if (kind == 0 && a.fixed_alpha > 0.0) {
@@ -240,6 +298,9 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
   a.accepts = rows ? h->accepts_r : h->accepts_c;
   a.eval_only = eval_only;
   a.fixed_alpha = eval_only ? 0.0 : h->fixed_alpha;
+  a.descid = rows ? h->rowdescid : nullptr;
+  a.udesc = h->udesc;
+  a.n_udesc = h->n_udesc;
   if (rows && h->rng_e >= 0) { // glrm_hip_step_x_range
     const int64_t s0 = h->rng_b;
     a.nseg = h->rng_e - s0;
@@ -248,15 +309,24 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
     if (!a.reg_single) a.regs += s0;
     a.trials += s0; a.accepts += s0;
   }
-  if (rows) {
+  if (rows && !h->row_split) {
     a.segperm = h->rng_e >= 0 ? nullptr : h->rowperm; // a sub-range sweep keeps the natural order
     return launch_tiled(h, loss, 0, a);
   }
-  a.nsup = h->nsup;
-  a.tiles_per_sup = h->tiles_per_sup;
-  a.part = h->part; a.gsum = h->gsum; a.trial = h->trialbuf; a.jold = h->joldbuf;
-  a.active = h->activebuf; a.ntrial = h->ntrialbuf; a.nactive = h->nactive;
-  a.segperm = h->colperm;
+  if (rows) { // super-tile passes over the rows (glrm_setup_tiled): the column machinery with the roles swapped
+    const int64_t s0 = h->rng_e >= 0 ? h->rng_b : 0;
+    a.nsup = h->nsup_r;
+    a.tiles_per_sup = h->tiles_per_sup_r;
+    a.part = h->part_r + s0 * (int64_t)h->nsup_r * (h->kp + 2); a.gsum = h->gsum_r + s0 * (int64_t)h->kp; a.trial = h->trial_r + s0 * (int64_t)h->kp;
+    a.jold = h->jold_r + s0; a.active = h->active_r + s0; a.ntrial = h->ntrial_r + s0; a.nactive = h->nactive;
+    a.segperm = h->rng_e >= 0 ? nullptr : h->rowperm;
+  } else {
+    a.nsup = h->nsup;
+    a.tiles_per_sup = h->tiles_per_sup;
+    a.part = h->part; a.gsum = h->gsum; a.trial = h->trialbuf; a.jold = h->joldbuf;
+    a.active = h->activebuf; a.ntrial = h->ntrialbuf; a.nactive = h->nactive;
+    a.segperm = h->colperm;
+  }
   int rc;
   HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
   if ((rc = launch_tiled(h, loss, 1, a))) return rc;

@@ -56,6 +56,12 @@ struct TiledArgs {
   int eval_only;         // col_reduce: obj = sum of losses, nothing else
   int64_t dense_len;     // ptr == nullptr (dense problem): every segment has this many observations
   double fixed_alpha;    // > 0: one prox-gradient step with this global step size, no line search
+  // heterogeneous row sweep (a loss descriptor per observation): the DISTINCT descriptors of the model (at most 256) sit in LDS behind
+  // the tile and every entry of the row view carries the id of its column's descriptor, so the step reads its descriptor from LDS
+  // with the batch instead of waiting for a dependent global load of losses[column] (nullptr: table lookups)
+  const uint8_t* descid;  // per entry of the view
+  const glrm_loss* udesc; // n_udesc distinct descriptors
+  int n_udesc;
   const int32_t* segperm; // lane-group slot -> local segment (nullptr = identity).  Which segment a group works on changes no sum:
                           // columns are handed out sorted by (loss kind, length), rows by length, so that the 16 groups of a wave
                           // evaluate the same loss formula and finish their lists together.
@@ -139,14 +145,20 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
   // into the segment, validity applied when the entry is used) so that the compiler can keep the prefetch of
   // the next batch in flight with a counted s_waitcnt instead of draining the queue at every branch merge.
   const int64_t last = end > 0 ? end - 1 : 0; // idx/vals always hold at least one element
-  auto load_entry = [&](int64_t p, int& c, double& av) {
+  constexpr bool UDESC = FOUR && loss_mode(LOSS) == 2; // descriptor ids travel with the entries (see TiledArgs::descid)
+  const uint8_t* __restrict__ descid = a.descid;
+  const bool have_ids = UDESC && descid != nullptr;    // uniform
+  const char* udesc_lds = lds + TILE * ROWB;            // the kernel staged the distinct descriptors there
+  auto load_entry = [&](int64_t p, int& c, double& av, int& did) {
     const int64_t q = p < last ? p : last;
     c = idx[q];
     av = vals[q];
+    did = 0;
+    if constexpr (UDESC) { if (have_ids) did = descid[q]; }
   };
-  int cb;
+  int cb, db;
   double ab;
-  load_entry(pos + j, cb, ab);
+  load_entry(pos + j, cb, ab, db);
   if (!(active && pos + j < end)) cb = 0x7fffffff;
   for (int t = tile_begin; t < tile_end; ++t) {
     const int64_t lo = (int64_t)t * TILE;
@@ -156,9 +168,9 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
     __syncthreads();
     bool done = !active;
     while (!done) {
-      int cn; // prefetch the next batch while this one is consumed
+      int cn, dn; // prefetch the next batch while this one is consumed
       double an;
-      load_entry(pos + G + j, cn, an);
+      load_entry(pos + G + j, cn, an, dn);
       const bool next_ok = pos + G + j < end;
       int nproc = 0;
       // Two observations of the batch per step.  Every lane forms its partial dot products for BOTH observations;
@@ -214,7 +226,16 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
           if constexpr (loss_mode(LOSS) == 1) {
             loss_both<GRAD, loss_trig(LOSS)>(segloss, dot, ab, L, dL);
           } else {
-            const LossDesc lo_ = load_loss(a.losses, mine ? cb : c[0]);
+            LossDesc lo_;
+            if (have_ids) { // 32-byte descriptor from the LDS table (glrm_loss layout: kind, dim, scale, p0, p1)
+              const char* dp = udesc_lds + db * 32;
+              const int2 kd = *reinterpret_cast<const int2*>(dp);
+              const double sc = *reinterpret_cast<const double*>(dp + 8);
+              const double2 pp = *reinterpret_cast<const double2*>(dp + 16);
+              lo_ = LossDesc{kd.x, sc, pp.x, pp.y};
+            } else {
+              lo_ = load_loss(a.losses, mine ? cb : c[0]);
+            }
             loss_both<GRAD, loss_trig(LOSS)>(lo_, dot, ab, L, dL);
           }
           if (!mine) {
@@ -316,13 +337,27 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
       if (!done) { // the whole batch was consumed: continue with the prefetched one
         cb = next_ok ? cn : 0x7fffffff;
         ab = an;
+        db = dn;
       } else if (nproc > 0) { // stopped inside the batch: re-anchor the batch at the new position
-        load_entry(pos + j, cb, ab);
+        load_entry(pos + j, cb, ab, db);
         if (!(pos + j < end)) cb = 0x7fffffff;
       }
     }
   }
   J = group_sum<G>(J) * (FOUR ? 1.0 : 2.0 / G); // two per step: lanes hold parity-partial sums, each observation counted G/2 times
+}
+
+// distinct loss descriptors -> LDS behind the tile (read after the first tile barrier of tiled_pass); see TiledArgs::descid
+template <int G, int R, int NW, int TILE, int LOSS>
+__device__ __forceinline__ void stage_udesc(const TiledArgs& a, char* lds) {
+  if constexpr (loss_mode(LOSS) == 2) {
+    if (a.descid) {
+      const int words = a.n_udesc * 8; // 32 bytes each
+      const int* src = reinterpret_cast<const int*>(a.udesc);
+      int* dst = reinterpret_cast<int*>(lds + TILE * tile_row_bytes<G, R>());
+      for (int w = threadIdx.x; w < words; w += NW * 64) dst[w] = src[w];
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -343,6 +378,7 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_sweep_kernel(const TiledArgs
   const int64_t gseg = a.own_offset + (have ? seg : 0);
   double2* ownp = reinterpret_cast<double2*>(a.own + gseg * KP);
   const int ntiles = (int)((a.n_other + TILE - 1) / TILE);
+  stage_udesc<G, R, NW, TILE, LOSS>(a, lds);
 
   Vec<G, R> g, xn;
   const RegDesc rd = load_reg(a.regs, (a.reg_single || !have) ? 0 : seg);
@@ -451,6 +487,7 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_col_pass_kernel(const TiledA
   const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[slot] : slot; // which column a group works on does not change any sum
   if (!GRAD && have) have = a.active[seg] != 0;
   if (!GRAD && !__syncthreads_or(have ? 1 : 0)) return; // nothing left to evaluate in this column group
+  stage_udesc<G, R, NW, TILE, LOSS>(a, lds);
   const int64_t beg = have ? a.ptr[seg] : 0, end = have ? a.ptr[seg + 1] : 0;
   const int64_t gseg = a.own_offset + (have ? seg : 0);
   const int ntiles = (int)((a.n_other + TILE - 1) / TILE);
@@ -643,6 +680,11 @@ static __global__ void __launch_bounds__(64) group_rows_by_kind_kernel(const int
     oidx[wb + rank] = c;
     ovals[wb + rank] = vals[t];
   }
+}
+
+// descid[t] = colid[idx[t]]: the id of the column's loss descriptor among the model's distinct descriptors
+static __global__ void entry_descid_kernel(const int32_t* idx, int64_t nnz, const uint8_t* colid, uint8_t* descid) {
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nnz; t += (int64_t)gridDim.x * blockDim.x) descid[t] = colid[idx[t]];
 }
 
 } // namespace glrm

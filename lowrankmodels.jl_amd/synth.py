@@ -53,6 +53,9 @@ ORDINAL_1_5 = (6, 0, 1.0, 1.0, 5.0)
 def loss_table(n, loss_mix):
     """Descriptors matching glrm_synth_colkind: all Quad, or (Quad, Logistic, OrdinalHinge(1,5))[f mod 3]."""
     if not loss_mix:
+        if os.environ.get("GLRM_SYNTH_PER_COLUMN_QUAD"):  # experiment: QuadLoss everywhere, but one descriptor per column (two distinct
+            # scales), so the per-observation-descriptor kernels run on data whose loss is cheap
+            return np.array([(0, 0, 1.0 if f % 2 else 1.0 + 2.0 ** -40, 0.0, 0.0) for f in range(n)], dtype=_capi.LOSS_DTYPE)
         return np.array([QUAD], dtype=_capi.LOSS_DTYPE)
     kinds = [QUAD, LOGISTIC, ORDINAL_1_5]
     return np.array([kinds[f % 3] for f in range(n)], dtype=_capi.LOSS_DTYPE)
