@@ -85,6 +85,7 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
 
     family   'gather'  every update fetches the opposing k-vector from memory (csrc/glrm_hip.hip sweep_kernel)
              'tiled'   the opposing factor is staged tile by tile in LDS (csrc/glrm_tiled.hpp)
+             'blocked' phase-aligned gather passes: the k-vector gathers are served by the L2 of the XCD (csrc/glrm_blocked.hip)
              'dense'   fully observed QuadLoss on the fp64 matrix cores (csrc/glrm_dense.hpp)
              'general' multi-dimensional losses (csrc/glrm_multi.hpp)
     nnz updates per launch, nseg own segments, nopp opposing vectors, ld padded rank, ms duration of the half-step.
@@ -112,6 +113,16 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
                           what="tile staging: workgroups x P x opposing factor bytes (L2 -> LDS)"))
         cands.append(dict(bound="lds", achieved=nnz * P * 8 * ld / t / 1e9, peak=LDS_PEAK_GBS, unit="GB/s", per_launch=nnz * P * 8 * ld,
                           what="LDS reads: one opposing vector (8 ld bytes) per update and pass"))
+    elif family == "blocked":
+        # groups in flight walk the opposing factor together: its bytes cross the fabric once per XCD, slice of segments and pass; the
+        # gathers themselves are L2 traffic; partial sums (ld + 2 doubles per segment and super-tile) are written and read once
+        nsup = max(1, -(-opp // (128 * 2 ** 20)))
+        slices = max(1, -(-nseg // (256 * 16 * (64 // max(ld // 8, 4)))))
+        fabric = stream + 8 * slices * P * opp + 2 * nseg * nsup * (ld + 2) * 8 + 4 * nseg * ld * 8
+        cands.append(dict(bound="hbm", achieved=fabric / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=fabric,
+                          what="fabric bytes: P x 12 B x |Omega| + own factor r/w + partial sums + the opposing factor once per XCD, slice and pass"))
+        cands.append(dict(bound="l2", achieved=nnz * P * 8 * k / t / 1e9, peak=L2_PEAK_GBS, unit="GB/s", per_launch=nnz * P * 8 * k,
+                          what="k-vector gathers served by the L2 of the XCD (phase-aligned walk): P x 8k bytes per update"))
     else:
         if opp > MALL_BYTES or family == "general":  # the opposing factor cannot stay on chip: the gathers are HBM traffic
             cands.append(dict(bound="hbm", achieved=alg / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=alg,
@@ -407,8 +418,8 @@ def main():
         value = args.steps * updates_per_step / elapsed
         ms_x = st["ms_x"] / max(args.steps, 1)  # per outer iteration (the X half-step may run as several chunk launches)
         ms_y = st["ms_y"] / max(args.steps, 1)
-        fam_r = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 1 else "gather"
-        fam_c = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 2 else "gather"
+        fam_r = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 1 else "blocked" if flags & 16 else "gather"
+        fam_c = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 2 else "blocked" if flags & 32 else "gather"
         ld = st["ld"]
         tile = 150 * 1024 // (ld * 8 + 16)
         rl_r = kernel_roofline(fam_r, nnz=nnz_r, nseg=nseg_r, nopp=n, k=k, ld=ld, ms=ms_x, m=nseg_r, n=n, tile=tile)
@@ -420,6 +431,8 @@ def main():
                  ("col", "gather"): ("sweep_kernel (Y half-step, k-vector gather)", "sweep_kernel"),
                  ("row", "tiled"): ("tiled_sweep_kernel (X half-step, LDS-tiled)", "tiled_sweep_kernel"),
                  ("col", "tiled"): ("tiled_col_pass_kernel x2 + col_reduce/col_decide (Y half-step, LDS-tiled)", "tiled_col_pass_kernel"),
+                 ("row", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (X half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
+                 ("col", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (Y half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
                  ("row", "dense"): ("dense_pass_kernel (X half-step, fp64 MFMA)", "dense_pass_kernel"),
                  ("col", "dense"): ("dense_pass_kernel (Y half-step, fp64 MFMA)", "dense_pass_kernel"),
                  ("row", "general"): ("multi_sweep_kernel (X half-step)", "multi_sweep_kernel"),

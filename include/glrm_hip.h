@@ -347,7 +347,8 @@ typedef struct glrm_kernel_stats {
   int64_t nnz_rows, nnz_cols;  /* |Omega| of the local CSR / CSC */
   int32_t waves_row, waves_col, ld;
   int32_t tiled;               /* bit0: LDS-tiled row sweep in use, bit1: LDS-tiled column sweep in use,
-                                  bit2: dense MFMA path in use */
+                                  bit2: dense MFMA path in use, bit3: general sweeps (multi-dimensional losses),
+                                  bit4 / bit5: phase-aligned gather passes (L2-blocked) for the row / column sweep */
 } glrm_kernel_stats;
 
 int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int reset);

@@ -1,0 +1,205 @@
+// glrm_blocked.hip -- phase-aligned gather passes: the sweep family for problems whose opposing factor is far larger than the 4 MB
+// L2 of an XCD and whose segments meet too few observations per LDS tile for the tiled sweeps (BASELINE config 4: 10M x 100k,
+// rank 64, 100 observations per row).
+//
+// Why.  The one-kernel gather sweep (glrm_hip.hip) fetches one k-vector per observation from wherever the opposing factor lives:
+// measured 6.5 TB/s from HBM (X, 5.1 GB) and 8.2 TB/s from the Infinity Cache (Y, 51 MB) -- the ceilings of random 512-byte reads at
+// those levels (profiles/r02_ubench_gather.txt).  The same reads served by the L2 of the XCD run at ~30 TB/s.  The index lists are
+// sorted, so a lane group that owns a segment walks the opposing factor front to back; if every group in flight starts at the same
+// time and works at the same rate, all of them read the same ~2 MB window of the factor at any moment and that window stays in L2.
+//
+// How.  The pass structure of the LDS-tiled column sweep (glrm_tiled.hpp: pass over one super-tile, partials per (segment,
+// super-tile), reduce in super-tile order, trial passes, decide) with the LDS tile taken out (tiled_pass<..., L2 = true>):
+//   * a lane group (G lanes) owns one segment, its factor vector and gradient live in registers, its observations are consumed in
+//     list order (the reference's summation order);
+//   * one launch = one super-tile x one SLICE of the segments, the slice being what the chip holds at once (occupancy x CUs), so
+//     all groups of a launch start together; launches are issued super-tile by super-tile;
+//   * a super-tile is ~128 MB of the opposing factor (64 L2 windows): short enough that the groups have not drifted apart by the
+//     end of it, long enough that the partial sums (k + 2 doubles per segment and super-tile) are a few percent of the traffic.
+//     Its size is a function of (number of opposing vectors, kp) only, so the summation order does not depend on the sharding.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "glrm_engine.hpp"
+#include "glrm_tiled.hpp"
+
+using namespace glrm;
+
+constexpr int BNW = 4;                                                     // waves per workgroup
+constexpr int tile_rows_b(int kp) { return ((150 * 1024) / (kp * 8 + 16)) / 16 * 16; } // the LDS tile unit the super-tiles are counted in
+
+int glrm_setup_blocked(glrm_handle* h) {
+  h->blocked_row = h->blocked_col = 0;
+  const int want = env_int("GLRM_HIP_BLOCKED", h->tiled_opt == 1 ? 0 : -1); // -1 auto, else bit0 rows, bit1 columns (glrm_options.tiled = 1: gather sweeps only)
+  if (want == 0 || h->kp < 8) return GLRM_OK;
+  hipDeviceProp_t prop;
+  HIPCK(hipGetDeviceProperties(&prop, h->device));
+  const int64_t cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  const int T = tile_rows_b(h->kp);
+  auto decide = [&](bool rows) -> bool {
+    if (rows ? h->tiled_row : h->tiled_col) return false;          // the LDS-tiled sweep already owns this view
+    if (!(rows ? h->rows_sorted : h->cols_sorted)) return false;   // a group must meet the opposing factor front to back
+    const int64_t nseg = rows ? h->ml : h->nl, nnz = rows ? h->nnz_r : h->nnz_c, nopp = rows ? h->n : h->m;
+    if (nseg <= 0 || nnz <= 0) return false;
+    if (want > 0) return ((want >> (rows ? 0 : 1)) & 1) != 0;
+    // The choice is made from the GLOBAL problem (m, n, mean list length), not from the shard, so that every shard count runs the
+    // same family (the families differ in summation order).
+    const double opp_bytes = (double)nopp * h->kp * 8;
+    const int64_t nseg_glob = rows ? h->m : h->n;
+    const double mean_len = (double)nnz / (double)nseg;
+    if (opp_bytes <= 32.0 * 1024 * 1024 || mean_len * (double)nseg_glob < 2e8) return false; // small factor: LDS tiles or plain L2 hits do better
+    // observations that meet one vector of the opposing factor while the groups the chip holds (4 waves per SIMD) walk past it, per XCD
+    const double resident = std::min<double>((double)nseg_glob, (double)cus * 16 * (64 / h->G));
+    const double reuse = resident * mean_len / (double)nopp / 8.0;
+    return reuse >= 2.0;
+  };
+  const bool br = decide(true), bc = decide(false);
+  auto sups = [&](int64_t nopp, int& tps, int& nsup) {
+    const int64_t ntiles = (nopp + T - 1) / T;
+    int64_t t = ((int64_t)128 * 1024 * 1024) / ((int64_t)T * h->kp * 8); // ~128 MB of the opposing factor per super-tile
+    t = env_int("GLRM_HIP_BLOCKED_TPS", (int)(t < 1 ? 1 : t));
+    tps = (int)t;
+    nsup = (int)((ntiles + t - 1) / t);
+  };
+  if (br) {
+    sups(h->n, h->tiles_per_sup_r, h->nsup_r);
+    const int64_t ml1 = h->ml > 0 ? h->ml : 1;
+    HIPCK(hipMalloc((void**)&h->part_r, (size_t)ml1 * h->nsup_r * (h->kp + 2) * 8));
+    HIPCK(hipMalloc((void**)&h->gsum_r, (size_t)ml1 * h->kp * 8));
+    HIPCK(hipMalloc((void**)&h->trial_r, (size_t)ml1 * h->kp * 8));
+    HIPCK(hipMalloc((void**)&h->jold_r, (size_t)ml1 * 8));
+    HIPCK(hipMalloc((void**)&h->active_r, (size_t)ml1 * 4));
+    HIPCK(hipMalloc((void**)&h->ntrial_r, (size_t)ml1 * 4));
+    h->blocked_row = 1;
+  }
+  if (bc) {
+    sups(h->m, h->tiles_per_sup, h->nsup);
+    const int64_t nl1 = h->nl > 0 ? h->nl : 1;
+    HIPCK(hipMalloc((void**)&h->part, (size_t)nl1 * h->nsup * (h->kp + 2) * 8));
+    HIPCK(hipMalloc((void**)&h->gsum, (size_t)nl1 * h->kp * 8));
+    HIPCK(hipMalloc((void**)&h->trialbuf, (size_t)nl1 * h->kp * 8));
+    HIPCK(hipMalloc((void**)&h->joldbuf, (size_t)nl1 * 8));
+    HIPCK(hipMalloc((void**)&h->activebuf, (size_t)nl1 * 4));
+    HIPCK(hipMalloc((void**)&h->ntrialbuf, (size_t)nl1 * 4));
+    h->blocked_col = 1;
+  }
+  if ((br || bc) && !h->nactive) HIPCK(hipMalloc((void**)&h->nactive, 4));
+  return GLRM_OK;
+}
+
+// segments one launch may cover: what the chip holds at once (every group of the launch then starts its walk together)
+template <typename K>
+static int64_t slice_capacity(K kernel, int device, int spb) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, BNW * 64, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+  hipDeviceProp_t prop;
+  int cus = 256;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+  const int64_t cap = (int64_t)nb * cus * spb;
+  const int pct = env_int("GLRM_HIP_BLOCKED_FILL", 100); // percent of the residency to use per launch
+  return std::max<int64_t>(spb, cap * pct / 100 / spb * spb);
+}
+
+template <int G, int R, int LOSS, bool GRAD>
+static int launch_blocked_inst(glrm_handle* h, TiledArgs a) {
+  constexpr int KP = G * R, T = tile_rows_b(KP), SPB = BNW * (64 / G);
+  auto kernel = tiled_col_pass_kernel<G, R, BNW, T, LOSS, GRAD, true>;
+  static int64_t cap = 0; // per instantiation
+  if (cap == 0) cap = slice_capacity(kernel, h->device, SPB);
+  const int64_t nseg = a.nseg;
+  for (int sup = 0; sup < a.nsup; ++sup) {
+    for (int64_t s0 = 0; s0 < nseg; s0 += cap) {
+      a.sup_fixed = sup;
+      a.seg_begin = s0;
+      a.nseg_slice = std::min(cap, nseg - s0);
+      hipLaunchKernelGGL(kernel, dim3((unsigned)((a.nseg_slice + SPB - 1) / SPB)), dim3(BNW * 64), 0, h->stream, a);
+    }
+  }
+  HIPCK(hipGetLastError());
+  return GLRM_OK;
+}
+
+template <int G, int R>
+static int launch_blocked_layout(glrm_handle* h, int loss, bool grad, const TiledArgs& a) {
+#define GLRM_BL(LOSSV) (grad ? launch_blocked_inst<G, R, LOSSV, true>(h, a) : launch_blocked_inst<G, R, LOSSV, false>(h, a))
+  switch (loss) {
+    case LOSS_QUAD_UNIFORM: return GLRM_BL(0);
+    case LOSS_SEGMENT: return GLRM_BL(1);
+    case LOSS_SEGMENT_NOTRIG: return GLRM_BL(3);
+    case LOSS_PER_OBS_NOTRIG: return GLRM_BL(4);
+    default: return GLRM_BL(2);
+  }
+#undef GLRM_BL
+}
+
+static int launch_blocked(glrm_handle* h, int loss, bool grad, const TiledArgs& a) {
+  switch (h->G * 100 + h->R) {
+    case 402: return launch_blocked_layout<4, 2>(h, loss, grad, a);
+    case 404: return launch_blocked_layout<4, 4>(h, loss, grad, a);
+    case 408: return launch_blocked_layout<4, 8>(h, loss, grad, a);
+    case 808: return launch_blocked_layout<8, 8>(h, loss, grad, a);
+    case 1608: return launch_blocked_layout<16, 8>(h, loss, grad, a);
+    default: return fail(GLRM_ERR_UNSUPPORTED, "no phase-aligned pass kernel for lane layout G=%d R=%d", h->G, h->R);
+  }
+}
+
+int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only) {
+  TiledArgs a{};
+  a.nseg = rows ? h->ml : h->nl;
+  a.ptr = rows ? h->rowptr : h->colptr;
+  a.idx = rows ? h->colidx : h->rowidx;
+  a.vals = rows ? h->rowvals : h->colvals;
+  a.own = rows ? h->X : h->Y;
+  a.own_offset = rows ? h->rb : h->cb;
+  a.other = rows ? h->Y : h->X;
+  a.n_other = rows ? h->n : h->m;
+  a.alpha = rows ? h->alpharow : h->alphacol;
+  a.obj = rows ? nullptr : h->objcol;
+  a.losses = h->losses;
+  a.loss_by_segment = loss_by_segment;
+  a.regs = rows ? h->rx : h->ry;
+  a.reg_single = (rows ? h->n_rx : h->n_ry) == 1;
+  a.k = h->k;
+  a.min_stepsize = min_stepsize;
+  a.trials = rows ? h->trials_r : h->trials_c;
+  a.accepts = rows ? h->accepts_r : h->accepts_c;
+  a.eval_only = eval_only;
+  a.fixed_alpha = eval_only ? 0.0 : h->fixed_alpha;
+  a.nsup = rows ? h->nsup_r : h->nsup;
+  a.tiles_per_sup = rows ? h->tiles_per_sup_r : h->tiles_per_sup;
+  a.part = rows ? h->part_r : h->part;
+  a.gsum = rows ? h->gsum_r : h->gsum;
+  a.trial = rows ? h->trial_r : h->trialbuf;
+  a.jold = rows ? h->jold_r : h->joldbuf;
+  a.active = rows ? h->active_r : h->activebuf;
+  a.ntrial = rows ? h->ntrial_r : h->ntrialbuf;
+  a.nactive = h->nactive;
+  if (rows && h->rng_e >= 0) { // glrm_hip_step_x_range: local rows [rng_b, rng_e)
+    const int64_t s0 = h->rng_b;
+    a.nseg = h->rng_e - s0;
+    if (a.nseg <= 0) return GLRM_OK;
+    a.ptr += s0; a.alpha += s0; a.own_offset += s0;
+    if (!a.reg_single) a.regs += s0;
+    a.trials += s0; a.accepts += s0;
+    a.part += s0 * (int64_t)a.nsup * (h->kp + 2); a.gsum += s0 * (int64_t)h->kp; a.trial += s0 * (int64_t)h->kp;
+    a.jold += s0; a.active += s0; a.ntrial += s0;
+  }
+  int rc;
+  HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
+  if ((rc = launch_blocked(h, loss, true, a))) return rc;        // gradient + loss partials, super-tile by super-tile
+  glrm_launch_col_small(h->kp, 0, a, h->stream);                 // reduce in super-tile order, J_old, first trial point
+  HIPCK(hipGetLastError());
+  if (eval_only || a.fixed_alpha > 0.0) return GLRM_OK;
+  for (int round = 0; round < 64; ++round) {
+    unsigned int nact = 0;
+    HIPCK(hipMemcpyAsync(&nact, h->nactive, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    if (nact == 0) break;
+    HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
+    if ((rc = launch_blocked(h, loss, false, a))) return rc;     // loss partials at the trial points of the searching segments
+    glrm_launch_col_small(h->kp, 1, a, h->stream);               // accept / shrink / give up, next trial point
+    HIPCK(hipGetLastError());
+  }
+  return GLRM_OK;
+}

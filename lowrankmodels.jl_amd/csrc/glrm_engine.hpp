@@ -51,7 +51,9 @@ struct glrm_handle {
   int tiled_row = 0, tiled_col = 0;   // 0 = gather sweep, 1 = tiled
   int tG = 4, tR = 2;                 // lane layout of the tiled kernels (kp = tG*tR)
   int tile_cfg = 0;                   // 0: 8 waves + ~64 KB tile, 1: 16 waves + ~128 KB tile
+  bool tile_cfg12 = false;            // GLRM_HIP_TILE_CFG=2: heterogeneous row sweep on 12 waves
   int nsup = 0, tiles_per_sup = 0;
+  int blocked_row = 0, blocked_col = 0; // phase-aligned gather passes (glrm_blocked.hip) instead of the one-kernel gather sweep
   int row_split = 0, tiles_per_sup_r = 0; // row sweep in super-tile passes (nsup_r super-tiles; buffers part_r ... ntrial_r below)
   double *part = nullptr, *gsum = nullptr, *trialbuf = nullptr, *joldbuf = nullptr;
   int32_t *activebuf = nullptr, *ntrialbuf = nullptr;
@@ -130,6 +132,10 @@ inline int env_int(const char* name, int dflt) {
 // LDS-tiled sweeps (glrm_tiled.hip)
 int glrm_setup_tiled(glrm_handle* h);
 int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only);
+
+// phase-aligned gather passes (glrm_blocked.hip): setup decides blocked_row / blocked_col and allocates the pass buffers
+int glrm_setup_blocked(glrm_handle* h);
+int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only);
 
 // stable segmented sort of a view by tile index (glrm_tilesort.hip)
 int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals);

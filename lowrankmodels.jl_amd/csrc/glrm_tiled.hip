@@ -48,7 +48,9 @@ static int make_segperm(glrm_handle* h, bool rows, int32_t** out) {
 int glrm_setup_tiled(glrm_handle* h) {
   hipStream_t st = h->stream;
   int rc0 = GLRM_OK;
-  h->tile_cfg = env_int("GLRM_HIP_TILE_CFG", 1) ? 1 : 0;
+  h->tile_cfg = env_int("GLRM_HIP_TILE_CFG", 1);
+  h->tile_cfg12 = h->tile_cfg == 2; // experiment: 12-wave heterogeneous row sweep
+  h->tile_cfg = h->tile_cfg ? 1 : 0;
   h->tG = h->G;
   h->tR = h->R;
   const int T0 = tile_rows(h->kp, h->tile_cfg);
@@ -179,7 +181,8 @@ int glrm_setup_tiled(glrm_handle* h) {
   h->row_split = 0;
   if (h->tiled_row) {
     const int64_t ybytes = h->n * (int64_t)h->kp * 8;
-    const int want_split = env_int("GLRM_HIP_ROW_SPLIT", ybytes > (int64_t)3 * 1024 * 1024 ? 1 : 0);
+    (void)ybytes;
+    const int want_split = env_int("GLRM_HIP_ROW_SPLIT", 0); // measured: no gain (the staged tiles already hit L2 at 88 %); kept as an experiment switch
     if (want_split) {
       const int64_t nt = (h->n + T - 1) / T;
       int64_t tps = ((int64_t)5 * 512 * 1024) / ((int64_t)T * h->kp * 8);
@@ -232,6 +235,12 @@ static int launch_tiled_inst(int kind, const TiledArgs& a, hipStream_t st) {
 template <int G, int R>
 static int launch_tiled_layout(int cfg, int loss, int kind, const TiledArgs& a, hipStream_t st) {
   constexpr int KP = G * R, T0 = tile_rows_c(KP, 0), T1 = tile_rows_c(KP, 1);
+  if constexpr ((G == 4 || G == 8) && R == 8) {
+    // heterogeneous row sweep on 12 waves (3 per SIMD, 168 VGPRs: no spills) instead of 16 (128 VGPRs, ~45 spilled)
+    if (cfg == 2 && kind == 0 && a.fixed_alpha <= 0.0 && (loss == LOSS_PER_OBS || loss == LOSS_PER_OBS_NOTRIG))
+      return loss == LOSS_PER_OBS ? launch_tiled_inst<G, R, 12, T1, 2>(kind, a, st) : launch_tiled_inst<G, R, 12, T1, 4>(kind, a, st);
+  }
+  if (cfg == 2) cfg = 1;
 #define GLRM_TL(LOSSV)                                                                   \
   (cfg ? launch_tiled_inst<G, R, 16, T1, LOSSV>(kind, a, st) : launch_tiled_inst<G, R, 8, T0, LOSSV>(kind, a, st))
   switch (loss) {
@@ -245,12 +254,13 @@ static int launch_tiled_layout(int cfg, int loss, int kind, const TiledArgs& a, 
 }
 
 static int launch_tiled(glrm_handle* h, int loss, int kind, const TiledArgs& a) {
+  const int cfg = (h->tile_cfg12 && h->tile_cfg) ? 2 : h->tile_cfg;
   switch (h->tG * 100 + h->tR) {
-    case 402: return launch_tiled_layout<4, 2>(h->tile_cfg, loss, kind, a, h->stream);
-    case 404: return launch_tiled_layout<4, 4>(h->tile_cfg, loss, kind, a, h->stream);
-    case 408: return launch_tiled_layout<4, 8>(h->tile_cfg, loss, kind, a, h->stream);
-    case 808: return launch_tiled_layout<8, 8>(h->tile_cfg, loss, kind, a, h->stream);
-    case 1608: return launch_tiled_layout<16, 8>(h->tile_cfg, loss, kind, a, h->stream);
+    case 402: return launch_tiled_layout<4, 2>(cfg, loss, kind, a, h->stream);
+    case 404: return launch_tiled_layout<4, 4>(cfg, loss, kind, a, h->stream);
+    case 408: return launch_tiled_layout<4, 8>(cfg, loss, kind, a, h->stream);
+    case 808: return launch_tiled_layout<8, 8>(cfg, loss, kind, a, h->stream);
+    case 1608: return launch_tiled_layout<16, 8>(cfg, loss, kind, a, h->stream);
     default: return fail(GLRM_ERR_UNSUPPORTED, "no tiled kernel for lane layout G=%d R=%d", h->tG, h->tR);
   }
 }

@@ -62,6 +62,10 @@ struct TiledArgs {
   const uint8_t* descid;  // per entry of the view
   const glrm_loss* udesc; // n_udesc distinct descriptors
   int n_udesc;
+  // phase-aligned gather passes (tiled_col_pass_kernel<..., L2 = true>): the launch covers segments [seg_begin, seg_begin + nseg_slice)
+  // of super-tile sup_fixed
+  int64_t seg_begin, nseg_slice;
+  int sup_fixed;
   const int32_t* segperm; // lane-group slot -> local segment (nullptr = identity).  Which segment a group works on changes no sum:
                           // columns are handed out sorted by (loss kind, length), rows by length, so that the 16 groups of a wave
                           // evaluate the same loss formula and finish their lists together.
@@ -127,11 +131,18 @@ __device__ __forceinline__ void stage_tile(const double* __restrict__ other, int
 //   g, J    outputs: gradient (GRAD) and loss sum of the segment's observations inside those tiles
 //   pos     in/out: position in the segment's list (first entry with idx >= tile_begin*TILE on entry)
 //   active  group-uniform; inactive groups only take part in staging and barriers
-template <int G, int R, int NW, int TILE, int LOSS, bool GRAD>
+//
+// L2 = true is the same walk WITHOUT the LDS tile: the group reads the opposing vectors of its observations straight from memory
+// (one 16-byte load per lane and 2G components) and [tile_begin, tile_end) is one range that is walked in a single go, with no
+// barrier.  It is what the phase-aligned pass kernels below run: when every group in flight walks its sorted list through the same
+// super-tile at the same time, those reads hit the 4 MB L2 of the XCD (~30 TB/s) instead of the Infinity Cache / HBM (6.5-8 TB/s,
+// profiles/r02_ubench_gather.txt).
+template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false>
 __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const Vec<G, R>& xv, Vec<G, R>& g, double& J,
                                            bool active, int64_t& pos, int64_t end, int tile_begin, int tile_end,
                                            const LossDesc& segloss, int lane, int j) {
-  constexpr int ROWB = tile_row_bytes<G, R>(), NT = NW * 64;
+  constexpr int ROWB = L2 ? G * R * 8 : tile_row_bytes<G, R>(), NT = NW * 64;
+  const char* const mem = L2 ? reinterpret_cast<const char*>(a.other) : lds; // where the opposing vectors are read from
   constexpr bool FOUR = (G == 4 || G == 8) && LOSS != 0; // the whole batch of G observations per step (below)
   const double two_scale = 2 * segloss.scale;
   J = 0.0;
@@ -145,7 +156,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
   // into the segment, validity applied when the entry is used) so that the compiler can keep the prefetch of
   // the next batch in flight with a counted s_waitcnt instead of draining the queue at every branch merge.
   const int64_t last = end > 0 ? end - 1 : 0; // idx/vals always hold at least one element
-  constexpr bool UDESC = FOUR && loss_mode(LOSS) == 2; // descriptor ids travel with the entries (see TiledArgs::descid)
+  constexpr bool UDESC = FOUR && loss_mode(LOSS) == 2 && !L2; // descriptor ids travel with the entries (see TiledArgs::descid)
   const uint8_t* __restrict__ descid = a.descid;
   const bool have_ids = UDESC && descid != nullptr;    // uniform
   const char* udesc_lds = lds + TILE * ROWB;            // the kernel staged the distinct descriptors there
@@ -160,12 +171,15 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
   double ab;
   load_entry(pos + j, cb, ab, db);
   if (!(active && pos + j < end)) cb = 0x7fffffff;
-  for (int t = tile_begin; t < tile_end; ++t) {
+  for (int t = tile_begin; t < (L2 ? tile_begin + 1 : tile_end); ++t) {
     const int64_t lo = (int64_t)t * TILE;
-    const int64_t hi = lo + TILE < a.n_other ? lo + TILE : a.n_other;
-    __syncthreads(); // everybody is done with the previous tile
-    stage_tile<G, R, NT>(a.other, lo, hi, lds);
-    __syncthreads();
+    const int64_t hi_ = L2 ? (int64_t)tile_end * TILE : lo + TILE;
+    const int64_t hi = hi_ < a.n_other ? hi_ : a.n_other;
+    if constexpr (!L2) {
+      __syncthreads(); // everybody is done with the previous tile
+      stage_tile<G, R, NT>(a.other, lo, hi, lds);
+      __syncthreads();
+    }
     bool done = !active;
     while (!done) {
       int cn, dn; // prefetch the next batch while this one is consumed
@@ -193,13 +207,14 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
           ok[u] = (u == 0 || ok[u - 1]) && c[u] < (int)hi; // c == INT_MAX past the end of the segment
         }
         if (ok[0]) {
-          const char* base = lds + j * 16 - (int)lo * ROWB;
+          const char* base = L2 ? mem + j * 16 : mem + j * 16 - (int)lo * ROWB;
           const char* rp[G];
           double p[G];
           bool mine = false;
 #pragma unroll
           for (int u = 0; u < G; ++u) {
-            rp[u] = base + (ok[u] ? c[u] : c[0]) * ROWB;
+            if constexpr (L2) rp[u] = base + (int64_t)(ok[u] ? c[u] : c[0]) * ROWB;
+            else rp[u] = base + (ok[u] ? c[u] : c[0]) * ROWB;
             mine = (j == u) ? ok[u] : mine;
             p[u] = 0.0;
 #pragma unroll
@@ -270,8 +285,8 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
         const bool ok0 = !done && c0 < (int)hi; // c == INT_MAX past the end of the segment
         const bool ok1 = ok0 && c1 < (int)hi;
         if (ok0) {
-          const char* rp0 = lds + (c0 - (int)lo) * ROWB + j * 16;
-          const char* rp1 = lds + ((ok1 ? c1 : c0) - (int)lo) * ROWB + j * 16;
+          const char* rp0 = L2 ? mem + (int64_t)c0 * ROWB + j * 16 : mem + (c0 - (int)lo) * ROWB + j * 16;
+          const char* rp1 = L2 ? mem + (int64_t)(ok1 ? c1 : c0) * ROWB + j * 16 : mem + ((ok1 ? c1 : c0) - (int)lo) * ROWB + j * 16;
           double2 y0[R / 2], y1[R / 2];
 #pragma unroll
           for (int i = 0; i < R / 2; ++i) y0[i] = *reinterpret_cast<const double2*>(rp0 + i * (2 * G * 8));
@@ -366,7 +381,7 @@ __device__ __forceinline__ void stage_udesc(const TiledArgs& a, char* lds) {
 // FIXED = true is the SparseProxGradParams step (one gradient pass, x <- prox(x - (alpha/l) g), no line search); it is a
 // separate instantiation so that the line-search kernel keeps its register budget.
 template <int G, int R, int NW, int TILE, int LOSS, bool FIXED>
-__global__ void __launch_bounds__(NW * 64, 4) tiled_sweep_kernel(const TiledArgs a) {
+__global__ void __launch_bounds__(NW * 64, NW == 12 ? 3 : 4) tiled_sweep_kernel(const TiledArgs a) {
   constexpr int KP = G * R, NGW = 64 / G, SPB = NW * NGW;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -475,19 +490,23 @@ __device__ __forceinline__ int64_t lower_bound_idx(const int32_t* idx, int64_t b
 
 // GRAD = true: pass 1 (gradient + loss partials at the current point a.own);
 // GRAD = false: trial pass (loss partials at a.trial for the still-active segments).
-template <int G, int R, int NW, int TILE, int LOSS, bool GRAD>
-__global__ void __launch_bounds__(NW * 64, 4) tiled_col_pass_kernel(const TiledArgs a) {
+//
+// L2 = true: the phase-aligned gather pass (no LDS tile, tiled_pass<..., L2>).  One launch covers ONE super-tile (a.sup_fixed) and
+// a slice [a.seg_begin, a.seg_begin + a.nseg_slice) of the segments that is at most what the chip holds at once, so every group of
+// the launch starts its walk through the super-tile at the same moment; the host issues the launches super-tile by super-tile.
+template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false>
+__global__ void __launch_bounds__(NW * 64, L2 ? 1 : 4) tiled_col_pass_kernel(const TiledArgs a) {
   constexpr int KP = G * R, NGW = 64 / G, SPB = NW * NGW, PSTRIDE = KP + 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % G, gi = lane / G;
-  const int64_t slot = (int64_t)blockIdx.x * SPB + wave * NGW + gi;
-  const int sup = blockIdx.y;
-  bool have = slot < a.nseg;
+  const int64_t slot = (L2 ? a.seg_begin : 0) + (int64_t)blockIdx.x * SPB + wave * NGW + gi;
+  const int sup = L2 ? a.sup_fixed : (int)blockIdx.y;
+  bool have = slot < (L2 ? a.seg_begin + a.nseg_slice : a.nseg);
   const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[slot] : slot; // which column a group works on does not change any sum
   if (!GRAD && have) have = a.active[seg] != 0;
   if (!GRAD && !__syncthreads_or(have ? 1 : 0)) return; // nothing left to evaluate in this column group
-  stage_udesc<G, R, NW, TILE, LOSS>(a, lds);
+  if constexpr (!L2) stage_udesc<G, R, NW, TILE, LOSS>(a, lds);
   const int64_t beg = have ? a.ptr[seg] : 0, end = have ? a.ptr[seg + 1] : 0;
   const int64_t gseg = a.own_offset + (have ? seg : 0);
   const int ntiles = (int)((a.n_other + TILE - 1) / TILE);
@@ -501,7 +520,7 @@ __global__ void __launch_bounds__(NW * 64, 4) tiled_col_pass_kernel(const TiledA
   if constexpr (loss_mode(LOSS) != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
   int64_t pos = have ? lower_bound_idx<G>(a.idx, beg, end, (int64_t)tb * TILE) : 0;
   double J;
-  tiled_pass<G, R, NW, TILE, LOSS, GRAD>(a, lds, x, g, J, have, pos, end, tb, te, segloss, lane, j);
+  tiled_pass<G, R, NW, TILE, LOSS, GRAD, L2>(a, lds, x, g, J, have, pos, end, tb, te, segloss, lane, j);
   if (have) {
     double* p = a.part + ((int64_t)seg * a.nsup + sup) * PSTRIDE;
     if (GRAD) {
