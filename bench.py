@@ -114,15 +114,13 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
         cands.append(dict(bound="lds", achieved=nnz * P * 8 * ld / t / 1e9, peak=LDS_PEAK_GBS, unit="GB/s", per_launch=nnz * P * 8 * ld,
                           what="LDS reads: one opposing vector (8 ld bytes) per update and pass"))
     elif family == "blocked":
-        # groups in flight walk the opposing factor together: its bytes cross the fabric once per XCD, slice of segments and pass; the
-        # gathers themselves are L2 traffic; partial sums (ld + 2 doubles per segment and super-tile) are written and read once
-        nsup = max(1, -(-opp // (128 * 2 ** 20)))
-        slices = max(1, -(-nseg // (256 * 16 * (64 // max(ld // 8, 4)))))
-        fabric = stream + 8 * slices * P * opp + 2 * nseg * nsup * (ld + 2) * 8 + 4 * nseg * ld * 8
-        cands.append(dict(bound="hbm", achieved=fabric / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=fabric,
-                          what="fabric bytes: P x 12 B x |Omega| + own factor r/w + partial sums + the opposing factor once per XCD, slice and pass"))
-        cands.append(dict(bound="l2", achieved=nnz * P * 8 * k / t / 1e9, peak=L2_PEAK_GBS, unit="GB/s", per_launch=nnz * P * 8 * k,
-                          what="k-vector gathers served by the L2 of the XCD (phase-aligned walk): P x 8k bytes per update"))
+        # phase-aligned gather passes: every update still fetches its k-vector from the memory system; what the phase alignment buys is
+        # that the window all groups read at a time sits in the Infinity Cache (measured 8.2 TB/s for random 512-byte reads against
+        # 6.5 TB/s from HBM, profiles/r02_ubench_gather.txt) and partly in L2 (TCC hit rate ~21 % at C4).  Same byte model as the
+        # one-kernel gather sweep, so the two families are comparable; `traffic` (PMC) shows what reached the fabric.
+        cands.append(dict(bound="hbm", achieved=alg / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=alg,
+                          what="SURVEY 8(d) algorithmic bytes: P x (12 + 8k) per update (k-vector gathers served by Infinity Cache / HBM, "
+                               "L2 hits where the phase-aligned walk keeps the window resident)"))
     else:
         if opp > MALL_BYTES or family == "general":  # the opposing factor cannot stay on chip: the gathers are HBM traffic
             cands.append(dict(bound="hbm", achieved=alg / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=alg,
@@ -227,7 +225,7 @@ def jref_leg(args, cfg, api, device):
 
 # ----------------------------------------------------------------------------- PMC traffic (rank 0, N = 1 only)
 
-def pmc_traffic(args, kernel_re):
+def pmc_traffic(args, kernel_re, per_halfstep=False, child_env=None):
     """HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and
     WRITE_SIZE in SEPARATE passes (TCC slots), FETCH_SIZE doubled on gfx950 (128-B requests tallied at 64 B); both counters are in KiB.
     Each pass re-runs this script as a child (same config, 2 timed steps) under `rocprofv3 --pmc <counter>`; the mean over the
@@ -242,7 +240,7 @@ def pmc_traffic(args, kernel_re):
                "--config", args.config, "--rows", str(args.rows), "--steps", "2", "--warmup", str(max(args.warmup, 1)), "--tiled", str(args.tiled),
                "--no-cpu-baseline", "--no-convergence-run", "--no-jref", "--pmc", "off", "--seed", str(args.seed),
                "--cols", str(args.cols), "--obs-per-row", str(args.obs_per_row), "--rank", str(args.k)]
-        env = dict(os.environ, TMPDIR="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", **(child_env or {}))
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
             try:
@@ -258,12 +256,15 @@ def pmc_traffic(args, kernel_re):
                         vals.append(float(r["Counter_Value"]))
             if not vals:
                 return None, f"PMC pass {ctr}: no dispatch matching /{kernel_re}/ in the counter CSV (exit {p.returncode})"
-            out[ctr] = (sum(vals) / len(vals), len(vals))
+            # one-kernel sweeps: mean over the dispatches; pass families (several launches per half-step): total over the child's
+            # dispatches / its half-steps (warm-up + 2 timed; the initial objective evaluation adds one gradient-type pass for columns)
+            halfsteps = max(args.warmup, 1) + 2
+            out[ctr] = (sum(vals) / (halfsteps if per_halfstep else len(vals)), len(vals))
         finally:
             shutil.rmtree(d, ignore_errors=True)
     fetch, write = out["FETCH_SIZE"][0] * 1024.0 * 2.0, out["WRITE_SIZE"][0] * 1024.0
     return fetch + write, (f"in-run rocprofv3 --pmc passes of this config: 2 x FETCH_SIZE ({out['FETCH_SIZE'][0]:.4g} KiB, gfx950 correction) + "
-                           f"WRITE_SIZE ({out['WRITE_SIZE'][0]:.4g} KiB), mean over {out['FETCH_SIZE'][1]} dispatches matching /{kernel_re}/")
+                           f"WRITE_SIZE ({out['WRITE_SIZE'][0]:.4g} KiB), {'total of' if per_halfstep else 'mean over'} {out['FETCH_SIZE'][1]} dispatches matching /{kernel_re}/{' divided by the half-steps of the child run' if per_halfstep else ''}")
 
 
 # ----------------------------------------------------------------------------- main
@@ -444,7 +445,11 @@ def main():
                 if dom_fam == "gather":  # row and column sweeps are instantiations of one template: tell them apart by WAVES
                     wv = st["waves_row"] if dom == "row" else st["waves_col"]
                     kre = r"(?<!tiled_)sweep_kernel<\d+, \d+, %d, \d+, \d+, false>" % wv
-                traffic, traffic_src = pmc_traffic(args, kre)
+                # the row and the column pass of the blocked family are the same kernel instantiation: the child runs only the dominant
+                # side on it (the other side on the one-kernel gather sweep), so its dispatches can be told apart by name
+                cenv = {"GLRM_HIP_BLOCKED": "1" if dom == "row" else "2"} if dom_fam == "blocked" else None
+                traffic, traffic_src = pmc_traffic(args, kre, per_halfstep=dom_fam == "blocked" or (dom_fam == "tiled" and dom == "col"),
+                                                   child_env=cenv)
                 if traffic is not None and dom_fam == "gather" and st["waves_row"] == st["waves_col"]:
                     traffic_src += " (row and column sweeps run the same instantiation here: the mean is over both)"
             except Exception as e:  # the bench line must survive a profiler problem
