@@ -113,18 +113,15 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
                           what="tile staging: workgroups x P x opposing factor bytes (L2 -> LDS)"))
         cands.append(dict(bound="lds", achieved=nnz * P * 8 * ld / t / 1e9, peak=LDS_PEAK_GBS, unit="GB/s", per_launch=nnz * P * 8 * ld,
                           what="LDS reads: one opposing vector (8 ld bytes) per update and pass"))
-    elif family == "blocked":
-        # phase-aligned gather passes: every update still fetches its k-vector from the memory system; what the phase alignment buys is
-        # that the window all groups read at a time sits in the Infinity Cache (measured 8.2 TB/s for random 512-byte reads against
-        # 6.5 TB/s from HBM, profiles/r02_ubench_gather.txt) and partly in L2 (TCC hit rate ~21 % at C4).  Same byte model as the
-        # one-kernel gather sweep, so the two families are comparable; `traffic` (PMC) shows what reached the fabric.
-        cands.append(dict(bound="hbm", achieved=alg / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=alg,
-                          what="SURVEY 8(d) algorithmic bytes: P x (12 + 8k) per update (k-vector gathers served by Infinity Cache / HBM, "
-                               "L2 hits where the phase-aligned walk keeps the window resident)"))
     else:
+        # 'gather' and 'blocked' share one byte model: every update fetches its k-vector from the memory system.  The phase-aligned
+        # passes ('blocked') only change WHERE the window all groups read at a time sits: in the Infinity Cache (measured 8.2 TB/s
+        # for random 512-byte reads against 6.5 TB/s from HBM, profiles/r02_ubench_gather.txt) and partly in L2 (TCC hit rate ~21 %
+        # at C4); `traffic` (PMC) shows what reached the fabric.
         if opp > MALL_BYTES or family == "general":  # the opposing factor cannot stay on chip: the gathers are HBM traffic
             cands.append(dict(bound="hbm", achieved=alg / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=alg,
-                              what="SURVEY 8(d) algorithmic bytes: P x (12 + 8k) per update (random k-vector gathers from HBM)"))
+                              what="SURVEY 8(d) algorithmic bytes: P x (12 + 8k) per update (random k-vector gathers from HBM"
+                                   + ("; phase-aligned passes keep the window being read in the Infinity Cache)" if family == "blocked" else ")")))
         else:  # the opposing factor fits the Infinity Cache / L2: HBM sees the streams, the gathers are cache traffic
             cands.append(dict(bound="hbm", achieved=(stream + opp) / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=stream + opp,
                               what="compulsory HBM bytes: P x 12 B x |Omega| + own factor r/w + opposing factor once"))
