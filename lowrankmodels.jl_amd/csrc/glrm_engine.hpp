@@ -51,6 +51,7 @@ struct glrm_handle {
   int tiled_row = 0, tiled_col = 0;   // 0 = gather sweep, 1 = tiled
   int tG = 4, tR = 2;                 // lane layout of the tiled kernels (kp = tG*tR)
   int tile_cfg = 0;                   // 0: 8 waves + ~64 KB tile, 1: 16 waves + ~128 KB tile
+  int tile_lw = 0, tile_lw_sides = 1; // loader waves per workgroup of the double-buffered tiled sweeps; which sides use them
   bool tile_cfg12 = false;            // GLRM_HIP_TILE_CFG=2: heterogeneous row sweep on 12 waves
   int nsup = 0, tiles_per_sup = 0;
   int blocked_row = 0, blocked_col = 0; // phase-aligned gather passes (glrm_blocked.hip) instead of the one-kernel gather sweep

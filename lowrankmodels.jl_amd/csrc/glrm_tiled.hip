@@ -50,10 +50,15 @@ int glrm_setup_tiled(glrm_handle* h) {
   int rc0 = GLRM_OK;
   h->tile_cfg = env_int("GLRM_HIP_TILE_CFG", 1);
   h->tile_cfg12 = h->tile_cfg == 2; // experiment: 12-wave heterogeneous row sweep
+  h->tile_lw = env_int("GLRM_HIP_TILE_LW", 0); // loader waves of the double-buffered tiled sweeps (0 = single tile, everybody stages)
+  if (h->tile_lw < 0 || h->tile_lw > 2 || !((h->G == 4 || h->G == 8) && h->R == 8)) h->tile_lw = 0;
+  h->tile_lw_sides = env_int("GLRM_HIP_TILE_LW_SIDES", 1); // bit0: row sweep, bit1: column passes
   h->tile_cfg = h->tile_cfg ? 1 : 0;
   h->tG = h->G;
   h->tR = h->R;
-  const int T0 = tile_rows(h->kp, h->tile_cfg);
+  // order granularity of the index lists: the entries of staged tile t must precede those of tile t+1; with loader waves the
+  // staged unit is HALF a tile (a list ordered by half tile is ordered by tile as well)
+  const int T0 = h->tile_lw > 0 ? tile_rows(h->kp, h->tile_cfg) / 2 : tile_rows(h->kp, h->tile_cfg);
   HIPCK(hipMalloc((void**)&h->dflag, 2 * sizeof(int)));
   HIPCK(hipMemsetAsync(h->dflag, 0, 2 * sizeof(int), st));
   if (h->ml > 0) hipLaunchKernelGGL(check_sorted_kernel, dim3((unsigned)h->ml), dim3(64), 0, st, h->rowptr, h->colidx, h->ml, T0, h->dflag);
@@ -77,7 +82,7 @@ int glrm_setup_tiled(glrm_handle* h) {
   // Auto choice (measured on MI355X, tests/perf/bench_small.py): the tiled sweeps need enough workgroups to fill 256 CUs and
   // enough observations to amortise their per-tile barriers; below ~2e7 observations per view the gather sweeps win (100k x 5k
   // at 1e7 observations: 1.06 vs 1.23 ms per iteration; 300k x 3k at 4.5e7: 4.6 vs 3.1 ms).
-  const int spb_auto = (h->tile_cfg ? 16 : 8) * (64 / h->tG);
+  const int spb_auto = ((h->tile_cfg ? 16 : 8) - h->tile_lw) * (64 / h->tG);
   const bool big_r = h->nnz_r >= 20000000 && h->ml >= (int64_t)512 * spb_auto;
   const bool big_c = h->nnz_c >= 20000000 && h->nl >= 256;
   bool want_row = want < 0 ? (per_tile_r >= 4.0 && big_r) : (want & 1) != 0;
@@ -88,11 +93,11 @@ int glrm_setup_tiled(glrm_handle* h) {
   const int tsort = env_int("GLRM_HIP_TILE_SORT", 1);
   const bool may_sort = tsort == 2 || (tsort == 1 && want < 0);
   if (want_row && !h->rows_sorted && may_sort) {
-    const int rc = glrm_tile_sort_view(st, h->rowptr, h->ml, h->nnz_r, T, h->n, &h->colidx, &h->rowvals);
+    const int rc = glrm_tile_sort_view(st, h->rowptr, h->ml, h->nnz_r, T0, h->n, &h->colidx, &h->rowvals);
     if (rc == GLRM_OK) h->rows_sorted = true; else if (rc != GLRM_ERR_UNSUPPORTED) return rc;
   }
   if (want_col && !h->cols_sorted && may_sort) {
-    const int rc = glrm_tile_sort_view(st, h->colptr, h->nl, h->nnz_c, T, h->m, &h->rowidx, &h->colvals);
+    const int rc = glrm_tile_sort_view(st, h->colptr, h->nl, h->nnz_c, T0, h->m, &h->rowidx, &h->colvals);
     if (rc == GLRM_OK) h->cols_sorted = true; else if (rc != GLRM_ERR_UNSUPPORTED) return rc;
   }
   h->tiled_row = (h->rows_sorted && want_row) ? 1 : 0;
@@ -102,7 +107,7 @@ int glrm_setup_tiled(glrm_handle* h) {
     double* ovals = nullptr;
     HIPCK(hipMalloc((void**)&oidx, (size_t)h->nnz_r * 4));
     if (hipMalloc((void**)&ovals, (size_t)h->nnz_r * 8) != hipSuccess) { (void)hipFree(oidx); return fail(GLRM_ERR_OOM, "out of device memory"); }
-    hipLaunchKernelGGL(group_rows_by_kind_kernel, dim3((unsigned)h->ml), dim3(64), 0, st, h->rowptr, h->colidx, h->rowvals, h->ml, T, h->losses, oidx, ovals);
+    hipLaunchKernelGGL(group_rows_by_kind_kernel, dim3((unsigned)h->ml), dim3(64), 0, st, h->rowptr, h->colidx, h->rowvals, h->ml, T0, h->losses, oidx, ovals);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(st));
     (void)hipFree(h->colidx);
@@ -209,25 +214,26 @@ static int set_lds(K kernel, int bytes) {
   return GLRM_OK;
 }
 
-// kind: 0 = whole sweep (tiled_sweep_kernel), 1 = column pass 1, 2 = column trial pass
-template <int G, int R, int NW, int TILE, int LOSS>
+// kind: 0 = whole sweep (tiled_sweep_kernel), 1 = column pass 1, 2 = column trial pass.  LW > 0: double-buffered half tiles, the
+// first LW waves of the workgroup are LDS-DMA loaders (glrm_tiled.hpp)
+template <int G, int R, int NW, int TILE, int LOSS, int LW = 0>
 static int launch_tiled_inst(int kind, const TiledArgs& a, hipStream_t st) {
-  constexpr int SPB = NW * (64 / G);
-  const int lds = TILE * tile_row_bytes<G, R>() + (loss_mode(LOSS) == 2 && a.descid ? a.n_udesc * 32 : 0);
+  constexpr int SPB = (NW - LW) * (64 / G);
+  const int lds = tile_lds_bytes<G, R, TILE, LW>() + (loss_mode(LOSS) == 2 && a.descid ? a.n_udesc * 32 : 0);
   const unsigned gx = (unsigned)((a.nseg + SPB - 1) / SPB);
   int rc = GLRM_OK;
   if (kind == 0 && a.fixed_alpha > 0.0) {
-    if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS, true>, lds))) return rc;
-    hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS, true>), dim3(gx), dim3(NW * 64), lds, st, a);
+    if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS, true, LW>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS, true, LW>), dim3(gx), dim3(NW * 64), lds, st, a);
   } else if (kind == 0) {
-    if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS, false>, lds))) return rc;
-    hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS, false>), dim3(gx), dim3(NW * 64), lds, st, a);
+    if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS, false, LW>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS, false, LW>), dim3(gx), dim3(NW * 64), lds, st, a);
   } else if (kind == 1) {
-    if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true>, lds))) return rc;
-    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
+    if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true, false, LW>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true, false, LW>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
   } else {
-    if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false>, lds))) return rc;
-    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
+    if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false, false, LW>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false, false, LW>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
   }
   return GLRM_OK;
 }
@@ -241,6 +247,20 @@ static int launch_tiled_layout(int cfg, int loss, int kind, const TiledArgs& a, 
       return loss == LOSS_PER_OBS ? launch_tiled_inst<G, R, 12, T1, 2>(kind, a, st) : launch_tiled_inst<G, R, 12, T1, 4>(kind, a, st);
   }
   if (cfg == 2) cfg = 1;
+  if constexpr ((G == 4 || G == 8) && R == 8) { // double-buffered half tiles with 1 / 2 loader waves (cfg 11 / 12)
+#define GLRM_TLW(LOSSV) (cfg == 11 ? launch_tiled_inst<G, R, 16, T1, LOSSV, 1>(kind, a, st) : launch_tiled_inst<G, R, 16, T1, LOSSV, 2>(kind, a, st))
+    if (cfg == 11 || cfg == 12) {
+      switch (loss) {
+        case LOSS_QUAD_UNIFORM: return GLRM_TLW(0);
+        case LOSS_SEGMENT: return GLRM_TLW(1);
+        case LOSS_SEGMENT_NOTRIG: return GLRM_TLW(3);
+        case LOSS_PER_OBS_NOTRIG: return GLRM_TLW(4);
+        default: return GLRM_TLW(2);
+      }
+    }
+#undef GLRM_TLW
+  }
+  if (cfg >= 11) cfg = 1;
 #define GLRM_TL(LOSSV)                                                                   \
   (cfg ? launch_tiled_inst<G, R, 16, T1, LOSSV>(kind, a, st) : launch_tiled_inst<G, R, 8, T0, LOSSV>(kind, a, st))
   switch (loss) {
@@ -254,7 +274,8 @@ static int launch_tiled_layout(int cfg, int loss, int kind, const TiledArgs& a, 
 }
 
 static int launch_tiled(glrm_handle* h, int loss, int kind, const TiledArgs& a) {
-  const int cfg = (h->tile_cfg12 && h->tile_cfg) ? 2 : h->tile_cfg;
+  const bool lw_here = h->tile_lw > 0 && h->tile_cfg && ((h->tile_lw_sides >> (kind == 0 ? 0 : 1)) & 1);
+  const int cfg = lw_here ? 10 + h->tile_lw : (h->tile_cfg12 && h->tile_cfg) ? 2 : h->tile_cfg;
   switch (h->tG * 100 + h->tR) {
     case 402: return launch_tiled_layout<4, 2>(cfg, loss, kind, a, h->stream);
     case 404: return launch_tiled_layout<4, 4>(cfg, loss, kind, a, h->stream);

@@ -126,6 +126,42 @@ __device__ __forceinline__ void stage_tile(const double* __restrict__ other, int
   }
 }
 
+// ---- double-buffered tiles (LW > 0 loader waves) ------------------------------------------------------------------------
+// Measured (tools/gpu_r2l.sh): staging is 20 % (C2) to 37 % (1M x 50k) of an LDS-tiled sweep and fully exposed -- every wave loads,
+// waits, writes LDS and meets two barriers per tile before anyone computes.  With LW > 0 the first LW waves of the workgroup are
+// LOADERS: they bring the next HALF tile into the other half of LDS with LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write
+// pass) while the remaining waves consume the current one; one barrier per half tile ("next one landed, everybody done with this
+// one").  Ordinary global loads of the compute waves cannot drain the DMA queue (hipcc waits vmcnt(0) at the first use of any
+// load result while LDS-DMA is in flight) because the DMA is issued by other waves.
+// The padded row layout is kept: the DMA destination is linear (base + lane x 16 B), so the SOURCE address of each 16-byte piece is
+// computed from its position in the padded image (piece c of the image = row c / 17, piece c % 17 of that row for kp = 32; the 17th
+// piece is the pad and re-reads the 16th).
+template <int G, int R, int TILE, int LW>
+constexpr int tile_buf_rows() { return LW > 0 ? TILE / 2 : TILE; }
+template <int G, int R, int TILE, int LW>
+constexpr int tile_buf_bytes() { // one staged buffer; a multiple of 1 KiB in loader mode (a DMA instruction writes a whole KiB)
+  return LW > 0 ? (tile_buf_rows<G, R, TILE, LW>() * tile_row_bytes<G, R>() + 1023) / 1024 * 1024 : TILE * tile_row_bytes<G, R>();
+}
+template <int G, int R, int TILE, int LW>
+constexpr int tile_lds_bytes() { return (LW > 0 ? 2 : 1) * tile_buf_bytes<G, R, TILE, LW>(); } // the descriptor table sits behind
+
+template <int G, int R, int LW>
+__device__ __forceinline__ void dma_tile(const double* __restrict__ other, int64_t lo, int64_t hi, char* buf, int wave, int lane) {
+  constexpr int KPB = G * R * 8, ROWB = tile_row_bytes<G, R>(), CPR = ROWB / 16;
+  const int rows = (int)(hi - lo), total = rows * CPR;
+  const char* src0 = reinterpret_cast<const char*>(other) + lo * KPB;
+  for (int base = wave * 64; base < total; base += LW * 64) { // one KiB of the padded image per instruction
+    int c = base + lane;
+    c = c < total ? c : total - 1;
+    const int row = c / CPR;
+    int cc = c - row * CPR;
+    cc = cc < CPR - 1 ? cc : CPR - 2; // the pad piece
+    const char* src = src0 + row * KPB + cc * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
+  }
+}
+
 // One pass of every group of the workgroup over tiles [tile_begin, tile_end).
 //   xv      the point at which the segment's losses are evaluated
 //   g, J    outputs: gradient (GRAD) and loss sum of the segment's observations inside those tiles
@@ -137,12 +173,16 @@ __device__ __forceinline__ void stage_tile(const double* __restrict__ other, int
 // barrier.  It is what the phase-aligned pass kernels below run: when every group in flight walks its sorted list through the same
 // super-tile at the same time, those reads hit the 4 MB L2 of the XCD (~30 TB/s) instead of the Infinity Cache / HBM (6.5-8 TB/s,
 // profiles/r02_ubench_gather.txt).
-template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false>
+template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false, int LW = 0>
 __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const Vec<G, R>& xv, Vec<G, R>& g, double& J,
                                            bool active, int64_t& pos, int64_t end, int tile_begin, int tile_end,
                                            const LossDesc& segloss, int lane, int j) {
   constexpr int ROWB = L2 ? G * R * 8 : tile_row_bytes<G, R>(), NT = NW * 64;
-  const char* const mem = L2 ? reinterpret_cast<const char*>(a.other) : lds; // where the opposing vectors are read from
+  constexpr int TROWS = tile_buf_rows<G, R, TILE, LW>(), BUFB = tile_buf_bytes<G, R, TILE, LW>(); // staged rows / bytes per buffer
+  if constexpr (LW > 0) { // tiles are counted in half tiles from here on
+    tile_begin *= 2;
+    tile_end *= 2;
+  }
   constexpr bool FOUR = (G == 4 || G == 8) && LOSS != 0; // the whole batch of G observations per step (below)
   const double two_scale = 2 * segloss.scale;
   J = 0.0;
@@ -159,7 +199,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
   constexpr bool UDESC = FOUR && loss_mode(LOSS) == 2 && !L2; // descriptor ids travel with the entries (see TiledArgs::descid)
   const uint8_t* __restrict__ descid = a.descid;
   const bool have_ids = UDESC && descid != nullptr;    // uniform
-  const char* udesc_lds = lds + TILE * ROWB;            // the kernel staged the distinct descriptors there
+  const char* udesc_lds = lds + tile_lds_bytes<G, R, TILE, LW>(); // the kernel staged the distinct descriptors there
   auto load_entry = [&](int64_t p, int& c, double& av, int& did) {
     const int64_t q = p < last ? p : last;
     c = idx[q];
@@ -167,20 +207,50 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
     did = 0;
     if constexpr (UDESC) { if (have_ids) did = descid[q]; }
   };
+  if constexpr (LW > 0) {
+    if ((int)(threadIdx.x >> 6) < LW) { // loader wave: half tile t+1 lands in the other buffer while the compute waves consume t
+      const int lwave = threadIdx.x >> 6;
+      auto dma = [&](int t) {
+        const int64_t lo = (int64_t)t * TROWS;
+        const int64_t hi = lo + TROWS < a.n_other ? lo + TROWS : a.n_other;
+        if (lo < hi) dma_tile<G, R, LW>(a.other, lo, hi, lds + ((t - tile_begin) & 1) * BUFB, lwave, lane);
+      };
+      if (tile_begin < tile_end) dma(tile_begin);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads(); // B0: the first half tile is in LDS
+      for (int t = tile_begin; t < tile_end; ++t) {
+        if (t + 1 < tile_end) dma(t + 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads(); // B(t+1): half tile t+1 has landed and every compute wave is done with half tile t
+      }
+      return;
+    }
+  }
   int cb, db;
   double ab;
   load_entry(pos + j, cb, ab, db);
   if (!(active && pos + j < end)) cb = 0x7fffffff;
+  if constexpr (LW > 0) __syncthreads(); // B0
   for (int t = tile_begin; t < (L2 ? tile_begin + 1 : tile_end); ++t) {
-    const int64_t lo = (int64_t)t * TILE;
-    const int64_t hi_ = L2 ? (int64_t)tile_end * TILE : lo + TILE;
+    const int64_t lo = (int64_t)t * TROWS;
+    const int64_t hi_ = L2 ? (int64_t)tile_end * TROWS : lo + TROWS;
     const int64_t hi = hi_ < a.n_other ? hi_ : a.n_other;
-    if constexpr (!L2) {
+    const char* const mem = L2 ? reinterpret_cast<const char*>(a.other) : (LW > 0 ? lds + ((t - tile_begin) & 1) * BUFB : lds);
+    if constexpr (!L2 && LW == 0) {
       __syncthreads(); // everybody is done with the previous tile
+#if defined(GLRM_EXP_NOSTAGE) // timing experiment: stage only the first tile of the pass (results are wrong, the control flow stays finite)
+      if (t == tile_begin) stage_tile<G, R, NT>(a.other, lo, hi, lds);
+#else
       stage_tile<G, R, NT>(a.other, lo, hi, lds);
+#endif
       __syncthreads();
     }
+#if defined(GLRM_EXP_NOCOMPUTE) // timing experiment: staging and barriers only
+    bool done = true;
+    if (t + 1 == tile_end && active) J = 1.0;
+#else
     bool done = !active;
+#endif
     while (!done) {
       int cn, dn; // prefetch the next batch while this one is consumed
       double an;
@@ -358,18 +428,19 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
         if (!(pos + j < end)) cb = 0x7fffffff;
       }
     }
+    if constexpr (LW > 0) __syncthreads(); // B(t+1), see the loader loop
   }
   J = group_sum<G>(J) * (FOUR ? 1.0 : 2.0 / G); // two per step: lanes hold parity-partial sums, each observation counted G/2 times
 }
 
 // distinct loss descriptors -> LDS behind the tile (read after the first tile barrier of tiled_pass); see TiledArgs::descid
-template <int G, int R, int NW, int TILE, int LOSS>
+template <int G, int R, int NW, int TILE, int LOSS, int LW = 0>
 __device__ __forceinline__ void stage_udesc(const TiledArgs& a, char* lds) {
   if constexpr (loss_mode(LOSS) == 2) {
     if (a.descid) {
       const int words = a.n_udesc * 8; // 32 bytes each
       const int* src = reinterpret_cast<const int*>(a.udesc);
-      int* dst = reinterpret_cast<int*>(lds + TILE * tile_row_bytes<G, R>());
+      int* dst = reinterpret_cast<int*>(lds + tile_lds_bytes<G, R, TILE, LW>());
       for (int w = threadIdx.x; w < words; w += NW * 64) dst[w] = src[w];
     }
   }
@@ -380,20 +451,20 @@ __device__ __forceinline__ void stage_udesc(const TiledArgs& a, char* lds) {
 // Workgroup = NW waves, SPB = NW*64/G segments; each pass streams the WHOLE opposing factor through LDS.
 // FIXED = true is the SparseProxGradParams step (one gradient pass, x <- prox(x - (alpha/l) g), no line search); it is a
 // separate instantiation so that the line-search kernel keeps its register budget.
-template <int G, int R, int NW, int TILE, int LOSS, bool FIXED>
+template <int G, int R, int NW, int TILE, int LOSS, bool FIXED, int LW = 0>
 __global__ void __launch_bounds__(NW * 64, NW == 12 ? 3 : 4) tiled_sweep_kernel(const TiledArgs a) {
-  constexpr int KP = G * R, NGW = 64 / G, SPB = NW * NGW;
+  constexpr int KP = G * R, NGW = 64 / G, SPB = (NW - LW) * NGW; // the first LW waves are loaders (double-buffered tiles)
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % G, gi = lane / G;
-  const int64_t slot = (int64_t)blockIdx.x * SPB + wave * NGW + gi;
-  const bool have = slot < a.nseg;
+  const int64_t slot = (int64_t)blockIdx.x * SPB + (wave - LW) * NGW + gi;
+  const bool have = wave >= LW && slot < a.nseg;
   const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[slot] : slot; // segments of similar length share a wave (skewed data)
   const int64_t beg = have ? a.ptr[seg] : 0, end = have ? a.ptr[seg + 1] : 0;
   const int64_t gseg = a.own_offset + (have ? seg : 0);
   double2* ownp = reinterpret_cast<double2*>(a.own + gseg * KP);
   const int ntiles = (int)((a.n_other + TILE - 1) / TILE);
-  stage_udesc<G, R, NW, TILE, LOSS>(a, lds);
+  stage_udesc<G, R, NW, TILE, LOSS, LW>(a, lds);
 
   Vec<G, R> g, xn;
   const RegDesc rd = load_reg(a.regs, (a.reg_single || !have) ? 0 : seg);
@@ -407,7 +478,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 3 : 4) tiled_sweep_kernel(
     Vec<G, R> x;
 #pragma unroll
     for (int i = 0; i < R / 2; ++i) x.v[i] = have ? ownp[i * G + j] : make_double2(0.0, 0.0);
-    tiled_pass<G, R, NW, TILE, LOSS, true>(a, lds, x, g, Jold, have, pos, end, 0, ntiles, segloss, lane, j);
+    tiled_pass<G, R, NW, TILE, LOSS, true, false, LW>(a, lds, x, g, Jold, have, pos, end, 0, ntiles, segloss, lane, j);
     if constexpr (FIXED) { // src/algorithms/sparse_proxgrad.jl:72-78: g *= -alpha/l; x += g; prox!(r, x, alpha/l)
       const double s = a.fixed_alpha / l;
 #pragma unroll
@@ -444,7 +515,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 3 : 4) tiled_sweep_kernel(
     double Jn;
     Vec<G, R> dummy;
     pos = beg;
-    tiled_pass<G, R, NW, TILE, LOSS, false>(a, lds, xn, dummy, Jn, searching, pos, end, 0, ntiles, segloss, lane, j);
+    tiled_pass<G, R, NW, TILE, LOSS, false, false, LW>(a, lds, xn, dummy, Jn, searching, pos, end, 0, ntiles, segloss, lane, j);
     Jn += reg_eval<G, R>(rd, xn, j, a.k);
     if (searching) {
       ++ntrials;
@@ -494,19 +565,19 @@ __device__ __forceinline__ int64_t lower_bound_idx(const int32_t* idx, int64_t b
 // L2 = true: the phase-aligned gather pass (no LDS tile, tiled_pass<..., L2>).  One launch covers ONE super-tile (a.sup_fixed) and
 // a slice [a.seg_begin, a.seg_begin + a.nseg_slice) of the segments that is at most what the chip holds at once, so every group of
 // the launch starts its walk through the super-tile at the same moment; the host issues the launches super-tile by super-tile.
-template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false>
+template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false, int LW = 0>
 __global__ void __launch_bounds__(NW * 64, L2 ? 1 : 4) tiled_col_pass_kernel(const TiledArgs a) {
-  constexpr int KP = G * R, NGW = 64 / G, SPB = NW * NGW, PSTRIDE = KP + 2;
+  constexpr int KP = G * R, NGW = 64 / G, SPB = (NW - LW) * NGW, PSTRIDE = KP + 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % G, gi = lane / G;
-  const int64_t slot = (L2 ? a.seg_begin : 0) + (int64_t)blockIdx.x * SPB + wave * NGW + gi;
+  const int64_t slot = (L2 ? a.seg_begin : 0) + (int64_t)blockIdx.x * SPB + (wave - LW) * NGW + gi;
   const int sup = L2 ? a.sup_fixed : (int)blockIdx.y;
-  bool have = slot < (L2 ? a.seg_begin + a.nseg_slice : a.nseg);
+  bool have = wave >= LW && slot < (L2 ? a.seg_begin + a.nseg_slice : a.nseg);
   const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[slot] : slot; // which column a group works on does not change any sum
   if (!GRAD && have) have = a.active[seg] != 0;
   if (!GRAD && !__syncthreads_or(have ? 1 : 0)) return; // nothing left to evaluate in this column group
-  if constexpr (!L2) stage_udesc<G, R, NW, TILE, LOSS>(a, lds);
+  if constexpr (!L2) stage_udesc<G, R, NW, TILE, LOSS, LW>(a, lds);
   const int64_t beg = have ? a.ptr[seg] : 0, end = have ? a.ptr[seg + 1] : 0;
   const int64_t gseg = a.own_offset + (have ? seg : 0);
   const int ntiles = (int)((a.n_other + TILE - 1) / TILE);
@@ -520,7 +591,7 @@ __global__ void __launch_bounds__(NW * 64, L2 ? 1 : 4) tiled_col_pass_kernel(con
   if constexpr (loss_mode(LOSS) != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
   int64_t pos = have ? lower_bound_idx<G>(a.idx, beg, end, (int64_t)tb * TILE) : 0;
   double J;
-  tiled_pass<G, R, NW, TILE, LOSS, GRAD, L2>(a, lds, x, g, J, have, pos, end, tb, te, segloss, lane, j);
+  tiled_pass<G, R, NW, TILE, LOSS, GRAD, L2, LW>(a, lds, x, g, J, have, pos, end, tb, te, segloss, lane, j);
   if (have) {
     double* p = a.part + ((int64_t)seg * a.nsup + sup) * PSTRIDE;
     if (GRAD) {

@@ -137,6 +137,23 @@ def test_unsorted_lists_fall_back_to_gather_sweeps():
     assert st["tiled"] == 3
 
 
+def test_tile_sort_in_batches_of_whole_segments():
+    """hipCUB counts in int: views beyond 2e9 entries are tile-sorted batch by batch (glrm_tilesort.hip).  The batching is exercised
+    here with a tiny batch limit (GLRM_HIP_TILE_SORT_BATCH) on shuffled lists with duplicates."""
+    rng = np.random.default_rng(82)
+    pa, X0, Y0 = random_problem(rng, 2500, 2500, 8, 0.02, dup=True)
+    os.environ["GLRM_HIP_TILE_SORT"] = "2"
+    os.environ["GLRM_HIP_TILE_SORT_BATCH"] = "3000"  # ~55 entries per segment: ~50 segments per batch
+    try:
+        h = hip().create(pa, tiled=2)
+        st = hip().kernel_stats(h)
+        hip().destroy(h)
+        assert st["tiled"] == 3
+        compare(pa, X0, Y0, L.ProxGradParams(max_iter=8), tiled=2)
+    finally:
+        del os.environ["GLRM_HIP_TILE_SORT"], os.environ["GLRM_HIP_TILE_SORT_BATCH"]
+
+
 LOSS_CASES = {
     "l1": L.L1Loss(1.3), "huber": L.HuberLoss(0.9, crossover=0.6), "quantile": L.QuantileLoss(1.1, quantile=0.3),
     "periodic": L.PeriodicLoss(2.5, 0.8), "quad_scaled": L.QuadLoss(2.5),
