@@ -53,27 +53,54 @@ int glrm_setup_dense(glrm_handle* h, const glrm_problem* p) {
   h->dense_scale = p->losses[0].scale;
   h->nnz_r = h->ml * h->n;
   h->nnz_c = h->nl * h->m;
-  // bring the caller's matrix to the device if needed
-  const double* dsrc = p->dense_A;
-  double* tmp = nullptr;
-  if (!(p->flags & GLRM_PROBLEM_DEVICE_ARRAYS)) {
-    const size_t rows = p->dense_colmajor ? (size_t)p->n : (size_t)p->m; // number of contiguous runs
-    const size_t run = p->dense_colmajor ? (size_t)p->m : (size_t)p->n;
-    for (size_t r = 0; r < rows; ++r)
-      for (size_t c = 0; c < run; ++c)
-        if (std::isnan(p->dense_A[r * (size_t)p->dense_ld + c])) {
-          const size_t i = p->dense_colmajor ? c : r, j = p->dense_colmajor ? r : c;
-          return fail(GLRM_ERR_NONFINITE, "Observed value in entry (%zu, %zu) is NaN.", i, j);
-        }
-    HIPCK(hipMalloc((void**)&tmp, rows * run * 8));
-    HIPCK(hipMemcpy2DAsync(tmp, run * 8, p->dense_A, (size_t)p->dense_ld * 8, run * 8, rows, hipMemcpyHostToDevice, h->stream));
-    dsrc = tmp;
+  // Bring the caller's matrix to the device if needed.  Whole problem on this handle: one upload, both packed views come from it.
+  // A shard of a multi-GPU fit only needs its row block (for the X half-step) and its column block (for the Y half-step): those
+  // two sub-matrices are uploaded one after the other (2D copies), never the whole matrix -- at C3 on 8 GPUs 10 + 10 GB per
+  // device instead of 80 GB.  The NaN check (src/glrm.jl:63-71) covers the shard's row block; the row blocks partition A.
+  const bool on_dev = (p->flags & GLRM_PROBLEM_DEVICE_ARRAYS) != 0;
+  const bool whole = h->rb == 0 && h->re == h->m && h->cb == 0 && h->ce == h->n;
+  const int cm = p->dense_colmajor ? 1 : 0;
+  const int64_t ld = p->dense_ld;
+  if (!on_dev) {
+    for (int64_t i = h->rb; i < h->re; ++i)
+      for (int64_t j = 0; j < h->n; ++j)
+        if (std::isnan(p->dense_A[cm ? i + j * ld : i * ld + j]))
+          return fail(GLRM_ERR_NONFINITE, "Observed value in entry (%lld, %lld) is NaN.", (long long)i, (long long)j);
   }
-  const int64_t ldsrc = (p->flags & GLRM_PROBLEM_DEVICE_ARRAYS) ? p->dense_ld : (p->dense_colmajor ? p->m : p->n);
-  int rc = pack_view(h, dsrc, ldsrc, p->dense_colmajor, 0, h->rb, h->ml, h->n, &h->Arow, &h->lda_r);
-  if (!rc) rc = pack_view(h, dsrc, ldsrc, p->dense_colmajor, 1, h->cb, h->nl, h->m, &h->Acol, &h->lda_c);
-  if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(GLRM_ERR_HIP, "dense pack failed");
-  if (tmp) (void)hipFree(tmp);
+  int rc = GLRM_OK;
+  if (on_dev) {
+    rc = pack_view(h, p->dense_A, ld, cm, 0, h->rb, h->ml, h->n, &h->Arow, &h->lda_r);
+    if (!rc) rc = pack_view(h, p->dense_A, ld, cm, 1, h->cb, h->nl, h->m, &h->Acol, &h->lda_c);
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(GLRM_ERR_HIP, "dense pack failed");
+  } else if (whole) {
+    double* tmp = nullptr;
+    const size_t runs = cm ? (size_t)p->n : (size_t)p->m, run = cm ? (size_t)p->m : (size_t)p->n; // contiguous runs and their length
+    HIPCK(hipMalloc((void**)&tmp, runs * run * 8));
+    if (hipMemcpy2DAsync(tmp, run * 8, p->dense_A, (size_t)ld * 8, run * 8, runs, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+      rc = fail(GLRM_ERR_HIP, "upload of the dense matrix failed");
+    if (!rc) rc = pack_view(h, tmp, (int64_t)run, cm, 0, 0, h->ml, h->n, &h->Arow, &h->lda_r);
+    if (!rc) rc = pack_view(h, tmp, (int64_t)run, cm, 1, 0, h->nl, h->m, &h->Acol, &h->lda_c);
+    if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(GLRM_ERR_HIP, "dense pack failed");
+    (void)hipFree(tmp);
+  } else {
+    // (which, first segment, segments, extent of the other dimension) for the row block and the column block
+    for (int which = 0; which < 2 && !rc; ++which) {
+      const int64_t s0 = which ? h->cb : h->rb, ns = which ? h->nl : h->ml, other = which ? h->m : h->n;
+      if (ns <= 0) { rc = pack_view(h, p->dense_A, ld, cm, which, 0, 0, other, which ? &h->Acol : &h->Arow, which ? &h->lda_c : &h->lda_r); continue; }
+      // the block as a dense sub-matrix in the caller's own storage order: segments run along the caller's rows (which = 0) / columns
+      const bool seg_is_run = (which == 0) != (cm != 0); // are whole segments contiguous runs of the source?
+      const size_t width = (size_t)(seg_is_run ? other : ns) * 8, height = (size_t)(seg_is_run ? ns : other);
+      const double* src = p->dense_A + (seg_is_run ? s0 * ld : s0);
+      double* tmp = nullptr;
+      HIPCK(hipMalloc((void**)&tmp, width * height));
+      if (hipMemcpy2DAsync(tmp, width, src, (size_t)ld * 8, width, height, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+        rc = fail(GLRM_ERR_HIP, "upload of the dense block failed");
+      // inside tmp the block starts at segment 0 and has leading dimension width / 8
+      if (!rc) rc = pack_view(h, tmp, (int64_t)(width / 8), cm, which, 0, ns, other, which ? &h->Acol : &h->Arow, which ? &h->lda_c : &h->lda_r);
+      if (!rc && hipStreamSynchronize(h->stream) != hipSuccess) rc = fail(GLRM_ERR_HIP, "dense pack failed");
+      (void)hipFree(tmp);
+    }
+  }
   if (rc) return rc;
   pick_sup(h->n, h->nsup_r, h->vps_r);
   pick_sup(h->m, h->nsup_c, h->vps_c);

@@ -68,3 +68,16 @@ def test_eight_ranks_on_one_gpu_equal_one_rank():
     one = run([sys.executable, "bench.py", "--rows", "200000"] + common, dict(os.environ))
     assert eight["n_gpus"] == 8 and eight["config"]["observed"] == one["config"]["observed"] == 200000 * 200
     assert eight["objective"] == one["objective"]
+
+
+def test_phase_aligned_passes_two_ranks_equal_one_rank():
+    """The C4 recipe at 2M rows (2e8 observations): large enough for the automatic choice of the phase-aligned gather passes on
+    both half-steps (csrc/glrm_blocked.hip) -- made from the GLOBAL problem, so two shards run the same family as one and record the
+    same objectives bit for bit (strong scaling, pipelined X exchange on the blocked row sweep)."""
+    common = ["--config", "C4", "--rows", "2000000", "--steps", "2", "--warmup", "2"] + QUIET
+    env = dict(os.environ, GLRM_BENCH_BACKEND="gloo", GLRM_GATHER="allgather")
+    two = run(torchrun(2) + common, env)
+    one = run([sys.executable, "bench.py"] + common, dict(os.environ))
+    assert one["config"]["row_sweep"] == one["config"]["col_sweep"] == "blocked"
+    assert two["config"]["row_sweep"] == two["config"]["col_sweep"] == "blocked"
+    assert two["objective"] == one["objective"]
