@@ -1,0 +1,78 @@
+"""bench.py's host-side pieces that need no GPU: the per-family roofline model (every fraction a ratio of an achieved rate to the
+peak of the limiter it is priced against, never an on-chip-reuse artefact above 1 at the measured times), the config table, and the
+CPU legs (cpu_baseline sample, J_ref leg) with the oracle standing in for the engine."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
+
+
+def test_algorithmic_bytes_match_the_survey():
+    assert bench.algorithmic_bytes_per_update(32) == 536 and bench.algorithmic_bytes_per_update(64) == 1048
+
+
+@pytest.mark.parametrize("family,kw,bound", [
+    # measured half-step times of round 2 (profiles/r02_*_bench_final.json)
+    ("blocked", dict(nnz=10**9, nseg=100_000, nopp=10_000_000, k=64, ld=64, ms=143.0), "hbm"),   # C4 Y half-step: X = 5 GB
+    ("gather", dict(nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=128.8), "l2"),     # C4 X half-step: Y = 51 MB, cache resident
+    ("tiled", dict(nnz=5 * 10**8, nseg=10_000, nopp=1_000_000, k=32, ld=32, ms=9.7), "lds"),     # C2 Y half-step
+    ("dense", dict(nnz=10**10, nseg=1_000_000, nopp=10_000, k=32, ld=32, ms=42.3, m=1_000_000, n=10_000), "mfma"),
+])
+def test_roofline_fractions_are_fractions(family, kw, bound):
+    r = bench.kernel_roofline(family, **kw)
+    assert r["best"]["bound"] == bound
+    assert 0 < r["best"]["frac"] <= 1.0
+    for c in r["candidates"]:
+        assert 0 < c["frac"] <= 1.0 and c["frac"] == pytest.approx(c["achieved"] / c["peak"])
+    assert r["best"]["frac"] == max(c["frac"] for c in r["candidates"])
+
+
+def test_c4_gather_column_sweep_is_priced_at_the_survey_bytes():
+    r = bench.kernel_roofline("gather", nnz=10**9, nseg=100_000, nopp=10_000_000, k=64, ld=64, ms=161.3)
+    assert r["best"]["bound"] == "hbm" and r["best"]["per_launch"] == 1048 * 10**9
+    assert r["best"]["frac"] == pytest.approx(0.812, abs=2e-3)  # profiles/r02_c4_bench.json
+
+
+def test_config_table():
+    c4 = bench.CONFIGS["C4"]
+    assert (c4["rows"], c4["cols"], c4["k"], c4["q"], c4["reg"][0]) == (10_000_000, 100_000, 64, 100, 3) and bench.nonneg_start(c4)
+    assert not bench.nonneg_start(bench.CONFIGS["C2"])
+    for c in bench.CONFIGS.values():
+        assert c["cols"] % c["q"] == 0
+        if c["jref"]:
+            assert c["jref"][1] % c["jref"][2] == 0
+
+
+def test_cpu_legs_with_the_oracle_standing_in(monkeypatch):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+
+    class Args:
+        seed, cpu_sample_rows, rows = 20260926, 64, 10_000
+
+    cfg = dict(bench.CONFIGS["C4"], jref=(600, 400, 20))
+    api = O.oracle_api()
+    orig = api.create
+    monkeypatch.setattr(api, "create", lambda pa, device_id=0, **kw: orig(pa))
+
+    class Dev:
+        index = 0
+
+    r = bench.jref_leg(Args, cfg, api, Dev)
+    assert r["gpu_first_iteration_at_or_below_J_ref"] is not None and r["gpu_objective_there"] <= r["J_ref"] * (1 + 1e-5)
+    assert r["gpu_first_iteration_at_or_below_J_ref"] <= r["cpu_iterations_to_own_stop"]
+    monkeypatch.setattr(bench.time, "time", _fast_clock())
+    b = bench.cpu_baseline(Args, dict(cfg, q=20), 64, 20, 400)
+    assert b["kind"] == "port" and b["value"] > 0 and b["cores"] >= 1 and "first" in b["sample"]
+
+
+def _fast_clock():
+    import time as _t
+    t0, p0, real = _t.time(), _t.perf_counter(), _t.perf_counter  # perf_counter: bench.time.time itself is what gets patched
+    return lambda: t0 + (real() - p0) * 50.0  # the 10-second sampling window of cpu_baseline in 0.2 s
