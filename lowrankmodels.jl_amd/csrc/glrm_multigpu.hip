@@ -20,8 +20,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -62,8 +64,64 @@ constexpr int NCCL_FLOAT64 = 8; // ncclFloat64 (rccl.h)
 
 } // namespace
 
+// One persistent host thread per shard beyond the first (shard 0 runs on the caller's thread): a half-step is ~8 calls per iteration
+// and shard, so the threads are kept instead of being spawned per call.
+struct ShardPool {
+  std::vector<std::thread> th;
+  std::mutex mu;
+  std::condition_variable cv_go, cv_done;
+  const std::function<void(int)>* job = nullptr;
+  uint64_t epoch = 0;
+  int pending = 0;
+  bool quit = false;
+  void start(int n) {
+    for (int s = 1; s < n; ++s)
+      th.emplace_back([this, s] {
+        uint64_t seen = 0;
+        for (;;) {
+          const std::function<void(int)>* j;
+          {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_go.wait(lk, [&] { return quit || epoch != seen; });
+            if (quit) return;
+            seen = epoch;
+            j = job;
+          }
+          (*j)(s);
+          {
+            std::lock_guard<std::mutex> lk(mu);
+            if (--pending == 0) cv_done.notify_one();
+          }
+        }
+      });
+  }
+  void run(const std::function<void(int)>& f) { // f(s) for s = 0..n-1, returns when all are done
+    if (!th.empty()) {
+      std::lock_guard<std::mutex> lk(mu);
+      job = &f;
+      pending = (int)th.size();
+      ++epoch;
+    }
+    cv_go.notify_all();
+    f(0);
+    if (!th.empty()) {
+      std::unique_lock<std::mutex> lk(mu);
+      cv_done.wait(lk, [&] { return pending == 0; });
+    }
+  }
+  ~ShardPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      quit = true;
+    }
+    cv_go.notify_all();
+    for (auto& t : th) t.join();
+  }
+};
+
 struct glrm_multi {
   int n = 0;
+  ShardPool pool;
   int64_t m = 0, nn = 0, d = 0;
   int k = 0, ld = 0;
   std::vector<int> dev;
@@ -115,14 +173,11 @@ int run_all(glrm_multi* mh, const std::function<int(int)>& fn) {
   const int n = mh->n;
   std::vector<int> rc((size_t)n, 0);
   std::vector<std::string> msg((size_t)n);
-  auto body = [&](int s) {
+  const std::function<void(int)> body = [&](int s) {
     rc[s] = fn(s);
     if (rc[s]) msg[s] = g_err; // thread-local message of the failing call
   };
-  std::vector<std::thread> th;
-  for (int s = 1; s < n; ++s) th.emplace_back(body, s);
-  body(0);
-  for (auto& t : th) t.join();
+  mh->pool.run(body);
   for (int s = 0; s < n; ++s)
     if (rc[s]) return fail(rc[s], "shard %d (device %d): %s", s, mh->dev[s], msg[s].c_str());
   return GLRM_OK;
@@ -393,6 +448,7 @@ extern "C" int glrm_hip_multi_create(glrm_multi** out, const glrm_problem* p, co
   glrm_multi* mh = new (std::nothrow) glrm_multi();
   if (!mh) return fail(GLRM_ERR_OOM, "out of host memory");
   mh->n = mo->n_shards;
+  mh->pool.start(mh->n);
   const int rc = multi_create_impl(mh, p, o, mo);
   if (rc) {
     char keep[sizeof g_err];
