@@ -6,14 +6,25 @@
  * import, link, call or fall back to it; only tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg use it (as the checker / the timed CPU baseline).
  *
- * PARITY STATUS: "operator-pinned, trajectory unpinned".  The reference is pure Julia;
- * no `julia` binary exists in the build container or on the GPU box, so the reference
- * itself can be neither run nor compiled here.  The oracle is pinned against every
- * closed-form known answer the reference's tests/notebook hold for this path
- * (tests/test_oracle_kat.py) and cross-checked against an independent dense numpy
- * transcription of proxgrad.jl (tests/test_oracle_vs_numpy.py), but the reference has
- * no golden *trajectory* that is reproducible without Julia's RNG (SURVEY.md section
- * 8(c)): for trajectories this oracle is "parity unpinned".
+ * PARITY STATUS: "operators pinned, trajectory pinned by the reference's notebook".  The
+ * reference is pure Julia; no `julia` binary exists in the build container or on the GPU
+ * box, so the reference itself can be neither run nor compiled here (no oracle/_ref).
+ * The oracle is pinned against
+ *   - every closed-form known answer the reference's tests/notebook hold for this path
+ *     (tests/test_oracle_kat.py);
+ *   - the three seeded trajectories the reference's demo notebook printed under Julia
+ *     1.1.0 (examples/LowRankModelsDemo-v1.1.0.ipynb:308-317, :587-595, :1005-1030):
+ *     Julia's MersenneTwister / rand / rand(a:b) / randn / sprandn are restated in
+ *     tests/julia_rng.py, the cells' random inputs rebuilt bit for bit, and this oracle
+ *     lands on the printed objectives (fit!(ProxGradParams) with duplicated observations
+ *     and an Inf start: iteration 10 the same double, all of 10..100 within 6e-12;
+ *     init_svd! + fit!: 1e-15; init_svd! + fit!(SparseProxGradParams) with HuberLoss:
+ *     2e-16) and on the printed corner entries of X and Y
+ *     (tests/test_reference_notebook.py);
+ *   - an independent dense numpy transcription of proxgrad.jl
+ *     (tests/test_oracle_vs_numpy.py), which reproduces the notebook to the last ulp.
+ * What stays unpinned by reference output: trajectories of the losses the notebook does
+ * not fit (julia/crosscheck.jl is the script that would pin them where Julia exists).
  *
  * Every function cites the reference file:line (relative to the LowRankModels.jl
  * tree) it follows.  Arithmetic is Float64 throughout, indices 0-based here

@@ -66,8 +66,8 @@ def _reference_dumps():
 @pytest.mark.parametrize("name", _reference_dumps() or ["<none>"])
 def test_reference_dump_matches_the_oracle(name):
     """Consumes tests/golden/ref/<name>.ref.bin -- the trajectory of the REAL LowRankModels.fit! on the fixture's inputs, written by
-    julia/crosscheck.jl -- and compares it with the oracle's: this is what lifts the oracle from "operators pinned" to "trajectory
-    pinned".  No dump is committed yet (no julia in the image): the test then skips, and DESIGN.md section 3 says "parity unpinned"."""
+    julia/crosscheck.jl -- and compares it with the oracle's: this extends the reference-output pin of the trajectory (tests/test_reference_notebook.py:
+    the notebook's printed runs) to every fixture.  No dump is committed yet (no julia in the image): the test then skips."""
     if name == "<none>":
         pytest.skip("no reference dump under tests/golden/ref (run julia/crosscheck.jl where Julia and LowRankModels.jl exist)")
     import fixture_bin as FB
