@@ -419,7 +419,7 @@ def main():
         fam_r = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 1 else "blocked" if flags & 16 else "gather"
         fam_c = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 2 else "blocked" if flags & 32 else "gather"
         ld = st["ld"]
-        tile = 150 * 1024 // (ld * 8 + 16)
+        tile = 150 * 1024 // (ld * 8 + 16) // 16 * 16  # csrc/glrm_tiled.hip: tile_rows_c
         rl_r = kernel_roofline(fam_r, nnz=nnz_r, nseg=nseg_r, nopp=n, k=k, ld=ld, ms=ms_x, m=nseg_r, n=n, tile=tile)
         rl_c = kernel_roofline(fam_c, nnz=nnz_c, nseg=nseg_c, nopp=m, k=k, ld=ld, ms=ms_y, m=m, n=nseg_c, tile=tile)
         # dominant kernel = the longer half-step

@@ -17,6 +17,7 @@ using namespace glrm;
 // cfg 1 = 150 KB tile, 16 waves, one workgroup per CU (fewer barriers, fewer factor re-reads)
 constexpr int tile_rows_c(int kp, int cfg) { return ((cfg ? 150 * 1024 : 64 * 1024) / (kp * 8 + 16)) / 16 * 16; }
 static int tile_rows(int kp, int cfg) { return tile_rows_c(kp, cfg); }
+static bool tile_rot_rt(int G, int R) { return GLRM_TILE_ROT && (G == 4 || G == 8) && R == 8; }
 
 // slot -> segment permutation of a tiled sweep: segments sorted by (loss kind of the column,) descending length, so that the 16
 // lane groups of a wave meet one loss formula and lists of similar length.  nullptr when the natural order is already that
@@ -39,6 +40,24 @@ static int make_segperm(glrm_handle* h, bool rows, int32_t** out) {
     if (kinds && lt[x].kind != lt[y].kind) return lt[x].kind < lt[y].kind;
     return ptr[x + 1] - ptr[x] > ptr[y + 1] - ptr[y];
   });
+  if (!rows && tile_rot_rt(h->G, h->R)) {
+    // the column passes read their tiles conflict-free (glrm_tiled.hpp: tile_rot) when slot s holds a segment of class (s & 7) >> 1,
+    // class = ((global id) & 7) >> 1: deal the sorted list out class by class, two per block of eight slots -- the four classes are
+    // equally frequent, so every wave still meets segments of one kind and similar length; a class that runs dry is filled from the
+    // longest remaining queue (costs bank conflicts at the tail, never bits)
+    std::vector<int32_t> q[4];
+    for (int32_t sgm : perm) q[tile_rot_of(h->cb + sgm)].push_back(sgm);
+    size_t head[4] = {0, 0, 0, 0};
+    for (int64_t slot = 0; slot < nseg; ++slot) {
+      int c = tile_rot_of(slot); // the class the slot's position wants
+      if (head[c] >= q[c].size()) {
+        size_t best = 0;
+        for (int d = 0; d < 4; ++d)
+          if (q[d].size() - head[d] > best) { best = q[d].size() - head[d]; c = d; }
+      }
+      perm[(size_t)slot] = q[c][head[c]++];
+    }
+  }
   HIPCK(hipMalloc((void**)out, (size_t)nseg * 4));
   HIPCK(hipMemcpyAsync(*out, perm.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream)); // perm is a local

@@ -97,13 +97,38 @@ __device__ __forceinline__ double pair_bcast_f64(double v, int u0, int lane) {
   }
 }
 
+// ---- conflict-free tile reads in the column passes (G = 4 or 8 lanes, four 16-byte chunks per lane) ---------------------------
+// ds_read_b128 serves a wave in four LDS cycles of 16 lanes -- {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same + 32
+// (MI355X_MICROARCH.md, LDS) -- i.e. four lane groups (G = 4) per cycle, each reading 64 contiguous bytes of ITS row.  With rows
+// padded by 16 B those four 16-bank windows start at random banks and overlap: 52 % of the LDS cycles of the C2 sweeps were conflict
+// cycles, and random row reads reach 63 TB/s against 118 TB/s conflict-free (tools/ubench_lanerow.hip,
+// profiles/r02_ubench_lanerow.txt).  With ROT the staged rows are NOT padded (every row starts at bank 0) and a lane group walks its
+// row's chunks in the order i ^ p, p = ((global segment id) & 7) >> 1: the four groups of an LDS cycle sit at positions {0,3,5,6}
+// or {1,2,4,7} of their half wave, whose p are all different when segments occupy the slots in order, so at every instruction they
+// read four DIFFERENT bank quarters -- SQ_LDS_BANK_CONFLICT = 0, whatever rows they read.  Register i of a lane then holds chunk
+// i ^ p of x, g and y alike (dot products and axpys pair equal registers; loads, stores and masks go by the chunk id).  p depends
+// on the segment only, never on where it runs, so sums are formed in the same order under any shard layout or slot permutation (a
+// slot order that breaks the pattern costs conflicts, not bits; make_segperm keeps the pattern).
+// Measured (profiles/r02_rot_pmc_c2.md, r02_rot_ab.txt; same box A/B): conflicts 1.43e9 -> 0 and LDS-busy cycles halved in every tiled
+// kernel, SQ_WAIT_INST_LDS / 20 -- but the sweeps are not LDS-bound.  Row sweeps: QuadLoss 8.56 vs 8.48 ms, heterogeneous 407 vs 387 ms
+// (three more address XORs per observation, a few more spilled registers).  Column passes: QuadLoss 9.80 vs 9.67 ms, heterogeneous
+// 47.96 vs 50.08 ms.  So only the column passes of models with non-quadratic losses (LOSS != 0) use it.
+#ifndef GLRM_TILE_ROT
+#define GLRM_TILE_ROT 1
+#endif
 template <int G, int R>
-constexpr int tile_row_bytes() { return G * R * 8 + 16; } // +16 B pad: consecutive rows start 4 banks apart
+constexpr bool tile_rot() { return GLRM_TILE_ROT && (G == 4 || G == 8) && R == 8; }
+__host__ __device__ __forceinline__ int tile_rot_of(int64_t gseg) { return ((int)gseg & 7) >> 1; }
+
+template <int G, int R>
+constexpr int tile_row_bytes() { return G * R * 8 + 16; } // LDS budget per staged row: +16 B pad, consecutive rows start 4 banks apart
+template <int G, int R, bool ROT>
+constexpr int tile_row_stride() { return ROT ? G * R * 8 : tile_row_bytes<G, R>(); } // ROT: unpadded rows inside the same budget
 
 // Copy opposing vectors [lo, hi) into LDS (coalesced 16-byte loads, padded rows).
-template <int G, int R, int NT>
+template <int G, int R, int NT, bool ROT = false>
 __device__ __forceinline__ void stage_tile(const double* __restrict__ other, int64_t lo, int64_t hi, char* lds) {
-  constexpr int KPB = G * R * 8, ROWB = tile_row_bytes<G, R>();
+  constexpr int KPB = G * R * 8, ROWB = tile_row_stride<G, R, ROT>();
   const char* src = reinterpret_cast<const char*>(other) + lo * KPB;
   const int total = (int)(hi - lo) * KPB;
   constexpr int U = 4; // 4 x 16-byte loads in flight per thread before the LDS writes
@@ -162,6 +187,13 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ other, int64
   }
 }
 
+// chunk held by register i of a lane whose first chunk sits at byte `ro` of the tile (ro carries the lane's 16-byte slot and, with
+// ROT, its rotation in the chunk field, which register index i then flips: chunk i ^ rot)
+template <bool ROT, int CB>
+__device__ __forceinline__ double2 tile_chunk(const char* tile, int ro, int i) {
+  return *reinterpret_cast<const double2*>(tile + (ROT ? (ro ^ (i * CB)) : ro + i * CB));
+}
+
 // One pass of every group of the workgroup over tiles [tile_begin, tile_end).
 //   xv      the point at which the segment's losses are evaluated
 //   g, J    outputs: gradient (GRAD) and loss sum of the segment's observations inside those tiles
@@ -173,11 +205,14 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ other, int64
 // barrier.  It is what the phase-aligned pass kernels below run: when every group in flight walks its sorted list through the same
 // super-tile at the same time, those reads hit the 4 MB L2 of the XCD (~30 TB/s) instead of the Infinity Cache / HBM (6.5-8 TB/s,
 // profiles/r02_ubench_gather.txt).
-template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false, int LW = 0>
+template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false, int LW = 0, bool ROTK = false>
 __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const Vec<G, R>& xv, Vec<G, R>& g, double& J,
                                            bool active, int64_t& pos, int64_t end, int tile_begin, int tile_end,
-                                           const LossDesc& segloss, int lane, int j) {
-  constexpr int ROWB = L2 ? G * R * 8 : tile_row_bytes<G, R>(), NT = NW * 64;
+                                           const LossDesc& segloss, int lane, int j, int rot = 0) {
+  constexpr bool ROT = ROTK && !L2 && LW == 0 && tile_rot<G, R>(); // register i holds chunk i ^ rot (see tile_rot)
+  constexpr int ROWB = L2 ? G * R * 8 : tile_row_stride<G, R, ROT>(), NT = NW * 64;
+  constexpr int CB = 2 * G * 8;                 // bytes per chunk row of the group
+  const int jrot = j * 16 + (ROT ? rot * CB : 0);
   constexpr int TROWS = tile_buf_rows<G, R, TILE, LW>(), BUFB = tile_buf_bytes<G, R, TILE, LW>(); // staged rows / bytes per buffer
   if constexpr (LW > 0) { // tiles are counted in half tiles from here on
     tile_begin *= 2;
@@ -239,9 +274,9 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
     if constexpr (!L2 && LW == 0) {
       __syncthreads(); // everybody is done with the previous tile
 #if defined(GLRM_EXP_NOSTAGE) // timing experiment: stage only the first tile of the pass (results are wrong, the control flow stays finite)
-      if (t == tile_begin) stage_tile<G, R, NT>(a.other, lo, hi, lds);
+      if (t == tile_begin) stage_tile<G, R, NT, ROT>(a.other, lo, hi, lds);
 #else
-      stage_tile<G, R, NT>(a.other, lo, hi, lds);
+      stage_tile<G, R, NT, ROT>(a.other, lo, hi, lds);
 #endif
       __syncthreads();
     }
@@ -277,19 +312,19 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
           ok[u] = (u == 0 || ok[u - 1]) && c[u] < (int)hi; // c == INT_MAX past the end of the segment
         }
         if (ok[0]) {
-          const char* base = L2 ? mem + j * 16 : mem + j * 16 - (int)lo * ROWB;
-          const char* rp[G];
+          const char* rp[G]; // L2: address of the lane's first chunk
+          int ro[G];         // LDS tile: its byte offset in the tile
           double p[G];
           bool mine = false;
 #pragma unroll
           for (int u = 0; u < G; ++u) {
-            if constexpr (L2) rp[u] = base + (int64_t)(ok[u] ? c[u] : c[0]) * ROWB;
-            else rp[u] = base + (ok[u] ? c[u] : c[0]) * ROWB;
+            if constexpr (L2) rp[u] = mem + j * 16 + (int64_t)(ok[u] ? c[u] : c[0]) * ROWB;
+            else ro[u] = ((ok[u] ? c[u] : c[0]) - (int)lo) * ROWB + jrot;
             mine = (j == u) ? ok[u] : mine;
             p[u] = 0.0;
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) {
-              const double2 y = *reinterpret_cast<const double2*>(rp[u] + i * (2 * G * 8));
+              const double2 y = L2 ? *reinterpret_cast<const double2*>(rp[u] + i * CB) : tile_chunk<ROT, CB>(mem, ro[u], i);
               p[u] = fma(xv.v[i].x, y.x, p[u]);
               p[u] = fma(xv.v[i].y, y.y, p[u]);
             }
@@ -335,7 +370,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
               const double d = group_bcast_f64<G>(dL, u, lane);
 #pragma unroll
               for (int i = 0; i < R / 2; ++i) {
-                const double2 y = *reinterpret_cast<const double2*>(rp[u] + i * (2 * G * 8));
+                const double2 y = L2 ? *reinterpret_cast<const double2*>(rp[u] + i * CB) : tile_chunk<ROT, CB>(mem, ro[u], i);
                 g.v[i].x = fma(d, y.x, g.v[i].x);
                 g.v[i].y = fma(d, y.y, g.v[i].y);
               }
@@ -355,13 +390,21 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
         const bool ok0 = !done && c0 < (int)hi; // c == INT_MAX past the end of the segment
         const bool ok1 = ok0 && c1 < (int)hi;
         if (ok0) {
-          const char* rp0 = L2 ? mem + (int64_t)c0 * ROWB + j * 16 : mem + (c0 - (int)lo) * ROWB + j * 16;
-          const char* rp1 = L2 ? mem + (int64_t)(ok1 ? c1 : c0) * ROWB + j * 16 : mem + ((ok1 ? c1 : c0) - (int)lo) * ROWB + j * 16;
           double2 y0[R / 2], y1[R / 2];
+          if constexpr (L2) {
+            const char* rp0 = mem + (int64_t)c0 * ROWB + j * 16;
+            const char* rp1 = mem + (int64_t)(ok1 ? c1 : c0) * ROWB + j * 16;
 #pragma unroll
-          for (int i = 0; i < R / 2; ++i) y0[i] = *reinterpret_cast<const double2*>(rp0 + i * (2 * G * 8));
+            for (int i = 0; i < R / 2; ++i) y0[i] = *reinterpret_cast<const double2*>(rp0 + i * CB);
 #pragma unroll
-          for (int i = 0; i < R / 2; ++i) y1[i] = *reinterpret_cast<const double2*>(rp1 + i * (2 * G * 8));
+            for (int i = 0; i < R / 2; ++i) y1[i] = *reinterpret_cast<const double2*>(rp1 + i * CB);
+          } else {
+            const int ro0 = (c0 - (int)lo) * ROWB + jrot, ro1 = ((ok1 ? c1 : c0) - (int)lo) * ROWB + jrot;
+#pragma unroll
+            for (int i = 0; i < R / 2; ++i) y0[i] = tile_chunk<ROT, CB>(mem, ro0, i);
+#pragma unroll
+            for (int i = 0; i < R / 2; ++i) y1[i] = tile_chunk<ROT, CB>(mem, ro1, i);
+          }
           double p0 = 0.0, p1 = 0.0;
 #pragma unroll
           for (int i = 0; i < R / 2; ++i) {
@@ -584,19 +627,21 @@ __global__ void __launch_bounds__(NW * 64, L2 ? 1 : 4) tiled_col_pass_kernel(con
   const int tb = sup * a.tiles_per_sup;
   const int te = tb + a.tiles_per_sup < ntiles ? tb + a.tiles_per_sup : ntiles;
   const double2* xp = reinterpret_cast<const double2*>(GRAD ? a.own + gseg * KP : a.trial + (have ? seg : 0) * (int64_t)KP);
+  constexpr bool ROT = !L2 && LW == 0 && LOSS != 0 && tile_rot<G, R>();
+  const int rot = ROT ? tile_rot_of(gseg) : 0; // register i <-> chunk i ^ rot (conflict-free tile reads, see tile_rot)
   Vec<G, R> x, g;
 #pragma unroll
-  for (int i = 0; i < R / 2; ++i) x.v[i] = have ? xp[i * G + j] : make_double2(0.0, 0.0);
+  for (int i = 0; i < R / 2; ++i) x.v[i] = have ? xp[(i ^ rot) * G + j] : make_double2(0.0, 0.0);
   LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
   if constexpr (loss_mode(LOSS) != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
   int64_t pos = have ? lower_bound_idx<G>(a.idx, beg, end, (int64_t)tb * TILE) : 0;
   double J;
-  tiled_pass<G, R, NW, TILE, LOSS, GRAD, L2, LW>(a, lds, x, g, J, have, pos, end, tb, te, segloss, lane, j);
+  tiled_pass<G, R, NW, TILE, LOSS, GRAD, L2, LW, ROT>(a, lds, x, g, J, have, pos, end, tb, te, segloss, lane, j, rot);
   if (have) {
     double* p = a.part + ((int64_t)seg * a.nsup + sup) * PSTRIDE;
     if (GRAD) {
 #pragma unroll
-      for (int i = 0; i < R / 2; ++i) *reinterpret_cast<double2*>(p + i * 2 * G + 2 * j) = g.v[i];
+      for (int i = 0; i < R / 2; ++i) *reinterpret_cast<double2*>(p + (i ^ rot) * 2 * G + 2 * j) = g.v[i];
     }
     if (j == 0) p[KP] = J;
   }
