@@ -112,7 +112,12 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
         cands.append(dict(bound="l2", achieved=staged / t / 1e9, peak=L2_PEAK_GBS, unit="GB/s", per_launch=staged,
                           what="tile staging: workgroups x P x opposing factor bytes (L2 -> LDS)"))
         cands.append(dict(bound="lds", achieved=nnz * P * 8 * ld / t / 1e9, peak=LDS_PEAK_GBS, unit="GB/s", per_launch=nnz * P * 8 * ld,
-                          what="LDS reads: one opposing vector (8 ld bytes) per update and pass"))
+                          what="LDS reads: one opposing vector (8 ld bytes) per update and pass",
+                          # tools/ubench_lanerow.hip, profiles/r02_ubench_lanerow.txt: random 256-byte row reads by 4-lane groups and
+                          # NOTHING else reach 63 TB/s with the padded rows (bank conflicts between the four groups of an LDS cycle)
+                          # and 118 TB/s conflict-free; the sweeps turned out not to be bound by either (profiles/r02_rot_ab.txt)
+                          measured_ceiling=dict(padded_rows=63000.0, conflict_free=118000.0, unit="GB/s",
+                                                source="profiles/r02_ubench_lanerow.txt")))
     else:
         # 'gather' and 'blocked' share one byte model: every update fetches its k-vector from the memory system.  The phase-aligned
         # passes ('blocked') only change WHERE the window all groups read at a time sits: in the Infinity Cache (measured 8.2 TB/s
