@@ -80,7 +80,7 @@ def algorithmic_bytes_per_update(k):
 
 # ----------------------------------------------------------------------------- rooflines
 
-def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, segs_per_wg=256):
+def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, segs_per_wg=256, quad_gram=False):
     """Candidate limiters of ONE half-step (all its launches) of the given kernel family, each as achieved/peak.
 
     family   'gather'  every update fetches the opposing k-vector from memory (csrc/glrm_hip.hip sweep_kernel)
@@ -99,11 +99,15 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
     opp = nopp * ld * 8
     cands = []
     if family == "dense":
-        flops = 6.0 * m * n * k                  # three m x n x k products per half-step (u, gradient, first trial): 12mnk per iteration
-        cands.append(dict(bound="mfma", achieved=flops / t / 1e12, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", per_launch=flops,
-                          what="6 m n k flop per half-step (SURVEY 8(d): 12 m n k per outer iteration)"))
-        cands.append(dict(bound="hbm", achieved=P * m * n * 8 / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=P * m * n * 8,
-                          what="A streamed once per pass, 2 passes"))
+        if quad_gram:  # glrm_options.quad_gram: the trial is O(k^2) per segment from the quadratic form -- one pass over A per half-step
+            flops, passes = 4.0 * m * n * k, 1
+            what = "4 m n k flop per half-step: residual and gradient products; the trial comes from J(x) + g.s + s'(YY')s (quad_gram)"
+        else:
+            flops, passes = 6.0 * m * n * k, P  # three m x n x k products per half-step (u, gradient, first trial): 12mnk per iteration
+            what = "6 m n k flop per half-step (SURVEY 8(d): 12 m n k per outer iteration)"
+        cands.append(dict(bound="mfma", achieved=flops / t / 1e12, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", per_launch=flops, what=what))
+        cands.append(dict(bound="hbm", achieved=passes * m * n * 8 / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=passes * m * n * 8,
+                          what="A streamed once per pass, %d pass%s per half-step" % (passes, "es" if passes > 1 else "")))
     elif family == "tiled":
         nwg = max(1, -(-nseg // segs_per_wg))
         staged = nwg * P * opp                   # every workgroup stages the whole opposing factor once per pass
@@ -239,7 +243,7 @@ def pmc_traffic(args, kernel_re, per_halfstep=False, child_env=None):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="glrm_pmc_", dir="/tmp")
         cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-               "--config", args.config, "--rows", str(args.rows), "--steps", "2", "--warmup", str(max(args.warmup, 1)), "--tiled", str(args.tiled),
+               "--config", args.config, "--rows", str(args.rows), "--steps", "2", "--warmup", str(max(args.warmup, 1)), "--tiled", str(args.tiled), *(["--quad-gram"] if args.quad_gram else []),
                "--no-cpu-baseline", "--no-convergence-run", "--no-jref", "--pmc", "off", "--seed", str(args.seed),
                "--cols", str(args.cols), "--obs-per-row", str(args.obs_per_row), "--rank", str(args.k)]
         env = dict(os.environ, TMPDIR="/tmp", **(child_env or {}))
@@ -287,6 +291,7 @@ def main():
     ap.add_argument("--waves-row", type=int, default=0)
     ap.add_argument("--waves-col", type=int, default=0)
     ap.add_argument("--tiled", type=int, default=0, help="0 auto, 1 gather sweeps only, 2 LDS-tiled sweeps")
+    ap.add_argument("--quad-gram", action="store_true", help="C3 only: glrm_options.quad_gram (line-search trials from the quadratic form, no pass over A per trial)")
     ap.add_argument("--x-chunks", type=int, default=4, help="N > 1: row chunks of the X half-step whose all-gather overlaps the next chunk")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
@@ -345,7 +350,7 @@ def main():
     t_gen = time.time() - t_gen
     t_create = time.time()
     sf = ShardedFit(api, w.problem(), rbs, cbs, device=device, stream=torch.cuda.current_stream().cuda_stream,
-                    opts=dict(profile=1, waves_row=args.waves_row, waves_col=args.waves_col, tiled=args.tiled),
+                    opts=dict(profile=1, waves_row=args.waves_row, waves_col=args.waves_col, tiled=args.tiled, quad_gram=1 if args.quad_gram else 0),
                     x_chunks=args.x_chunks if args.config != "C3" else 1)
     nnz_r, nnz_c = w.nnz_rows, w.nnz_cols
     w.free_sources()
@@ -425,8 +430,8 @@ def main():
         fam_c = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 2 else "blocked" if flags & 32 else "gather"
         ld = st["ld"]
         tile = 150 * 1024 // (ld * 8 + 16) // 16 * 16  # csrc/glrm_tiled.hip: tile_rows_c
-        rl_r = kernel_roofline(fam_r, nnz=nnz_r, nseg=nseg_r, nopp=n, k=k, ld=ld, ms=ms_x, m=nseg_r, n=n, tile=tile)
-        rl_c = kernel_roofline(fam_c, nnz=nnz_c, nseg=nseg_c, nopp=m, k=k, ld=ld, ms=ms_y, m=m, n=nseg_c, tile=tile)
+        rl_r = kernel_roofline(fam_r, nnz=nnz_r, nseg=nseg_r, nopp=n, k=k, ld=ld, ms=ms_x, m=nseg_r, n=n, tile=tile, quad_gram=args.quad_gram)
+        rl_c = kernel_roofline(fam_c, nnz=nnz_c, nseg=nseg_c, nopp=m, k=k, ld=ld, ms=ms_y, m=m, n=nseg_c, tile=tile, quad_gram=args.quad_gram)
         # dominant kernel = the longer half-step
         dom = "row" if ms_x >= ms_y else "col"
         rl, dom_ms, dom_nnz, dom_fam = (rl_r, ms_x, nnz_r, fam_r) if dom == "row" else (rl_c, ms_y, nnz_c, fam_c)
@@ -472,7 +477,8 @@ def main():
             "metric": "observed-entry updates/sec", "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": cfg["text"].format(m=m, n=n, k=k, pct=100.0 * q / n) + f" ({tot_r} observations), ProxGradParams defaults, stop rule off",
+            "config": {"workload": cfg["text"].format(m=m, n=n, k=k, pct=100.0 * q / n) + f" ({tot_r} observations), ProxGradParams defaults, stop rule off"
+                                   + (", glrm_options.quad_gram = 1" if args.quad_gram else ""),
                        "name": args.config, "m": m, "n": n, "k": k, "observed": tot_r,
                        "full_size": m == CONFIGS[args.config]["rows"] and n == CONFIGS[args.config]["cols"] and k == CONFIGS[args.config]["k"], "start": INIT_NOTE[nonneg_start(cfg)], "regularizer": REG_NAME.get(reg[0], str(reg)),
                        "parallelism": f"rows/cols sharded over {world} GPU(s) ({args.scaling} scaling), X,Y replicated",

@@ -197,6 +197,13 @@ typedef struct glrm_options {
                             what a host that orders its own collectives on that stream must pass */
   int32_t tiled;     /* sweep kernels: 0 = choose (LDS-tiled when the index lists are tile-ordered -- e.g. sorted -- and the
                         problem is large enough), 1 = gather sweeps only, 2 = LDS-tiled sweeps wherever the lists allow */
+  int32_t quad_gram; /* dense_A hand-over only.  1 = the line-search trials of a half-step are evaluated from the quadratic form
+                        J(x') = J(x) + g.(x'-x) + scale (x'-x)' (Y Y') (x'-x) instead of one more pass over A per trial (the
+                        objective of a fully observed QuadLoss row IS that quadratic; Y Y' is shared by all rows).  Same
+                        algorithm and iterates as row_objective (src/evaluate_fit.jl:24-38) up to rounding (<< 1e-5; a trial whose
+                        decrease is below the rounding of the two sums the reference compares may be decided differently).
+                        0 = evaluate every trial by a pass over A, like the reference.  Default 0. */
+  int32_t reserved;  /* must be 0 */
 } glrm_options;
 
 typedef struct glrm_handle glrm_handle;

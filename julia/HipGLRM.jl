@@ -44,24 +44,24 @@ struct CParams
     stepsize::Float64; max_iter::Int64; inner_iter_X::Int64; inner_iter_Y::Int64
     abs_tol::Float64; rel_tol::Float64; min_stepsize::Float64
 end
-struct COptions; device_id::Int32; profile::Int32; waves_row::Int32; waves_col::Int32; stream::Ptr{Cvoid}; caller_stream::Int32; tiled::Int32; end
+struct COptions; device_id::Int32; profile::Int32; waves_row::Int32; waves_col::Int32; stream::Ptr{Cvoid}; caller_stream::Int32; tiled::Int32; quad_gram::Int32; reserved::Int32; end
 struct CMultiOptions; n_shards::Int32; exchange::Int32; device_ids::Ptr{Int32}; x_chunks::Int32; reserved::Int32; end
 
 "The 7 ProxGradParams fields (src/algorithms/proxgrad.jl:4-12) + where to run: `device_id` (one GPU) or `ngpus` / `device_ids`."
 mutable struct HipProxGradParams <: AbstractParams
     stepsize::Float64; max_iter::Int; inner_iter_X::Int; inner_iter_Y::Int
     abs_tol::Float64; rel_tol::Float64; min_stepsize::Float64
-    device_id::Int; ngpus::Int; device_ids::Vector{Int32}; exchange::Symbol; x_chunks::Int; dense::Bool
+    device_id::Int; ngpus::Int; device_ids::Vector{Int32}; exchange::Symbol; x_chunks::Int; dense::Bool; quad_gram::Bool
 end
 function HipProxGradParams(stepsize::Number=1.0; max_iter::Int=100, inner_iter_X::Int=1, inner_iter_Y::Int=1,
                            inner_iter::Int=1, abs_tol::Number=0.00001, rel_tol::Number=0.0001,
                            min_stepsize::Number=0.01*stepsize, device_id::Int=-1, ngpus::Int=1,
-                           device_ids=Int32.(0:ngpus-1), exchange::Symbol=:direct, x_chunks::Int=4, dense::Bool=true)
+                           device_ids=Int32.(0:ngpus-1), exchange::Symbol=:direct, x_chunks::Int=4, dense::Bool=true, quad_gram::Bool=false)
     length(device_ids) == ngpus || error("device_ids must list one device per shard")
     exchange in (:direct, :rccl) || error("exchange must be :direct or :rccl")
     HipProxGradParams(Float64(stepsize), max_iter, max(inner_iter_X, inner_iter), max(inner_iter_Y, inner_iter),
                       Float64(abs_tol), Float64(rel_tol), Float64(min_stepsize), device_id, ngpus, Vector{Int32}(device_ids),
-                      exchange, x_chunks, dense)
+                      exchange, x_chunks, dense, quad_gram)
 end
 
 closs(l::QuadLoss) = CLoss(0, 0, l.scale, 0, 0)
@@ -142,7 +142,7 @@ hip_release!(glrm::GLRM) = (haskey(CACHE, glrm) && (destroy(CACHE[glrm]); delete
 # what the device copy depends on (data, Omega, losses, placement) / what set_regularizers can replace
 hardkey(glrm, desc, p, dense) = hash((objectid(glrm.A), size(glrm.A), glrm.k, objectid(glrm.observed_features), objectid(glrm.observed_examples),
                                       sum(length, glrm.observed_features), sum(length, glrm.observed_examples), desc[1],
-                                      length(desc[2]), length(desc[3]), p.device_id, p.ngpus, p.device_ids, p.exchange, p.x_chunks, dense))
+                                      length(desc[2]), length(desc[3]), p.device_id, p.ngpus, p.device_ids, p.exchange, p.x_chunks, dense, p.quad_gram))
 softkey(desc) = hash((desc[2], desc[3]))
 
 function handle(glrm::GLRM, desc, p::HipProxGradParams)
@@ -167,7 +167,7 @@ function handle(glrm::GLRM, desc, p::HipProxGradParams)
         prob = CProblem(m, n, glrm.k, 0, 0, m, 0, n, nul(rowptr), nul(colidx), nul(rowvals), nul(colptr), nul(rowidx), nul(colvals),
                         pointer(losses), length(losses), pointer(rx), length(rx), pointer(ry), length(ry),
                         dense ? pointer(A) : Ptr{Float64}(C_NULL), dense ? m : 0, dense ? 1 : 0, 0)   # Julia's A is column-major
-        opt = COptions(p.device_id, 0, 0, 0, C_NULL, 0, 0)
+        opt = COptions(p.device_id, 0, 0, 0, C_NULL, 0, 0, p.quad_gram ? 1 : 0, 0)
         if multi
             mo = CMultiOptions(p.ngpus, p.exchange == :rccl ? 1 : 0, pointer(p.device_ids), p.x_chunks, 0)
             check(ccall((:glrm_hip_multi_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{CProblem}, Ref{COptions}, Ref{CMultiOptions}), h, prob, opt, mo))

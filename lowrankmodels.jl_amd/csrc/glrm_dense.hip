@@ -119,7 +119,34 @@ int glrm_setup_dense(glrm_handle* h, const glrm_problem* p) {
   if ((rc = alloc_arr(&h->activebuf, nl1))) return rc;
   if ((rc = alloc_arr(&h->ntrialbuf, nl1))) return rc;
   if ((rc = alloc_arr(&h->nactive, 1))) return rc;
+  // glrm_options.quad_gram (GLRM_HIP_DENSE_GRAM overrides): line-search trials from the quadratic form, no pass over A per trial
+  h->dense_gram = env_int("GLRM_HIP_DENSE_GRAM", h->opts.quad_gram ? 1 : 0) != 0;
+  if (h->dense_gram) {
+    if ((rc = alloc_arr(&h->gramH, (int64_t)h->kp * h->kp))) return rc;
+    if ((rc = alloc_arr(&h->gram_part, (int64_t)GRAM_BLOCKS * h->kp * h->kp))) return rc;
+    if ((rc = alloc_arr(&h->jloss_r, ml1))) return rc;
+    if ((rc = alloc_arr(&h->jloss_c, nl1))) return rc;
+  }
   return GLRM_OK;
+}
+
+template <int KP>
+static void launch_gram_inst(int which, const TiledArgs& a, const double* other, int64_t n_other, double* part, double* H, double scale, hipStream_t st) {
+  if (which == 0) {
+    hipLaunchKernelGGL((dense_gram_partial_kernel<KP>), dim3(GRAM_BLOCKS), dim3(256), 0, st, other, n_other, part);
+    hipLaunchKernelGGL((dense_gram_final_kernel<KP>), dim3((KP * KP + 255) / 256), dim3(256), 0, st, part, H);
+  } else {
+    hipLaunchKernelGGL((dense_gram_trial_kernel<KP>), dim3((unsigned)((a.nseg + 255) / 256)), dim3(256), 0, st, a, H, scale);
+  }
+}
+
+// which = 0: H = other other' (kp x kp); which = 1: the trial objectives of the active segments from the quadratic form
+static void launch_gram(int kp, int which, const TiledArgs& a, const double* other, int64_t n_other, double* part, double* H, double scale, hipStream_t st) {
+  switch (kp) {
+    case 16: launch_gram_inst<16>(which, a, other, n_other, part, H, scale, st); break;
+    case 32: launch_gram_inst<32>(which, a, other, n_other, part, H, scale, st); break;
+    default: launch_gram_inst<64>(which, a, other, n_other, part, H, scale, st); break;
+  }
 }
 
 template <int KP, int NWD>
@@ -188,7 +215,10 @@ int glrm_run_dense(glrm_handle* h, bool rows, double min_stepsize, int eval_only
   a.nactive = h->nactive;
   a.eval_only = eval_only;
   a.fixed_alpha = eval_only ? 0.0 : h->fixed_alpha;
+  const bool gram = h->dense_gram && !eval_only && a.fixed_alpha <= 0.0;
+  a.jloss = gram ? (rows ? h->jloss_r : h->jloss_c) : nullptr;
   HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
+  if (gram) launch_gram(h->kp, 0, a, d.other, d.n_other, h->gram_part, h->gramH, d.scale, h->stream);
   launch_dense_any(h->kp, true, d, h->stream);
   glrm_launch_col_small(h->kp, 0, a, h->stream);
   HIPCK(hipGetLastError());
@@ -202,7 +232,8 @@ int glrm_run_dense(glrm_handle* h, bool rows, double min_stepsize, int eval_only
     HIPCK(hipStreamSynchronize(h->stream));
     if (nact == 0) break;
     HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
-    launch_dense_any(h->kp, false, t, h->stream);
+    if (gram) launch_gram(h->kp, 1, a, d.other, d.n_other, h->gram_part, h->gramH, d.scale, h->stream);
+    else launch_dense_any(h->kp, false, t, h->stream);
     glrm_launch_col_small(h->kp, 1, a, h->stream);
     HIPCK(hipGetLastError());
   }

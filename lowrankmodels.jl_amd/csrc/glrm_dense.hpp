@@ -22,6 +22,7 @@
 #pragma once
 
 #include "glrm_device.hpp"
+#include "glrm_tiled.hpp"
 
 namespace glrm {
 
@@ -144,6 +145,88 @@ __global__ void __launch_bounds__(NWD * 64) dense_pass_kernel(const DenseArgs a)
       }
     }
   }
+}
+
+// ---- glrm_options.quad_gram (SURVEY.md 7.2 "K5"): trials without another pass over A -------------------------------------------
+// The loss of a fully observed QuadLoss segment is a quadratic in its factor vector: with r_c = x.y_c - a_c and s = x' - x,
+//   J(x') = scale sum_c (r_c + s.y_c)^2 = J(x) + g.s + scale s'Hs,   g = 2 scale sum_c r_c y_c,   H = sum_c y_c y_c' = Y Y',
+// and H is the SAME k x k matrix for every segment of the half-step because every segment sees all opposing vectors.  The gradient
+// pass already delivers J(x) and g; H costs one pass over the opposing FACTOR (not over A); every trial is then O(k^2) per segment.
+// Deterministic: H is summed in GRAM_BLOCKS fixed chunks of the opposing vectors (chunking depends on their number only), each chunk
+// sequentially, the chunk sums in order.
+constexpr int GRAM_BLOCKS = 256;
+
+template <int KP>
+__global__ void __launch_bounds__(256) dense_gram_partial_kernel(const double* __restrict__ other, int64_t n_other, double* __restrict__ part) {
+  constexpr int PAIRS = KP * KP, PER = (PAIRS + 255) / 256, TV = 32; // vectors staged per round
+  __shared__ double v[TV][KP];
+  const int64_t chunk = (n_other + GRAM_BLOCKS - 1) / GRAM_BLOCKS;
+  const int64_t lo = (int64_t)blockIdx.x * chunk, hi = lo + chunk < n_other ? lo + chunk : n_other;
+  double acc[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) acc[q] = 0.0;
+  for (int64_t t0 = lo; t0 < hi; t0 += TV) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < TV * KP; e += 256) {
+      const int64_t vec = t0 + e / KP;
+      v[e / KP][e % KP] = vec < hi ? other[vec * KP + e % KP] : 0.0;
+    }
+    __syncthreads();
+    for (int t = 0; t < TV; ++t) {
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int pr = threadIdx.x + 256 * q;
+        if (pr < PAIRS) acc[q] = fma(v[t][pr / KP], v[t][pr % KP], acc[q]);
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int pr = threadIdx.x + 256 * q;
+    if (pr < PAIRS) part[(int64_t)blockIdx.x * PAIRS + pr] = acc[q];
+  }
+}
+
+template <int KP>
+__global__ void __launch_bounds__(256) dense_gram_final_kernel(const double* __restrict__ part, double* __restrict__ H) {
+  const int pr = blockIdx.x * 256 + threadIdx.x;
+  if (pr >= KP * KP) return;
+  double s = 0.0;
+  for (int b = 0; b < GRAM_BLOCKS; ++b) s += part[(int64_t)b * KP * KP + pr];
+  H[pr] = s;
+}
+
+// One thread per segment: s = trial - own, J' = jloss + g.s + scale s'Hs, delivered where the trial pass would have left its
+// partial sums (super-tile 0 carries the value, the others zero) so that col_decide_kernel runs unchanged.
+template <int KP>
+__global__ void __launch_bounds__(256) dense_gram_trial_kernel(const TiledArgs a, const double* __restrict__ Hg, double scale) {
+  __shared__ double H[KP * KP];
+  for (int e = threadIdx.x; e < KP * KP; e += 256) H[e] = Hg[e];
+  __syncthreads();
+  const int64_t seg = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (seg >= a.nseg || a.active[seg] == 0) return;
+  const double* own = a.own + (a.own_offset + seg) * KP;
+  const double* tr = a.trial + seg * (int64_t)KP;
+  const double* g = a.gsum + seg * (int64_t)KP;
+  double s[KP];
+  double gs = 0.0;
+#pragma unroll
+  for (int i = 0; i < KP; ++i) {
+    s[i] = tr[i] - own[i];
+    gs = fma(g[i], s[i], gs);
+  }
+  double q = 0.0;
+#pragma unroll
+  for (int i = 0; i < KP; ++i) { // rows of H from LDS (every lane reads the same word: broadcast)
+    double t = 0.0;
+#pragma unroll
+    for (int jj = 0; jj < KP; ++jj) t = fma(H[i * KP + jj], s[jj], t);
+    q = fma(s[i], t, q);
+  }
+  constexpr int PSTRIDE = KP + 2;
+  double* p = a.part + (int64_t)seg * a.nsup * PSTRIDE + KP;
+  p[0] = (a.jloss[seg] + gs) + scale * q;
+  for (int sp = 1; sp < a.nsup; ++sp) p[(int64_t)sp * PSTRIDE] = 0.0;
 }
 
 // Pack a block of the caller's dense matrix into the padded row-major layout the pass kernel streams:

@@ -84,6 +84,10 @@ struct glrm_handle {
   int64_t vps_r = 0, vps_c = 0;           // opposing vectors per super-tile
   double *part_r = nullptr, *gsum_r = nullptr, *trial_r = nullptr, *jold_r = nullptr;
   int32_t *active_r = nullptr, *ntrial_r = nullptr;
+  // glrm_options.quad_gram: trials from the quadratic form (glrm_dense.hpp: dense_gram_*)
+  bool dense_gram = false;
+  double *gramH = nullptr, *gram_part = nullptr; // [kp*kp], [GRAM_BLOCKS][kp*kp]
+  double *jloss_r = nullptr, *jloss_c = nullptr; // loss sum at the current point, per local segment
   int64_t rb = 0, re = 0, cb = 0, ce = 0, ml = 0, nl = 0, nnz_r = 0, nnz_c = 0;
   int64_t *rowptr = nullptr, *colptr = nullptr;
   int32_t *colidx = nullptr, *rowidx = nullptr;

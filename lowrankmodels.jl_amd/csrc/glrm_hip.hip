@@ -554,7 +554,8 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
                   h->trials_r, h->accepts_r, h->trials_c, h->accepts_c, h->part, h->gsum, h->trialbuf, h->joldbuf,
                   h->activebuf, h->ntrialbuf, h->nactive, h->dflag, h->Arow, h->Acol, h->part_r, h->gsum_r, h->trial_r,
                   h->jold_r, h->active_r, h->ntrial_r, h->ystart, h->mtrial, h->mpart_loss, h->mpart_G, h->mgtot,
-                  h->mobjold, h->mactive, h->mnactive, h->colperm, h->rowperm, h->seglist_r, h->seglist_c, h->rowdescid, h->udesc};
+                  h->mobjold, h->mactive, h->mnactive, h->colperm, h->rowperm, h->seglist_r, h->seglist_c, h->rowdescid, h->udesc,
+                  h->gramH, h->gram_part, h->jloss_r, h->jloss_c};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->iter_exec) (void)hipGraphExecDestroy(h->iter_exec);
@@ -610,6 +611,7 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   h->unroll_col = env_int("GLRM_HIP_UNROLL_COL", 1) == 2 ? 2 : 1;
   h->profile = o ? o->profile : 0;
   h->tiled_opt = o ? o->tiled : 0;
+  if (o && o->reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_options.reserved must be 0");
   if (o) h->opts = *o; else { h->opts = glrm_options{}; h->opts.device_id = -1; }
   h->losses_h.assign(p->losses, p->losses + p->n_losses);
   h->rx_h.assign(p->rx, p->rx + p->n_rx);

@@ -50,6 +50,7 @@ struct TiledArgs {
   double* gsum;          // [nseg][KP]   reduced gradient (kept for later trials)
   double* trial;         // [nseg][KP]   current trial point
   double* jold;          // [nseg]
+  double* jloss;         // [nseg] nullable: col_reduce stores the loss sum at the current point (dense path, quad_gram trials)
   int32_t* active;       // [nseg] 1 while the segment's line search is still running
   int32_t* ntrial;       // [nseg] trials taken in this sweep
   unsigned int* nactive; // device counter of still-active segments
@@ -694,6 +695,7 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const TiledArgs a) {
     return;
   }
   const double Jold = J + reg_eval<G, R>(rd, y, j, a.k);
+  if (a.jloss && j == 0) a.jloss[seg] = J;
   const double alpha = a.alpha[seg];
   const double l = (double)(a.ptr ? a.ptr[seg + 1] - a.ptr[seg] : a.dense_len) + 1.0;
   const bool searching = alpha > a.min_stepsize;

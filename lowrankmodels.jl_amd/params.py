@@ -31,8 +31,11 @@ class HipProxGradParams(ProxGradParams):
     dispatches on it exactly like on the built-in solvers (src/fit.jl:8-12)."""
 
     def __init__(self, stepsize=1.0, *, device_id=-1, profile=False, waves_row=0, waves_col=0, tiled=0, dense=True, ngpus=1,
-                 device_ids=None, exchange="direct", x_chunks=0, **kw):
+                 device_ids=None, exchange="direct", x_chunks=0, quad_gram=False, **kw):
         super().__init__(stepsize, **kw)
+        # fully observed QuadLoss models only (glrm_options.quad_gram, SURVEY.md 7.2 K5): line-search trials from the quadratic form
+        # J(x) + g.s + scale s'(YY')s instead of another pass over A; same iterates up to rounding.  Off by default.
+        self.quad_gram = bool(quad_gram)
         self.device_id, self.profile = int(device_id), bool(profile)
         self.waves_row, self.waves_col, self.tiled = int(waves_row), int(waves_col), int(tiled)
         self.dense = bool(dense)  # fully observed QuadLoss models: run the half-steps on the matrix cores

@@ -55,7 +55,7 @@ def test_oracle_exports_the_same_entry_points():
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_capi.CLoss) == 32 and ctypes.sizeof(_capi.CReg) == 16
-    assert ctypes.sizeof(_capi.CParams) == 56 and ctypes.sizeof(_capi.COptions) == 32
+    assert ctypes.sizeof(_capi.CParams) == 56 and ctypes.sizeof(_capi.COptions) == 40
     assert ctypes.sizeof(_capi.CProblem) == 8 * 2 + 4 * 2 + 8 * 4 + 8 * 6 + 8 * 6 + 8 * 2 + 4 * 2
     assert ctypes.sizeof(_capi.CKernelStats) == 8 * 2 + 8 * 2 + 8 * 6 + 4 * 4
 

@@ -24,10 +24,12 @@ def dense_case(rng, m, n, k, rx, ry, scale=1.0, noise=0.1):
     return g, np.asfortranarray(X0), np.asfortranarray(Y0)
 
 
-def compare_dense(g, X0, Y0, params):
+def compare_dense(g, X0, Y0, params, quad_gram=0):
+    """quad_gram = 1: glrm_options.quad_gram -- the line-search trials come from the quadratic form J(x) + g.s + scale s'(YY')s instead
+    of a pass over A; same tolerances against the oracle (which evaluates every trial like the reference)."""
     O.set_threads(4)
     o_c, X_c, Y_c, st_c = cases.run_engine(O.oracle_api(), g.problem_arrays(), X0, Y0, params)
-    o_g, X_g, Y_g, st_g = cases.run_engine(hip(), g.problem_arrays(dense=True), X0, Y0, params)
+    o_g, X_g, Y_g, st_g = cases.run_engine(hip(), g.problem_arrays(dense=True), X0, Y0, params, quad_gram=quad_gram)
     assert st_g["tiled"] & 4, "the dense MFMA path was not taken"
     assert len(o_g) == len(o_c)
     e = (cases.rel_err(o_g, o_c), cases.fro_err(X_g, X_c), cases.fro_err(Y_g, Y_c))
@@ -40,27 +42,30 @@ def compare_dense(g, X0, Y0, params):
 
 @pytest.mark.parametrize("m,n,k", [(150, 90, 9), (64, 64, 16), (333, 257, 32), (100, 100, 33), (200, 130, 64), (17, 1000, 20),
                                    (1000, 17, 12)])
-def test_dense_path_matches_oracle(m, n, k):
+@pytest.mark.parametrize("quad_gram", [0, 1])
+def test_dense_path_matches_oracle(m, n, k, quad_gram):
     rng = np.random.default_rng(1000 + m + n + k)
     g, X0, Y0 = dense_case(rng, m, n, k, L.QuadReg(0.1), L.QuadReg(0.1))
-    compare_dense(g, X0, Y0, L.ProxGradParams(max_iter=15))
+    compare_dense(g, X0, Y0, L.ProxGradParams(max_iter=15), quad_gram)
 
 
 @pytest.mark.parametrize("name", ["zero", "nonneg", "one", "scaled"])
-def test_dense_path_regularizers_and_scale(name):
+@pytest.mark.parametrize("quad_gram", [0, 1])
+def test_dense_path_regularizers_and_scale(name, quad_gram):
     rng = np.random.default_rng(5)
     rx, ry, scale = {"zero": (L.ZeroReg(), L.ZeroReg(), 1.0), "nonneg": (L.NonNegConstraint(), L.NonNegConstraint(), 1.0),
                      "one": (L.OneReg(0.2), L.QuadReg(0.3), 1.0), "scaled": (L.QuadReg(0.1), L.ZeroReg(), 2.5)}[name]
     g, X0, Y0 = dense_case(rng, 180, 140, 24, rx, ry, scale)
-    compare_dense(g, X0, Y0, L.ProxGradParams(max_iter=20))
+    compare_dense(g, X0, Y0, L.ProxGradParams(max_iter=20), quad_gram)
 
 
-def test_dense_per_row_regularizers_and_inner_iterations():
+@pytest.mark.parametrize("quad_gram", [0, 1])
+def test_dense_per_row_regularizers_and_inner_iterations(quad_gram):
     rng = np.random.default_rng(6)
     kinds = [L.QuadReg(0.3), L.OneReg(0.2), L.NonNegConstraint(), L.ZeroReg()]
     m, n, k = 120, 70, 16
     g, X0, Y0 = dense_case(rng, m, n, k, [kinds[i % 4] for i in range(m)], L.QuadReg(0.05))
-    compare_dense(g, X0, Y0, L.ProxGradParams(max_iter=8, inner_iter=3))
+    compare_dense(g, X0, Y0, L.ProxGradParams(max_iter=8, inner_iter=3), quad_gram)
 
 
 def test_host_level_fit_takes_the_dense_path_and_agrees_with_lists():
@@ -82,17 +87,37 @@ def test_host_level_fit_takes_the_dense_path_and_agrees_with_lists():
     gd.close(); gl.close()
 
 
-def test_dense_two_shards_equal_one_shard():
+def test_quad_gram_follows_the_pass_over_A_to_convergence():
+    """glrm_options.quad_gram against the default on a run to the reference's own stop rule (host-level API): same number of
+    iterations, objective and factors to 1e-9 -- and against the oracle to the usual tolerance."""
+    rng = np.random.default_rng(17)
+    m, n, k = 400, 300, 32
+    A = rng.standard_normal((m, 6)) @ rng.standard_normal((6, n)) + 0.05 * rng.standard_normal((m, n))
+    X0, Y0 = rng.standard_normal((k, m)), rng.standard_normal((k, n))
+    mk = lambda: L.GLRM(A, L.QuadLoss(), L.QuadReg(.05), L.NonNegConstraint(), k, X=X0, Y=Y0)
+    ga, gg, gc = mk(), mk(), mk()
+    _, _, cha = L.fit_b(ga, L.HipProxGradParams(max_iter=200), verbose=False)
+    _, _, chg = L.fit_b(gg, L.HipProxGradParams(max_iter=200, quad_gram=True), verbose=False)
+    _, _, chc = L.fit_b(gc, L.ProxGradParams(max_iter=200), verbose=False, engine=O.oracle_api())
+    assert gg._handle_cache[0].kernel_stats(gg._handle_cache[1])["tiled"] & 4
+    assert len(chg.objective) == len(cha.objective) == len(chc.objective) and len(chg.objective) > 20
+    assert cases.rel_err(chg.objective, cha.objective) < 1e-9 and cases.fro_err(gg.X, ga.X) < 1e-9 and cases.fro_err(gg.Y, ga.Y) < 1e-9
+    assert cases.rel_err(chg.objective, chc.objective) < TOL and cases.fro_err(gg.X, gc.X) < TOL
+    ga.close(); gg.close()
+
+
+@pytest.mark.parametrize("quad_gram", [0, 1])
+def test_dense_two_shards_equal_one_shard(quad_gram):
     import torch
     rng = np.random.default_rng(8)
     m, n, k = 260, 150, 32
     g, X0, Y0 = dense_case(rng, m, n, k, L.QuadReg(0.1), L.NonNegConstraint())
     api, params = hip(), L.ProxGradParams(max_iter=6)
-    o1, X1, Y1, _ = cases.run_engine(api, g.problem_arrays(dense=True), X0, Y0, params)
+    o1, X1, Y1, _ = cases.run_engine(api, g.problem_arrays(dense=True), X0, Y0, params, quad_gram=quad_gram)
     stream = torch.cuda.current_stream().cuda_stream
     dev = torch.device("cuda", 0)
-    hs = [api.create(g.problem_arrays(rows=(0, 100), cols=(0, 70), dense=True), stream=stream),
-          api.create(g.problem_arrays(rows=(100, m), cols=(70, n), dense=True), stream=stream)]
+    hs = [api.create(g.problem_arrays(rows=(0, 100), cols=(0, 70), dense=True), stream=stream, quad_gram=quad_gram),
+          api.create(g.problem_arrays(rows=(100, m), cols=(70, n), dense=True), stream=stream, quad_gram=quad_gram)]
     ld = api.factor_ld(hs[0])
     dX, dY = torch.zeros(m * ld, dtype=torch.float64, device=dev), torch.zeros(n * ld, dtype=torch.float64, device=dev)
     dC, dR = torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(m, dtype=torch.float64, device=dev)

@@ -104,16 +104,18 @@ def test_hip_multi_c4_recipe_vs_oracle(tiled):
 
 
 @pytest.mark.gpu
-def test_hip_multi_dense_handover_and_host_level():
-    """Fully observed QuadLoss: the dense hand-over (matrix cores) on two shards, through HipProxGradParams(ngpus=2)."""
+@pytest.mark.parametrize("quad_gram", [False, True])
+def test_hip_multi_dense_handover_and_host_level(quad_gram):
+    """Fully observed QuadLoss: the dense hand-over (matrix cores) on two shards, through HipProxGradParams(ngpus=2); with
+    glrm_options.quad_gram the Gram matrix of the replicated opposing factor is the same on every shard."""
     rng = np.random.default_rng(5)
     m, n, k = 300, 200, 16
     A = rng.standard_normal((m, k)) @ rng.standard_normal((k, n)) / 4 + 0.1 * rng.standard_normal((m, n))
     X0, Y0 = rng.standard_normal((k, m)), rng.standard_normal((k, n))
     g1 = L.GLRM(A, L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), k, X=X0.copy(), Y=Y0.copy())
     g2 = L.GLRM(A, L.QuadLoss(), L.ZeroReg(), L.ZeroReg(), k, X=X0.copy(), Y=Y0.copy())
-    _, _, ch1 = L.fit_b(g1, L.HipProxGradParams(max_iter=10), verbose=False)
-    _, _, ch2 = L.fit_b(g2, L.HipProxGradParams(max_iter=10, ngpus=2, device_ids=[0, 0]), verbose=False)
+    _, _, ch1 = L.fit_b(g1, L.HipProxGradParams(max_iter=10, quad_gram=quad_gram), verbose=False)
+    _, _, ch2 = L.fit_b(g2, L.HipProxGradParams(max_iter=10, ngpus=2, device_ids=[0, 0], quad_gram=quad_gram), verbose=False)
     assert cases.rel_err(ch2.objective, ch1.objective) < 1e-9 and cases.fro_err(g2.X, g1.X) < 1e-9
     g1.close(); g2.close()
 
