@@ -105,7 +105,11 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
         else:
             flops, passes = 6.0 * m * n * k, P  # three m x n x k products per half-step (u, gradient, first trial): 12mnk per iteration
             what = "6 m n k flop per half-step (SURVEY 8(d): 12 m n k per outer iteration)"
-        cands.append(dict(bound="mfma", achieved=flops / t / 1e12, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", per_launch=flops, what=what))
+        cands.append(dict(bound="mfma", achieved=flops / t / 1e12, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", per_launch=flops, what=what,
+                          # tools/ubench_mfma.hip, profiles/r02_ubench_mfma.txt: what the instructions sustain with register operands
+                          # and nothing else going on, at 2.37-2.40 GHz (v_fma_f64 throttles the clock to ~1.98 GHz)
+                          measured_ceiling=dict(v_mfma_f64_16x16x4_f64=50.3, v_mfma_f64_4x4x4_4b_f64=73.1, v_fma_f64=61.1, unit="TFLOP/s",
+                                                used="v_mfma_f64_16x16x4_f64", source="profiles/r02_ubench_mfma.txt")))
         cands.append(dict(bound="hbm", achieved=passes * m * n * 8 / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=passes * m * n * 8,
                           what="A streamed once per pass, %d pass%s per half-step" % (passes, "es" if passes > 1 else "")))
     elif family == "tiled":

@@ -18,6 +18,12 @@
 //          D2[e][comp] += sum_kk R[e][col(kk + 4r)] * Y[comp][col(kk + 4r)]
 // col(cq + 4r) = 4*cq + r, so the four residuals a lane holds are four CONTIGUOUS entries of its A row.
 //
+// Ceiling of the instruction (tools/ubench_mfma.hip, profiles/r02_ubench_mfma.txt): v_mfma_f64_16x16x4_f64 sustains 50 TFLOP/s on
+// MI355X with register operands and nothing else going on (it issues every ~96 cycles at 2.38 GHz, not the 64 that the 78.6 TFLOP/s
+// rating implies); the gradient pass below runs at 50-52.  v_mfma_f64_4x4x4_4b_f64 sustains 70-73 TFLOP/s but needs four times the
+// operand words per flop: the same pass rebuilt on it (lane maps from tools/probe_mfma4.hip, operands in 16-byte LDS reads, conflict-
+// free row padding) was parity-green and no faster (82.3 vs 78.0 ms per C3 iteration) -- measured and dropped, DESIGN.md section 4.3.
+//
 // The line search (trial passes, accept / shrink) reuses col_reduce_kernel / col_decide_kernel of glrm_tiled.hpp.
 #pragma once
 
@@ -35,7 +41,7 @@ struct DenseArgs {
   int64_t own_offset;
   const double* other;  // opposing factor (global array, ld KP)
   int64_t n_other;      // opposing vectors
-  const double* A;      // packed block: A[s * lda + c], s in [0, nseg_pad), c in [0, lda), zero padded
+  const double* A;      // packed block of nseg_pad x lda entries (zero padded) in 16 x 16 tiles, see dense_tile_pos
   int64_t lda;
   double scale;         // QuadLoss scale
   int nsup;             // super-tiles over the opposing dimension
@@ -55,7 +61,7 @@ constexpr int dense_row_bytes() { return KP * 8 + 16; }
 template <int KP, bool GRAD, int NWD>
 __global__ void __launch_bounds__(NWD * 64) dense_pass_kernel(const DenseArgs a) {
   constexpr int ROWB = dense_row_bytes<KP>(), PSTRIDE = KP + 2, NQ = KP / 4, NCB = KP / 16;
-  __shared__ __attribute__((aligned(16))) char lds[DENSE_TN * ROWB];
+  __shared__ __attribute__((aligned(16))) char lds2[2 * DENSE_TN * ROWB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e = lane & 15, cq = lane >> 4;
   const int64_t seg0 = (int64_t)blockIdx.x * (NWD * 16) + wave * 16;
@@ -79,29 +85,56 @@ __global__ void __launch_bounds__(NWD * 64) dense_pass_kernel(const DenseArgs a)
 
   const int64_t v0 = (int64_t)sup * a.vec_per_sup;
   const int64_t v1 = v0 + a.vec_per_sup < a.n_other ? v0 + a.vec_per_sup : a.n_other;
-  const double* arow = a.A + seg * a.lda; // rows are padded to a multiple of 64: always in bounds
+  // A is packed in 16 x 16 tiles (dense_pack_kernel): the tile of segments [seg0, seg0+16) x opposing vectors [16 C, 16 C + 16) is one
+  // contiguous 2 KB block whose first KB holds, at double2 index `lane`, the lane's entries 4 cq + {0,1} and whose second KB holds
+  // 4 cq + {2,3} -- each of the wave's two loads per tile reads one fully coalesced KB, and a wave streams 8 KB of consecutive
+  // addresses per stage (with row-major A every load touched 16 rows 80 KB apart, 64 useful bytes in each; together with the
+  // double-buffered tiles: 84.8 -> 78.0 ms per C3 iteration, same box)
+  const double2* atile = reinterpret_cast<const double2*>(a.A) + (seg0 / 16) * (a.lda / 16) * 128 + lane; // 128 double2 per tile
   const int i1 = lane & 15;               // GEMM1 A-operand: tile index i -> local vector 4*(i&3) + (i>>2)
   const int vloc1 = 4 * (i1 & 3) + (i1 >> 2);
 
-  for (int64_t t0 = v0; t0 < v1; t0 += DENSE_TN) {
-    __syncthreads();
-    { // stage DENSE_TN opposing vectors (zero beyond n_other), padded rows
-      const char* src = reinterpret_cast<const char*>(a.other) + t0 * (KP * 8);
-      const int64_t valid = (a.n_other - t0) * (KP * 8);
-      for (int off = threadIdx.x * 16; off < DENSE_TN * KP * 8; off += NWD * 64 * 16) {
-        double2 v = make_double2(0.0, 0.0);
-        if (off < valid) v = *reinterpret_cast<const double2*>(src + off);
+  // The staged tiles are double-buffered: the next DENSE_TN opposing vectors are requested (into registers) before the current ones
+  // are consumed and written to the other buffer afterwards -- one barrier per stage, the load latency hidden behind 4 x 16 MFMAs
+  // per wave (single buffer, load + two barriers per stage: 84.8 vs 81.0 ms per C3 iteration, same box).
+  constexpr int STAGE_B = DENSE_TN * KP * 8, BUF_B = DENSE_TN * ROWB, NP = (STAGE_B + NWD * 64 * 16 - 1) / (NWD * 64 * 16);
+  double2 sv[NP];
+  auto fetch = [&](int64_t t0) { // DENSE_TN opposing vectors from t0 on (zero beyond n_other)
+    const char* src = reinterpret_cast<const char*>(a.other) + t0 * (KP * 8);
+    const int64_t valid = (a.n_other - t0) * (KP * 8);
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) {
+      const int off = (pc * NWD * 64 + (int)threadIdx.x) * 16;
+      sv[pc] = make_double2(0.0, 0.0);
+      if (off < STAGE_B && off < valid) sv[pc] = *reinterpret_cast<const double2*>(src + off);
+    }
+  };
+  auto put = [&](char* buf) { // padded rows
+#pragma unroll
+    for (int pc = 0; pc < NP; ++pc) {
+      const int off = (pc * NWD * 64 + (int)threadIdx.x) * 16;
+      if (off < STAGE_B) {
         const int row = off / (KP * 8), col = off - row * (KP * 8);
-        *reinterpret_cast<double2*>(lds + row * ROWB + col) = v;
+        *reinterpret_cast<double2*>(buf + row * ROWB + col) = sv[pc];
       }
     }
-    __syncthreads();
-    if (!wave_active) continue;
+  };
+  if (v0 < v1) {
+    fetch(v0);
+    put(lds2);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int64_t t0 = v0; t0 < v1; t0 += DENSE_TN, cur ^= 1) {
+    const bool more = t0 + DENSE_TN < v1;
+    if (more) fetch(t0 + DENSE_TN);
+    const char* lds = lds2 + cur * BUF_B;
+    if (wave_active) {
 #pragma unroll
     for (int ct = 0; ct < DENSE_TN / 16; ++ct) {
       // the lane's four A entries: A[seg][t0 + ct*16 + 4*cq + (0..3)]
-      const double2* ap = reinterpret_cast<const double2*>(arow + t0 + ct * 16 + 4 * cq);
-      const double2 a01 = ap[0], a23 = ap[1];
+      const double2* ap = atile + ((t0 >> 4) + ct) * 128;
+      const double2 a01 = ap[0], a23 = ap[64];
       // GEMM1: residual tile (transposed) = Y_tile' X
       f64x4 d = f64x4{0.0, 0.0, 0.0, 0.0};
       const char* y1 = lds + (ct * 16 + vloc1) * ROWB + cq * 8;
@@ -127,6 +160,9 @@ __global__ void __launch_bounds__(NWD * 64) dense_pass_kernel(const DenseArgs a)
         }
       }
     }
+    }
+    if (more) put(lds2 + (cur ^ 1) * BUF_B);
+    __syncthreads(); // the other buffer is complete, everybody is done with this one
   }
   if (!wave_active) return;
   // J of segment e: add the four cq partials (lanes e, e+16, e+32, e+48)
@@ -229,9 +265,17 @@ __global__ void __launch_bounds__(256) dense_gram_trial_kernel(const TiledArgs a
   for (int sp = 1; sp < a.nsup; ++sp) p[(int64_t)sp * PSTRIDE] = 0.0;
 }
 
-// Pack a block of the caller's dense matrix into the padded row-major layout the pass kernel streams:
-//   dst[s * lda + c] = A(seg0 + s, c)  for the row view   (transpose = 0)
-//   dst[s * lda + c] = A(c, seg0 + s)  for the column view (transpose = 1)
+// Where entry (segment s, opposing vector c) of a packed block lives: 16 x 16 tiles, tile (s / 16, c / 16) at ((s/16) (lda/16) + c/16)
+// x 256 doubles; inside the tile the lane that needs the entry in dense_pass_kernel is lane = 16 (cc / 4) + e (e = s % 16, cc = c %
+// 16) and the entry is double (cc % 2) of double2 `lane` of half (cc % 4) / 2.
+__host__ __device__ __forceinline__ int64_t dense_tile_pos(int64_t s, int64_t c, int64_t lda) {
+  const int e = (int)(s & 15), cc = (int)(c & 15);
+  return ((s >> 4) * (lda >> 4) + (c >> 4)) * 256 + ((cc & 3) >> 1) * 128 + (((cc >> 2) << 4) + e) * 2 + (cc & 1);
+}
+
+// Pack a block of the caller's dense matrix into the padded tile layout the pass kernel streams (dense_tile_pos):
+//   dst[pos(s, c)] = A(seg0 + s, c)  for the row view   (transpose = 0)
+//   dst[pos(s, c)] = A(c, seg0 + s)  for the column view (transpose = 1)
 // A(i,j) = src[i + j*ldsrc] if colmajor else src[i*ldsrc + j].  32x32 tiles through LDS keep both sides coalesced.
 __global__ void __launch_bounds__(256) dense_pack_kernel(const double* src, int64_t ldsrc, int colmajor, int transpose,
                                                          int64_t seg0, int64_t nseg, int64_t nother, double* dst, int64_t lda) {
@@ -254,7 +298,7 @@ __global__ void __launch_bounds__(256) dense_pack_kernel(const double* src, int6
   __syncthreads();
   for (int yy = ty; yy < 32; yy += 8) {
     const int64_t s = s0 + yy, c = c0 + tx;
-    if (c < lda) dst[s * lda + c] = tile[yy][tx]; // dst rows are allocated up to a multiple of 256 >= nseg
+    if (c < lda) dst[dense_tile_pos(s, c, lda)] = tile[yy][tx]; // dst rows are allocated up to a multiple of 256 >= nseg
   }
 }
 
