@@ -17,4 +17,5 @@ head -8 gpurun_out/prof_$TAG/bench_kernel_stats.csv | cut -c1-200
 timeout 600 python bench.py --config C2 > gpurun_out/bench_c2_$TAG.json 2> gpurun_out/bench_c2_$TAG.err; echo "bench C2 exit $?"; cut -c1-600 gpurun_out/bench_c2_$TAG.json
 timeout 600 python bench.py --config C5 --rows 1000000 --no-jref > gpurun_out/bench_c5_$TAG.json 2> gpurun_out/bench_c5_$TAG.err; echo "bench C5-family exit $?"; cut -c1-600 gpurun_out/bench_c5_$TAG.json
 timeout 900 python bench.py --config C3 --steps 10 > gpurun_out/bench_c3_$TAG.json 2> gpurun_out/bench_c3_$TAG.err; echo "bench C3 exit $?"; cut -c1-600 gpurun_out/bench_c3_$TAG.json; tail -2 gpurun_out/bench_c3_$TAG.err
+timeout 900 python bench.py --config C3 --steps 10 --quad-gram > gpurun_out/bench_c3gram_$TAG.json 2> gpurun_out/bench_c3gram_$TAG.err; echo "bench C3 quad_gram exit $?"; cut -c1-600 gpurun_out/bench_c3gram_$TAG.json; tail -2 gpurun_out/bench_c3gram_$TAG.err
 find gpurun_out -name "*kernel_trace*" -size +8M -delete
