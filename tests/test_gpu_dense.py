@@ -161,3 +161,20 @@ def test_dense_argument_errors():
     with pytest.raises(_capi.GLRMError) as ei:
         api.create(pa)
     assert ei.value.code == _capi.ERR_NONFINITE and "(3, 4)" in ei.value.message
+    # glrm_options.reserved must be 0 (the field behind quad_gram)
+    import ctypes
+    o = _capi.COptions(-1, 0, 0, 0, None, 0, 0, 1, 7)
+    h = ctypes.c_void_p()
+    pa = g.problem_arrays(dense=True)
+    cp = api._cproblem(pa)
+    rc = api._f["create"](ctypes.byref(h), ctypes.byref(cp), ctypes.byref(o))
+    assert rc == _capi.ERR_INVALID and not h.value
+
+
+def test_quad_gram_is_ignored_outside_the_dense_path():
+    """glrm_options.quad_gram on a handle with observation lists changes nothing (the Gram matrix of a sparse row is its own)."""
+    kwargs, params = cases.build_golden_case("c1")
+    pa = L.GLRM(**kwargs).problem_arrays()
+    o0, X0_, Y0_, _ = cases.run_engine(hip(), pa, kwargs["X"], kwargs["Y"], params)
+    o1, X1_, Y1_, st = cases.run_engine(hip(), pa, kwargs["X"], kwargs["Y"], params, quad_gram=1)
+    assert not st["tiled"] & 4 and np.array_equal(o0, o1) and np.array_equal(X0_, X1_) and np.array_equal(Y0_, Y1_)
