@@ -132,6 +132,30 @@ NOTEBOOK_SVD_HEAD = [np.inf, 28.4395, 9.14371, 0.864888, 0.37692, 0.272977, 0.22
 NOTEBOOK_SVD_TAIL = [0.0289067, 0.0249007, 0.0217853, 0.0190616, 0.0170927, 0.0154683, 0.0137965, 0.0120712, 0.0108689, 0.00989485]
 
 
+NOTEBOOK_IMPUTE = [  # :815-835 -- impute(glrm) after the init_svd! fit: columns 1-4 and 8-10 of the 20 x 10 matrix as printed
+    [0.201064, 0.178928, 0.0936361, 0.338963, 0.0610706, 0.0345337, 0.255634],
+    [0.626425, 0.498201, 0.404066, 0.52571, 0.35284, 0.163703, 0.485699],
+    [0.889128, 0.565398, 0.590757, 0.727527, 0.501572, 0.273879, 0.524708],
+    [0.264933, 0.213167, 0.172958, 0.30727, 0.140076, 0.0812656, 0.20812],
+    [0.849472, 0.627437, 0.40914, 0.780748, 0.346765, 0.113373, 0.797801],
+    [0.488824, 0.434675, 0.350332, 0.670804, 0.271115, 0.174788, 0.472898],
+    [0.620052, 0.641855, 0.322417, 0.565983, 0.29541, 0.0685478, 0.72269],
+    [1.1255, 1.02346, 0.63119, 1.2256, 0.527708, 0.210468, 1.20615],
+    [0.214933, 0.198515, 0.102426, 0.335253, 0.0716396, 0.0341962, 0.2766],
+    [0.79803, 0.865126, 0.424412, 0.781505, 0.385092, 0.0947092, 0.968798],
+    [0.612195, 0.538832, 0.363826, 0.736084, 0.292544, 0.14433, 0.624619],
+    [0.325503, 0.351202, 0.185431, 0.469194, 0.148028, 0.0699904, 0.372757],
+    [0.371371, 0.326883, 0.187448, 0.429956, 0.152637, 0.0570415, 0.403141],
+    [1.15949, 0.916536, 0.710041, 1.34629, 0.565187, 0.305434, 1.06717],
+    [0.223678, 0.208483, 0.0833057, 0.284272, 0.0673465, 0.012477, 0.251368],
+    [0.556494, 0.35883, 0.295561, 0.545181, 0.239097, 0.112382, 0.451415],
+    [0.504458, 0.394671, 0.306674, 0.526402, 0.252477, 0.126227, 0.440751],
+    [0.241705, 0.312739, 0.140464, 0.186293, 0.140516, 0.0255899, 0.301894],
+    [0.253238, 0.271053, 0.157952, 0.36181, 0.124748, 0.0631709, 0.308106],
+    [0.809283, 0.775808, 0.489043, 1.01611, 0.395559, 0.19164, 0.872817],
+]
+
+
 def init_svd_numpy(A, exs, k, nobs):
     """src/initialize.jl:83-131 for scalar losses without offset: centre the observed entries of each column (means and stds over the
     LIST, duplicates counted), zero elsewhere, scale by m n / |obs|, top-k SVD, X = sqrt(S) U', Y = sqrt(S) V' diag(stds)."""
@@ -163,15 +187,18 @@ def svd_cell_models():
                      observed_examples=g0.observed_examples, X=np.asfortranarray(s * Xs), Y=np.asfortranarray(s * Ys))
 
 
-def check_svd_cell(fit):
+def check_svd_cell(fit, impute=None):
     matches = []
     for g in svd_cell_models():
         obj = np.array(fit(g))
-        g.close()
         if abs(obj[1] - NOTEBOOK_SVD_HEAD[1]) <= 6e-6 * NOTEBOOK_SVD_HEAD[1]:
-            matches.append(obj)
+            matches.append((obj, None if impute is None else np.asarray(impute(g), dtype=float)))
+        g.close()
     assert len(matches) == 1  # exactly one sign assignment takes the notebook's first step
-    obj = matches[0]
+    obj, Ahat = matches[0]
+    if Ahat is not None:  # `impute(glrm)` of the next cell: X'Y for a real-valued QuadLoss model (src/impute_and_err.jl)
+        assert Ahat.shape == (20, 10)
+        np.testing.assert_allclose(Ahat[:, [0, 1, 2, 3, 7, 8, 9]], np.array(NOTEBOOK_IMPUTE), rtol=6e-6)
     assert len(obj) == 32 and obj[0] == np.inf
     for it, want in NOTEBOOK_SVD_OBJECTIVE.items():
         assert abs(obj[it] - want) <= 1e-9 * want, (it, obj[it], want)
@@ -181,7 +208,8 @@ def check_svd_cell(fit):
 
 def test_oracle_reproduces_the_init_svd_cell():
     O.set_threads(1)
-    check_svd_cell(lambda g: L.fit_b(g, L.ProxGradParams(), verbose=False, engine=O.oracle_api())[2].objective)
+    check_svd_cell(lambda g: L.fit_b(g, L.ProxGradParams(), verbose=False, engine=O.oracle_api())[2].objective,
+                   impute=lambda g: L.impute(g, engine=O.oracle_api()))
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -264,7 +292,7 @@ def test_oracle_init_svd_reproduces_the_sparse_cell():
 
 @pytest.mark.gpu
 def test_hip_engine_reproduces_the_init_svd_cell():
-    check_svd_cell(lambda g: L.fit_b(g, L.HipProxGradParams(), verbose=False)[2].objective)
+    check_svd_cell(lambda g: L.fit_b(g, L.HipProxGradParams(), verbose=False)[2].objective, impute=lambda g: L.impute(g))
 
 
 @pytest.mark.gpu
