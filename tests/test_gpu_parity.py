@@ -335,14 +335,17 @@ def test_error_codes_on_device():
     api.destroy(h)
 
 
-@pytest.mark.parametrize("mode", [1, 2])
-def test_two_shards_on_one_gpu_equal_one_shard(mode):
+@pytest.mark.parametrize("mode,mixed", [(1, False), (2, False), (2, True)])
+def test_two_shards_on_one_gpu_equal_one_shard(mode, mixed):
     """Sharding only re-labels which handle runs an independent row / column: two shard handles bound to the
-    same device buffers, stepped one after the other, give the single-handle bits."""
+    same device buffers, stepped one after the other, give the single-handle bits.
+    mixed: a loss per column -- the tiled column passes then read their tiles with the chunk walk i ^ p, p from the GLOBAL column id
+    (glrm_tiled.hpp: tile_rot); the second shard starts at column 50, off the eight-column pattern, and must still give the same bits."""
     import torch
     rng = np.random.default_rng(38)
     m, n, k = 500, 120, 32
-    pa, X0, Y0 = random_problem(rng, m, n, k, 0.3)
+    losses = [[L.QuadLoss(), L.HuberLoss(), L.L1Loss(0.7), L.QuantileLoss(1.0, quantile=0.3)][j % 4] for j in range(n)] if mixed else None
+    pa, X0, Y0 = random_problem(rng, m, n, k, 0.3, losses=losses)
     api = hip()
     params = L.ProxGradParams(max_iter=6)
     o1, X1, Y1, st1 = cases.run_engine(api, pa, X0, Y0, params, tiled=mode)
