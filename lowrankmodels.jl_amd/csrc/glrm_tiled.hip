@@ -69,8 +69,12 @@ int glrm_setup_tiled(glrm_handle* h) {
   int rc0 = GLRM_OK;
   h->tile_cfg = env_int("GLRM_HIP_TILE_CFG", 1);
   h->tile_cfg12 = h->tile_cfg == 2; // experiment: 12-wave heterogeneous row sweep
-  h->tile_lw = env_int("GLRM_HIP_TILE_LW", 0); // loader waves of the double-buffered tiled sweeps (0 = single tile, everybody stages)
-  if (h->tile_lw < 0 || h->tile_lw > 2 || !((h->G == 4 || h->G == 8) && h->R == 8)) h->tile_lw = 0;
+  // Loader waves of the double-buffered tiled sweeps (0 = single tile, everybody stages; glrm_tiled.hpp).  Default: two loader waves on
+  // the ROW sweep of uniform QuadLoss models -- measured on one box (tools/gpu_r3c.sh, profiles/r02_lw_default.txt): C2 row sweep 8.31 ->
+  // 7.41 ms, 1M x 50k 26.3 -> 23.0, 1M x 2k 1.65 -> 1.48, 300k x 3k 0.75 -> 0.73, same objective bits; the column passes and the
+  // heterogeneous row sweep lose with them and keep the single tile.  GLRM_HIP_TILE_LW = 0 | 1 | 2 overrides.
+  h->tile_lw = env_int("GLRM_HIP_TILE_LW", h->loss_quad_uniform ? 2 : 0);
+  if (h->tile_lw < 0 || h->tile_lw > 2 || !((h->G == 4 || h->G == 8) && h->R == 8) || !h->tile_cfg) h->tile_lw = 0;
   h->tile_lw_sides = env_int("GLRM_HIP_TILE_LW_SIDES", 1); // bit0: row sweep, bit1: column passes
   h->tile_cfg = h->tile_cfg ? 1 : 0;
   h->tG = h->G;
