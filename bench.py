@@ -126,6 +126,21 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
                           # and 118 TB/s conflict-free; the sweeps turned out not to be bound by either (profiles/r02_rot_ab.txt)
                           measured_ceiling=dict(padded_rows=63000.0, conflict_free=118000.0, unit="GB/s",
                                                 source="profiles/r02_ubench_lanerow.txt")))
+    elif family == "cached":
+        # csrc/glrm_cached.hip: the row's opposing vectors are gathered ONCE per half-step into LDS; every pass reads them there.
+        gathers = nnz * 8 * k
+        if opp > MALL_BYTES:
+            cands.append(dict(bound="hbm", achieved=(stream + gathers) / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=stream + gathers,
+                              what="P x 12 B x |Omega| + own factor r/w + ONE k-vector gather per update (the passes read it from LDS)"))
+        else:
+            cands.append(dict(bound="hbm", achieved=(stream + opp) / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=stream + opp,
+                              what="compulsory HBM bytes: P x 12 B x |Omega| + own factor r/w + opposing factor once"))
+            cands.append(dict(bound="l2", achieved=gathers / t / 1e9, peak=L2_PEAK_GBS, unit="GB/s", per_launch=gathers,
+                              what="ONE k-vector gather per update served by L2 / Infinity Cache (opposing factor %.0f MB <= 256 MiB; random "
+                                   "512-byte reads from the Infinity Cache measured 8.2 TB/s, profiles/r02_ubench_gather.txt), priced at the L2 peak"
+                                   % (opp / 1e6)))
+        cands.append(dict(bound="lds", achieved=nnz * P * 8 * ld / t / 1e9, peak=LDS_PEAK_GBS, unit="GB/s", per_launch=nnz * P * 8 * ld,
+                          what="LDS reads: one cached vector (8 ld bytes) per update and pass"))
     else:
         # 'gather' and 'blocked' share one byte model: every update fetches its k-vector from the memory system.  The phase-aligned
         # passes ('blocked') only change WHERE the window all groups read at a time sits: in the Infinity Cache (measured 8.2 TB/s
@@ -430,7 +445,7 @@ def main():
         value = args.steps * updates_per_step / elapsed
         ms_x = st["ms_x"] / max(args.steps, 1)  # per outer iteration (the X half-step may run as several chunk launches)
         ms_y = st["ms_y"] / max(args.steps, 1)
-        fam_r = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 1 else "blocked" if flags & 16 else "gather"
+        fam_r = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 1 else "cached" if flags & 64 else "blocked" if flags & 16 else "gather"
         fam_c = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 2 else "blocked" if flags & 32 else "gather"
         ld = st["ld"]
         tile = 150 * 1024 // (ld * 8 + 16) // 16 * 16  # csrc/glrm_tiled.hip: tile_rows_c
@@ -445,6 +460,7 @@ def main():
                  ("col", "tiled"): ("tiled_col_pass_kernel x2 + col_reduce/col_decide (Y half-step, LDS-tiled)", "tiled_col_pass_kernel"),
                  ("row", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (X half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
                  ("col", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (Y half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
+                 ("row", "cached"): ("cached_sweep_kernel (X half-step, the row's opposing vectors gathered once into LDS)", "cached_sweep_kernel"),
                  ("row", "dense"): ("dense_pass_kernel (X half-step, fp64 MFMA)", "dense_pass_kernel"),
                  ("col", "dense"): ("dense_pass_kernel (Y half-step, fp64 MFMA)", "dense_pass_kernel"),
                  ("row", "general"): ("multi_sweep_kernel (X half-step)", "multi_sweep_kernel"),

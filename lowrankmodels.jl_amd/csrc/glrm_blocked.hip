@@ -39,6 +39,7 @@ int glrm_setup_blocked(glrm_handle* h) {
   const int T = tile_rows_b(h->kp);
   auto decide = [&](bool rows) -> bool {
     if (rows ? h->tiled_row : h->tiled_col) return false;          // the LDS-tiled sweep already owns this view
+    if (rows && h->cached_row) return false;                       // the row sweep runs out of LDS (glrm_cached.hip)
     if (!(rows ? h->rows_sorted : h->cols_sorted)) return false;   // a group must meet the opposing factor front to back
     const int64_t nseg = rows ? h->ml : h->nl, nnz = rows ? h->nnz_r : h->nnz_c, nopp = rows ? h->n : h->m;
     if (nseg <= 0 || nnz <= 0) return false;

@@ -1,0 +1,556 @@
+// glrm_cached.hip -- row sweep with the row's opposing vectors fetched ONCE per half-step ("cached gather sweep").
+//
+// Where the opposing factor is far beyond L2 and a row is short (BASELINE config 4: 100 observations per row, rank 64, Y = 51 MB), the
+// gather sweeps are bound by the k-vector gathers -- 512 B per observation and PASS, gradient pass and every line-search trial alike
+// (the X half-step at C4: 2 x 1e9 x 512 B at the 8.2 TB/s the Infinity Cache delivers for such reads = 121 ms).  But all passes of
+// a row's half-step read the SAME vectors: Y does not change during the X half-step.  So the row's vectors are fetched once and kept
+// on chip for the gradient pass, the prox and every trial of the backtracking line search; the gather traffic of the half-step drops
+// from (1 + trials) passes to one.  Two homes for the row:
+//   registers (regcached_sweep_kernel, the default when the longest row of the shard needs <= 13 trips of the lane layout): a 64-lane
+//             wave may use 512 VGPRs per lane; two waves share a row, each holding every other trip's vectors, all loads of a wave
+//             in flight together; the passes are straight-line code over registers.  C4 X half-step 120.6 -> 85.4 ms.
+//   LDS       (cached_sweep_kernel; rows up to the LDS budget): one wave per row, the row gathered with LDS-DMA.  C4: 110.5 ms.
+//
+// Applies to the ROW view; index lists in any order.  Summation: a lane group takes its observations in ascending order, the groups of
+// a wave are combined by the butterfly of the gather sweeps (glrm_hip.hip: sweep_pass), the waves of a row in wave order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "glrm_device.hpp"
+#include "glrm_engine.hpp"
+
+using namespace glrm;
+
+namespace {
+
+#ifndef CACHED_U
+#define CACHED_U 4
+#endif
+
+struct CachedArgs {
+  int64_t nseg;
+  const int64_t* ptr;
+  const int32_t* idx;
+  const double* vals;
+  double* own;
+  int64_t own_offset;
+  const double* other;
+  double* alpha;
+  const glrm_loss* losses;
+  const glrm_reg* regs;
+  int reg_single;
+  int k;
+  double fixed_alpha;
+  double min_stepsize;
+  int32_t* trials;
+  int32_t* accepts;
+  int cap; // vectors the LDS buffer of a wave holds (a multiple of the vectors one DMA instruction moves)
+};
+
+// One pass over the row out of LDS: J = sum of losses at u = <xv, y_t>, and (GRAD) g = sum of dL * y_t.
+template <int G, int R, int LOSS, bool GRAD>
+__device__ __forceinline__ double cached_pass(const CachedArgs& a, const char* __restrict__ ybuf, const double* __restrict__ lval,
+                                              const int32_t* __restrict__ lidx, const Vec<G, R>& xv, Vec<G, R>& g, int len, int gi, int j,
+                                              const LossDesc& segloss) {
+  constexpr int KPB = G * R * 8, NG = 64 / G, LM = loss_mode(LOSS), U = CACHED_U;
+  constexpr bool TRIG = loss_trig(LOSS);
+  double J = 0.0;
+  if (GRAD) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) g.v[i] = make_double2(0.0, 0.0);
+  }
+  for (int t0 = 0; t0 < len; t0 += NG * U) { // wave-uniform trip count; U observations per group in flight
+    double2 y[U][R / 2];
+    double av[U];
+    int cc[U];
+    bool valid[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u * NG + gi;
+      valid[u] = t < len;
+      const int tt = valid[u] ? t : len - 1;
+      const char* yp = ybuf + tt * KPB + j * 16;
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) y[u][i] = *reinterpret_cast<const double2*>(yp + i * (G * 16));
+      av[u] = lval[tt];
+      cc[u] = lidx[tt];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      double dot = 0.0;
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) {
+        dot = fma(xv.v[i].x, y[u][i].x, dot);
+        dot = fma(xv.v[i].y, y[u][i].y, dot);
+      }
+      dot = group_sum<G>(dot);
+      double L, dL;
+      if constexpr (LOSS == LOSS_QUAD_UNIFORM) {
+        const double d = dot - av[u];
+        L = segloss.scale * (d * d);
+        dL = 2 * d * segloss.scale;
+      } else if constexpr (LM == LOSS_SEGMENT) {
+        loss_both<GRAD, TRIG>(segloss, dot, av[u], L, dL);
+      } else {
+        const LossDesc lo = load_loss(a.losses, cc[u]);
+        loss_both<GRAD, TRIG>(lo, dot, av[u], L, dL);
+      }
+      if (!valid[u]) {
+        L = 0.0;
+        dL = 0.0;
+      }
+      J += L;
+      if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+          g.v[i].x = fma(dL, y[u][i].x, g.v[i].x);
+          g.v[i].y = fma(dL, y[u][i].y, g.v[i].y);
+        }
+      }
+    }
+  }
+  J = across_groups_sum<G>(J);
+  if (GRAD) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      g.v[i].x = across_groups_sum<G>(g.v[i].x);
+      g.v[i].y = across_groups_sum<G>(g.v[i].y);
+    }
+  }
+  return J;
+}
+
+// One wave (= one workgroup) per row.  Dynamic LDS: [cap vectors][cap values][cap indices].
+template <int G, int R, int LOSS>
+__global__ void __launch_bounds__(64) cached_sweep_kernel(const CachedArgs a) {
+  constexpr int KP = G * R, KPB = KP * 8, CPV = KPB / 16, VPI = 64 / CPV; // 16-byte chunks per vector, vectors per DMA instruction
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int lane = threadIdx.x;
+  const int64_t seg = blockIdx.x;
+  if (seg >= a.nseg) return;
+  const int j = lane % G, gi = lane / G;
+  const int64_t beg = a.ptr[seg];
+  const int len = (int)(a.ptr[seg + 1] - beg);
+  const int64_t gseg = a.own_offset + seg;
+  double2* ownp = reinterpret_cast<double2*>(a.own + gseg * KP);
+  char* ybuf = lds;
+  double* lval = reinterpret_cast<double*>(lds + (size_t)a.cap * KPB);
+  int32_t* lidx = reinterpret_cast<int32_t*>(lds + (size_t)a.cap * (KPB + 8));
+
+  // the row's (index, value) list -> LDS
+  for (int t = lane; t < len; t += 64) {
+    lidx[t] = a.idx[beg + t];
+    lval[t] = a.vals[beg + t];
+  }
+  __syncthreads(); // one wave: orders the LDS writes above before the reads below
+  Vec<G, R> x, g;
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) x.v[i] = ownp[i * G + j];
+  const RegDesc rd = load_reg(a.regs, a.reg_single ? 0 : seg);
+  LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
+  if constexpr (loss_mode(LOSS) != LOSS_PER_OBS) segloss = load_loss(a.losses, 0);
+  const double alpha0 = a.alpha[seg];
+  // gather the row's opposing vectors into LDS with LDS-DMA: lane l of instruction `it` moves chunk l % CPV of vector it * VPI + l / CPV.
+  // No VGPRs, the whole row in flight at once.  Measured alternatives at C4 (X half-step; phase-aligned passes 120 ms): this 112 ms;
+  // the gradient pass streamed behind the DMA with counted vmcnt waits 124 ms; 26 ordinary 16-byte loads per lane in flight, then
+  // ds_write 129 ms.
+  if (len > 0) {
+    const int vsub = lane / CPV, chunk = lane % CPV;
+    const char* obase = reinterpret_cast<const char*>(a.other) + chunk * 16;
+    for (int it = 0; it * VPI < len; ++it) {
+      int s = it * VPI + vsub;
+      s = s < len ? s : len - 1; // the tail re-reads the last vector into an unused slot
+      const char* src = obase + (int64_t)lidx[s] * KPB;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(ybuf + it * 1024), 16, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the gathered vectors have landed
+  __syncthreads();
+
+  // pass 1: gradient + objective at the current point (proxgrad.jl:122-135)
+  double Jold = cached_pass<G, R, LOSS, true>(a, ybuf, lval, lidx, x, g, len, gi, j, segloss);
+  if (a.fixed_alpha > 0.0) { // src/algorithms/sparse_proxgrad.jl:72-77: g *= -alpha/l; x += g; prox!(r, x, alpha/l)
+    const double s = a.fixed_alpha / ((double)len + 1.0);
+    Vec<G, R> xn;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      xn.v[i].x = x.v[i].x + g.v[i].x * (-s);
+      xn.v[i].y = x.v[i].y + g.v[i].y * (-s);
+    }
+    reg_prox<G, R>(rd, xn, s, j, a.k);
+    if (gi == 0) {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = xn.v[i];
+    }
+    return;
+  }
+  Jold += reg_eval<G, R>(rd, x, j, a.k);
+
+  // backtracking line search (proxgrad.jl:136-155); every trial reads the cached vectors
+  double alpha = alpha0;
+  const double l = (double)len + 1.0;
+  int ntrials = 0;
+  bool accepted = false;
+  while (alpha > a.min_stepsize) {
+    const double s = alpha / l;
+    Vec<G, R> xn, dummy;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      xn.v[i].x = fma(-s, g.v[i].x, x.v[i].x);
+      xn.v[i].y = fma(-s, g.v[i].y, x.v[i].y);
+    }
+    reg_prox<G, R>(rd, xn, s, j, a.k);
+    double Jn = cached_pass<G, R, LOSS, false>(a, ybuf, lval, lidx, xn, dummy, len, gi, j, segloss);
+    Jn += reg_eval<G, R>(rd, xn, j, a.k);
+    ++ntrials;
+    if (Jn < Jold) { // strict; false for NaN and for Inf < Inf
+      x = xn;
+      alpha *= 1.05;
+      Jold = Jn;
+      accepted = true;
+      break;
+    }
+    alpha *= .7;
+    if (alpha < a.min_stepsize) {
+      alpha = a.min_stepsize * 1.1;
+      break;
+    }
+  }
+  if (accepted && gi == 0) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = x.v[i];
+  }
+  if (lane == 0) {
+    a.alpha[seg] = alpha;
+    if (a.trials) {
+      a.trials[seg] += ntrials;
+      a.accepts[seg] += accepted ? 1 : 0;
+    }
+  }
+}
+
+// ---- the row's vectors in REGISTERS ---------------------------------------------------------------------------------------------
+// A 64-thread workgroup may use 512 VGPRs per lane: at k = 64 a row of up to MAXT * 8 observations is MAXT * 16 VGPRs per lane in the
+// lane layout of the gather sweeps (lane group gi holds the vectors of observations gi, gi + NG, ...).  The row's vectors are loaded
+// ONCE -- all MAXT * R / 2 16-byte loads of a lane in flight together -- and the gradient pass, the prox and every line-search trial run
+// from registers: no LDS, four waves per CU, every trip of a pass independent of the others (the compiler interleaves them).
+// (WAVES = 2: two waves share a row, wave w holds the observations (t * WAVES + w) * NG + gi; `gi0` = w * NG + gi and the stride NG * WAVES)
+template <int G, int R, int LOSS, int MAXT, bool GRAD, int WAVES = 1>
+__device__ __forceinline__ double reg_pass(const CachedArgs& a, const double2 (&y)[MAXT][R / 2], const double (&av)[MAXT], const int (&cc)[MAXT],
+                                           const Vec<G, R>& xv, Vec<G, R>& g, int len, int gi, const LossDesc& segloss) {
+  constexpr int NG = (64 / G) * WAVES, LM = loss_mode(LOSS);
+  constexpr bool TRIG = loss_trig(LOSS);
+  double J = 0.0;
+  if (GRAD) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) g.v[i] = make_double2(0.0, 0.0);
+  }
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    if (t * NG + (gi & ~(64 / G - 1)) < len) { // wave-uniform: gi = wave * (64 / G) + group
+      double dot = 0.0;
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) {
+        dot = fma(xv.v[i].x, y[t][i].x, dot);
+        dot = fma(xv.v[i].y, y[t][i].y, dot);
+      }
+      dot = group_sum<G>(dot);
+      double L, dL;
+      if constexpr (LOSS == LOSS_QUAD_UNIFORM) {
+        const double d = dot - av[t];
+        L = segloss.scale * (d * d);
+        dL = 2 * d * segloss.scale;
+      } else if constexpr (LM == LOSS_SEGMENT) {
+        loss_both<GRAD, TRIG>(segloss, dot, av[t], L, dL);
+      } else {
+        const LossDesc lo = load_loss(a.losses, cc[t]);
+        loss_both<GRAD, TRIG>(lo, dot, av[t], L, dL);
+      }
+      if (!(t * NG + gi < len)) {
+        L = 0.0;
+        dL = 0.0;
+      }
+      J += L;
+      if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+          g.v[i].x = fma(dL, y[t][i].x, g.v[i].x);
+          g.v[i].y = fma(dL, y[t][i].y, g.v[i].y);
+        }
+      }
+    }
+  }
+  J = across_groups_sum<G>(J);
+  if (GRAD) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      g.v[i].x = across_groups_sum<G>(g.v[i].x);
+      g.v[i].y = across_groups_sum<G>(g.v[i].y);
+    }
+  }
+  return J;
+}
+
+// Per-wave totals of a row shared by WAVES waves, combined through LDS in wave order: every wave ends with the same bits.
+template <int G, int R, int WAVES, bool GRAD>
+__device__ __forceinline__ double row_combine(double J, Vec<G, R>& g, double* red, int wave, int lane) {
+  constexpr int KP = G * R, STRIDE = KP + 2;
+  if constexpr (WAVES == 1) return J;
+  const int j = lane % G;
+  __syncthreads(); // previous readers of `red` are done
+  if (lane < G) {
+    if (GRAD) {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) *reinterpret_cast<double2*>(&red[wave * STRIDE + i * 2 * G + 2 * j]) = g.v[i];
+    }
+    if (lane == 0) red[wave * STRIDE + KP] = J;
+  }
+  __syncthreads();
+  double Js = 0.0;
+  if (GRAD) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) g.v[i] = make_double2(0.0, 0.0);
+  }
+  for (int w = 0; w < WAVES; ++w) {
+    Js += red[w * STRIDE + KP];
+    if (GRAD) {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) {
+        const double2 p = *reinterpret_cast<const double2*>(&red[w * STRIDE + i * 2 * G + 2 * j]);
+        g.v[i].x += p.x;
+        g.v[i].y += p.y;
+      }
+    }
+  }
+  return Js;
+}
+
+// WAVES waves (= one workgroup) per row; wave w holds the observations (t * WAVES + w) * (64 / G) + group, t = 0 .. MAXT - 1.
+template <int G, int R, int LOSS, int MAXT, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64) regcached_sweep_kernel(const CachedArgs a) {
+  constexpr int KP = G * R, NG = (64 / G) * WAVES;
+  __shared__ __attribute__((aligned(16))) double red[WAVES == 1 ? 2 : WAVES * (KP + 2)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t seg = blockIdx.x;
+  if (seg >= a.nseg) return;
+  const int j = lane % G, gi = wave * (64 / G) + lane / G;
+  const int64_t beg = a.ptr[seg];
+  const int len = (int)(a.ptr[seg + 1] - beg);
+  const int64_t gseg = a.own_offset + seg;
+  double2* ownp = reinterpret_cast<double2*>(a.own + gseg * KP);
+  int cc[MAXT];
+  double av[MAXT];
+  double2 y[MAXT][R / 2];
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) { // the group's entries (clamped: lanes past the end re-read the last entry and are masked)
+    int tt = t * NG + gi;
+    tt = tt < len ? tt : (len > 0 ? len - 1 : 0);
+    cc[t] = len > 0 ? a.idx[beg + tt] : 0;
+    av[t] = len > 0 ? a.vals[beg + tt] : 0.0;
+  }
+  Vec<G, R> x, g;
+#pragma unroll
+  for (int i = 0; i < R / 2; ++i) x.v[i] = ownp[i * G + j];
+  const double2* __restrict__ other2 = reinterpret_cast<const double2*>(a.other);
+#pragma unroll
+  for (int t = 0; t < MAXT; ++t) {
+    if (t * NG + wave * (64 / G) < len) { // wave-uniform
+      const double2* yp = other2 + (int64_t)cc[t] * (KP / 2) + j;
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) y[t][i] = yp[i * G];
+    } else {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) y[t][i] = make_double2(0.0, 0.0);
+    }
+  }
+  const RegDesc rd = load_reg(a.regs, a.reg_single ? 0 : seg);
+  LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
+  if constexpr (loss_mode(LOSS) != LOSS_PER_OBS) segloss = load_loss(a.losses, 0);
+
+  double Jold = reg_pass<G, R, LOSS, MAXT, true, WAVES>(a, y, av, cc, x, g, len, gi, segloss);
+  Jold = row_combine<G, R, WAVES, true>(Jold, g, red, wave, lane);
+  if (a.fixed_alpha > 0.0) {
+    const double s = a.fixed_alpha / ((double)len + 1.0);
+    Vec<G, R> xn;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      xn.v[i].x = x.v[i].x + g.v[i].x * (-s);
+      xn.v[i].y = x.v[i].y + g.v[i].y * (-s);
+    }
+    reg_prox<G, R>(rd, xn, s, j, a.k);
+    if (gi == 0) {
+#pragma unroll
+      for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = xn.v[i];
+    }
+    return;
+  }
+  Jold += reg_eval<G, R>(rd, x, j, a.k);
+  double alpha = a.alpha[seg];
+  const double l = (double)len + 1.0;
+  int ntrials = 0;
+  bool accepted = false;
+  while (alpha > a.min_stepsize) {
+    const double s = alpha / l;
+    Vec<G, R> xn, dummy;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      xn.v[i].x = fma(-s, g.v[i].x, x.v[i].x);
+      xn.v[i].y = fma(-s, g.v[i].y, x.v[i].y);
+    }
+    reg_prox<G, R>(rd, xn, s, j, a.k);
+    double Jn = reg_pass<G, R, LOSS, MAXT, false, WAVES>(a, y, av, cc, xn, dummy, len, gi, segloss);
+    Jn = row_combine<G, R, WAVES, false>(Jn, dummy, red, wave, lane);
+    Jn += reg_eval<G, R>(rd, xn, j, a.k);
+    ++ntrials;
+    if (Jn < Jold) {
+      x = xn;
+      alpha *= 1.05;
+      Jold = Jn;
+      accepted = true;
+      break;
+    }
+    alpha *= .7;
+    if (alpha < a.min_stepsize) {
+      alpha = a.min_stepsize * 1.1;
+      break;
+    }
+  }
+  if (accepted && gi == 0) {
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = x.v[i];
+  }
+  if (lane == 0 && wave == 0) {
+    a.alpha[seg] = alpha;
+    if (a.trials) {
+      a.trials[seg] += ntrials;
+      a.accepts[seg] += accepted ? 1 : 0;
+    }
+  }
+}
+
+template <int G, int R, int LOSS>
+int launch_reg_inst(const CachedArgs& a, hipStream_t st) { // a.cap = trips of one wave the longest row needs (64 / G observations each)
+  // Two waves per row (each holds every other trip's vectors: half the registers, two waves per SIMD, so one wave's loads overlap the
+  // other's arithmetic).  Measured at C4, X half-step: one wave per row 101.5 ms, two 85.4 ms, four 130.3 ms (phase-aligned passes 120.6).
+  // ALWAYS two, also for rows one wave could hold: the wave count fixes the order of the sums, and it must not depend on the
+  // longest row of the shard.  GLRM_HIP_CACHED_WAVES = 1 | 4 are the experiment switches.
+  const int waves = env_int("GLRM_HIP_CACHED_WAVES", 2);
+  if (waves == 4 && (a.cap + 3) / 4 <= 4) {
+    hipLaunchKernelGGL((regcached_sweep_kernel<G, R, LOSS, 4, 4>), dim3((unsigned)a.nseg), dim3(256), 0, st, a);
+  } else if (waves == 1) {
+    if (a.cap <= 7) hipLaunchKernelGGL((regcached_sweep_kernel<G, R, LOSS, 7, 1>), dim3((unsigned)a.nseg), dim3(64), 0, st, a);
+    else hipLaunchKernelGGL((regcached_sweep_kernel<G, R, LOSS, 13, 1>), dim3((unsigned)a.nseg), dim3(64), 0, st, a);
+  } else if ((a.cap + 1) / 2 <= 4) {
+    hipLaunchKernelGGL((regcached_sweep_kernel<G, R, LOSS, 4, 2>), dim3((unsigned)a.nseg), dim3(128), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((regcached_sweep_kernel<G, R, LOSS, 7, 2>), dim3((unsigned)a.nseg), dim3(128), 0, st, a);
+  }
+  return GLRM_OK;
+}
+
+template <int G, int R>
+int launch_reg_layout(int loss, const CachedArgs& a, hipStream_t st) {
+  switch (loss) {
+    case LOSS_QUAD_UNIFORM: return launch_reg_inst<G, R, LOSS_QUAD_UNIFORM>(a, st);
+    case LOSS_SEGMENT: return launch_reg_inst<G, R, LOSS_SEGMENT>(a, st);
+    case LOSS_SEGMENT_NOTRIG: return launch_reg_inst<G, R, LOSS_SEGMENT_NOTRIG>(a, st);
+    case LOSS_PER_OBS_NOTRIG: return launch_reg_inst<G, R, LOSS_PER_OBS_NOTRIG>(a, st);
+    default: return launch_reg_inst<G, R, LOSS_PER_OBS>(a, st);
+  }
+}
+
+template <int G, int R, int LOSS>
+int launch_inst(const CachedArgs& a, hipStream_t st) {
+  const int lds = a.cap * (G * R * 8 + 12);
+  if (lds > 65536)
+    HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(cached_sweep_kernel<G, R, LOSS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL((cached_sweep_kernel<G, R, LOSS>), dim3((unsigned)a.nseg), dim3(64), lds, st, a);
+  return GLRM_OK;
+}
+
+template <int G, int R>
+int launch_layout(int loss, const CachedArgs& a, hipStream_t st) {
+  switch (loss) {
+    case LOSS_QUAD_UNIFORM: return launch_inst<G, R, LOSS_QUAD_UNIFORM>(a, st);
+    case LOSS_SEGMENT: return launch_inst<G, R, LOSS_SEGMENT>(a, st);
+    case LOSS_SEGMENT_NOTRIG: return launch_inst<G, R, LOSS_SEGMENT_NOTRIG>(a, st);
+    case LOSS_PER_OBS_NOTRIG: return launch_inst<G, R, LOSS_PER_OBS_NOTRIG>(a, st);
+    default: return launch_inst<G, R, LOSS_PER_OBS>(a, st);
+  }
+}
+
+} // namespace
+
+// Decide whether the row sweep of this handle runs out of LDS.  Auto (GLRM_HIP_CACHED unset): rows are not LDS-tiled, the opposing
+// factor is beyond the Infinity-Cache-friendly sizes where the plain gathers already do well (> 32 MB), the view is large, and EVERY
+// row of the shard fits a buffer of at most ~52 KB (three waves per CU: enough bytes in flight to stay bandwidth-bound).  The choice
+// does not change any sum of the uniform-QuadLoss row sweep (same order as the gather sweep), so shards may differ in it.
+int glrm_setup_cached(glrm_handle* h) {
+  h->cached_row = 0;
+  const int want = env_int("GLRM_HIP_CACHED", h->tiled_opt == 1 ? 0 : -1); // -1 auto, 0 off, 1 wherever the rows fit (160 KB)
+  if (want == 0 || h->tiled_row || h->ml <= 0 || h->nnz_r <= 0) return GLRM_OK;
+  if (!((h->G == 4 || h->G == 8) && h->R == 8)) return GLRM_OK;
+  std::vector<int64_t> ptr((size_t)h->ml + 1);
+  HIPCK(hipMemcpyAsync(ptr.data(), h->rowptr, ((size_t)h->ml + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream));
+  int64_t maxlen = 0;
+  for (int64_t s = 0; s < h->ml; ++s) maxlen = std::max(maxlen, ptr[s + 1] - ptr[s]);
+  const int vpi = 64 / (h->kp * 8 / 16);
+  const int64_t cap = (maxlen + vpi - 1) / vpi * vpi;
+  const int64_t bytes = cap * (h->kp * 8 + 12);
+  const int64_t budget = want > 0 ? 160 * 1024 : 53 * 1024;
+  if (cap <= 0 || bytes > budget) return GLRM_OK;
+  if (want < 0) {
+    const double opp_bytes = (double)h->n * h->kp * 8;
+    const double nnz_glob = (double)h->nnz_r * (double)h->m / (double)h->ml; // judged on the whole problem, not on the shard
+    if (opp_bytes <= 32.0 * 1024 * 1024 || nnz_glob < 1e8) return GLRM_OK;
+  }
+  h->cached_row = 1;
+  h->cached_cap = (int)cap;
+  // rows of at most 13 trips of the lane layout fit the wave's registers without spills (regcached_sweep_kernel)
+  const int ng = 64 / h->G;
+  const int64_t trips = (maxlen + ng - 1) / ng;
+  if (trips <= 13 && env_int("GLRM_HIP_CACHED_REGS", 1)) {
+    h->cached_row = 2;
+    h->cached_cap = (int)trips;
+  }
+  return GLRM_OK;
+}
+
+int glrm_run_cached(glrm_handle* h, int loss, double min_stepsize) {
+  CachedArgs a{};
+  a.nseg = h->ml;
+  a.ptr = h->rowptr;
+  a.idx = h->colidx;
+  a.vals = h->rowvals;
+  a.own = h->X;
+  a.own_offset = h->rb;
+  a.other = h->Y;
+  a.alpha = h->alpharow;
+  a.losses = h->losses;
+  a.regs = h->rx;
+  a.reg_single = h->n_rx == 1;
+  a.k = h->k;
+  a.fixed_alpha = h->fixed_alpha;
+  a.min_stepsize = min_stepsize;
+  a.trials = h->trials_r;
+  a.accepts = h->accepts_r;
+  a.cap = h->cached_cap;
+  if (h->rng_e >= 0) { // glrm_hip_step_x_range: local rows [rng_b, rng_e)
+    const int64_t s0 = h->rng_b;
+    a.nseg = h->rng_e - s0;
+    if (a.nseg <= 0) return GLRM_OK;
+    a.ptr += s0; a.alpha += s0; a.own_offset += s0;
+    if (!a.reg_single) a.regs += s0;
+    a.trials += s0; a.accepts += s0;
+  }
+  int rc;
+  if (h->cached_row == 2) rc = h->G == 4 ? launch_reg_layout<4, 8>(loss, a, h->stream) : launch_reg_layout<8, 8>(loss, a, h->stream);
+  else rc = h->G == 4 ? launch_layout<4, 8>(loss, a, h->stream) : launch_layout<8, 8>(loss, a, h->stream);
+  if (rc) return rc;
+  HIPCK(hipGetLastError());
+  return GLRM_OK;
+}

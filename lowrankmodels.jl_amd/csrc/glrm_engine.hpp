@@ -84,6 +84,7 @@ struct glrm_handle {
   int64_t vps_r = 0, vps_c = 0;           // opposing vectors per super-tile
   double *part_r = nullptr, *gsum_r = nullptr, *trial_r = nullptr, *jold_r = nullptr;
   int32_t *active_r = nullptr, *ntrial_r = nullptr;
+  int cached_row = 0, cached_cap = 0; // row sweep out of LDS (glrm_cached.hip): vectors a wave's buffer holds
   // glrm_options.quad_gram: trials from the quadratic form (glrm_dense.hpp: dense_gram_*)
   bool dense_gram = false;
   double *gramH = nullptr, *gram_part = nullptr; // [kp*kp], [GRAM_BLOCKS][kp*kp]
@@ -145,6 +146,9 @@ int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, d
 // stable segmented sort of a view by tile index (glrm_tilesort.hip)
 int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals);
 
+// cached gather row sweep (glrm_cached.hip)
+int glrm_setup_cached(glrm_handle* h);
+int glrm_run_cached(glrm_handle* h, int loss, double min_stepsize);
 // dense MFMA path (glrm_dense.hip)
 int glrm_setup_dense(glrm_handle* h, const glrm_problem* p);
 int glrm_run_dense(glrm_handle* h, bool rows, double min_stepsize, int eval_only);

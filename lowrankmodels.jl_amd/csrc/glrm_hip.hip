@@ -671,6 +671,7 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   if (rc2) return rc2;
   if (!h->multi) rc2 = p->dense_A ? glrm_setup_dense(h, p) : glrm_setup_tiled(h);
   if (rc2) return rc2;
+  if (!h->multi && !p->dense_A && (rc2 = glrm_setup_cached(h))) return rc2;
   if (!h->multi && !p->dense_A && (rc2 = glrm_setup_blocked(h))) return rc2;
   HIPCK(hipStreamSynchronize(st)); // host descriptor / index arrays may be released by the caller now
   return GLRM_OK;
@@ -964,6 +965,9 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
   } else if (tiled) {
     rc = glrm_run_tiled(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
     if (rc) return rc;
+  } else if (rows && h->cached_row && !eval_only) {
+    rc = glrm_run_cached(h, loss, min_stepsize);
+    if (rc) return rc;
   } else if (rows ? (h->blocked_row && !eval_only) : h->blocked_col) {
     rc = glrm_run_blocked(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
     if (rc) return rc;
@@ -1102,7 +1106,7 @@ extern "C" int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int
   if ((rc = count_sum(h, h->accepts_c, h->nl, &out->accepts_y))) return rc;
   out->nnz_rows = h->nnz_r; out->nnz_cols = h->nnz_c;
   out->waves_row = h->waves_row; out->waves_col = h->waves_col; out->ld = h->kp;
-  out->tiled = h->multi ? 8 : (h->tiled_row ? 1 : 0) | (h->tiled_col ? 2 : 0) | (h->dense ? 4 : 0) | (h->blocked_row ? 16 : 0) |
+  out->tiled = h->multi ? 8 : (h->tiled_row ? 1 : 0) | (h->tiled_col ? 2 : 0) | (h->dense ? 4 : 0) | (h->cached_row ? 64 : 0) | (h->blocked_row ? 16 : 0) |
                (h->blocked_col ? 32 : 0); // bit0 / bit1: LDS-tiled row / column sweep, bit4 / bit5: phase-aligned gather passes
   if (reset) {
     h->launches_x = h->launches_y = 0;
@@ -1152,7 +1156,7 @@ extern "C" int glrm_hip_objective(glrm_handle* h, const double* X, const double*
 // One outer iteration as a hipGraph.  Eligible: gather sweeps (fixed launch sequence, no host round trips inside a half-step) on
 // the handle's private stream (the legacy default stream cannot be captured), no per-launch event timing.
 static bool graph_eligible(const glrm_handle* h) {
-  return h->own_stream && !h->profile && !h->multi && !h->dense && !h->tiled_row && !h->tiled_col && !h->blocked_row && !h->blocked_col &&
+  return h->own_stream && !h->profile && !h->multi && !h->dense && !h->tiled_row && !h->tiled_col && !h->blocked_row && !h->blocked_col && !h->cached_row &&
          env_int("GLRM_HIP_GRAPH", 1) != 0;
 }
 

@@ -71,13 +71,21 @@ def test_eight_ranks_on_one_gpu_equal_one_rank():
 
 
 def test_phase_aligned_passes_two_ranks_equal_one_rank():
-    """The C4 recipe at 2M rows (2e8 observations): large enough for the automatic choice of the phase-aligned gather passes on
-    both half-steps (csrc/glrm_blocked.hip) -- made from the GLOBAL problem, so two shards run the same family as one and record the
-    same objectives bit for bit (strong scaling, pipelined X exchange on the blocked row sweep)."""
+    """The C4 recipe at 2M rows (2e8 observations): large enough for the automatic choices of the full-size problem -- the row sweep
+    with the row's vectors held in registers (csrc/glrm_cached.hip), the phase-aligned gather passes on the column side
+    (csrc/glrm_blocked.hip) -- made from the GLOBAL problem, so two shards run the same families as one and record the same objectives
+    bit for bit (strong scaling, pipelined X exchange in row chunks on the cached row sweep)."""
     common = ["--config", "C4", "--rows", "2000000", "--steps", "2", "--warmup", "2"] + QUIET
     env = dict(os.environ, GLRM_BENCH_BACKEND="gloo", GLRM_GATHER="allgather")
     two = run(torchrun(2) + common, env)
     one = run([sys.executable, "bench.py"] + common, dict(os.environ))
-    assert one["config"]["row_sweep"] == one["config"]["col_sweep"] == "blocked"
-    assert two["config"]["row_sweep"] == two["config"]["col_sweep"] == "blocked"
+    for r in (one, two):
+        assert r["config"]["row_sweep"] == "cached" and r["config"]["col_sweep"] == "blocked"
+    assert two["objective"] == one["objective"]
+    # both sides on the phase-aligned passes (the round-2 default before the cached row sweep)
+    env_b = dict(GLRM_HIP_CACHED="0")
+    two = run(torchrun(2) + common, dict(env, **env_b))
+    one = run([sys.executable, "bench.py"] + common, dict(os.environ, **env_b))
+    for r in (one, two):
+        assert r["config"]["row_sweep"] == r["config"]["col_sweep"] == "blocked"
     assert two["objective"] == one["objective"]

@@ -458,3 +458,97 @@ def test_skewed_lengths_split_launch():
     X0, Y0 = rng.standard_normal((k, m)), rng.standard_normal((k, n))
     g = L.GLRM(A, L.QuadLoss(), L.QuadReg(0.1), L.NonNegConstraint(), k, obs=(I, J), X=X0, Y=Y0)
     compare(g.problem_arrays(), np.asfortranarray(X0), np.asfortranarray(Y0), L.ProxGradParams(max_iter=15), tiled=1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# cached gather row sweep (csrc/glrm_cached.hip): the row's opposing vectors are gathered once into LDS, all passes read them there
+
+def _cached(monkeypatch, on):
+    monkeypatch.setenv("GLRM_HIP_CACHED", "1" if on else "0")
+
+
+@pytest.mark.parametrize("k", [20, 32, 40, 64])
+def test_cached_row_sweep_equals_the_gather_sweep_bit_for_bit(monkeypatch, k):
+    """Uniform QuadLoss: same observations per lane group in the same order, same butterfly -- the bits of the one-wave gather sweep."""
+    rng = np.random.default_rng(100 + k)
+    pa, X0, Y0 = random_problem(rng, 300, 90, k, 0.4, rx=L.NonNegConstraint(), ry=L.QuadReg(0.2), dup=True)
+    params = L.ProxGradParams(max_iter=8)
+    _cached(monkeypatch, False)
+    o0, Xa, Ya, st0 = cases.run_engine(hip(), pa, X0, Y0, params, tiled=1, waves_row=1)
+    _cached(monkeypatch, True)
+    for regs in ("1", "0"):  # the row's vectors in registers / in LDS
+        monkeypatch.setenv("GLRM_HIP_CACHED_REGS", regs)
+        monkeypatch.setenv("GLRM_HIP_CACHED_WAVES", "1")
+        o1, Xb, Yb, st1 = cases.run_engine(hip(), pa, X0, Y0, params, tiled=1, waves_row=1)
+        assert not st0["tiled"] & 64 and st1["tiled"] & 64
+        assert np.array_equal(o0, o1) and np.array_equal(Xa, Xb) and np.array_equal(Ya, Yb)
+        assert st0["trials_x"] == st1["trials_x"] and st0["accepts_x"] == st1["accepts_x"]
+    # two waves per row (the default for rows of more than four trips): the wave totals are added in wave order -- rounding only
+    monkeypatch.setenv("GLRM_HIP_CACHED_REGS", "1")
+    monkeypatch.setenv("GLRM_HIP_CACHED_WAVES", "2")
+    o2, Xc, Yc, st2 = cases.run_engine(hip(), pa, X0, Y0, params, tiled=1, waves_row=1)
+    assert st2["tiled"] & 64 and len(o2) == len(o0)
+    assert cases.rel_err(o2, o0) < 1e-10 and cases.fro_err(Xc, Xa) < 1e-10 and cases.fro_err(Yc, Ya) < 1e-10
+
+
+def test_cached_row_sweep_against_the_oracle_on_mixed_losses_and_regularizers(monkeypatch):
+    _cached(monkeypatch, True)
+    rng = np.random.default_rng(77)
+    m, n, k = 260, 120, 32
+    losses = [[L.QuadLoss(), L.HuberLoss(), L.LogisticLoss(), L.L1Loss(0.5), L.PoissonLoss(), L.OrdinalHingeLoss(1, 6)][j % 6] for j in range(n)]
+    doms = [L.default_domain(l) for l in losses]
+    Z = rng.standard_normal((m, 4)) @ rng.standard_normal((4, n))
+    A = np.array([[L.impute_entry(doms[j], losses[j], Z[i, j]) for j in range(n)] for i in range(m)], dtype=np.float64)
+    I, J_ = np.nonzero(rng.random((m, n)) < 0.5)
+    X0, Y0 = 0.3 * rng.standard_normal((k, m)), 0.3 * rng.standard_normal((k, n))
+    rx = [[L.QuadReg(0.3), L.OneReg(0.2), L.NonNegConstraint(), L.ZeroReg()][i % 4] for i in range(m)]
+    g = L.GLRM(A, losses, rx, L.QuadReg(0.1), k, obs=(I, J_), X=X0, Y=Y0)
+    pa = g.problem_arrays()
+    O.set_threads(4)
+    params = L.ProxGradParams(max_iter=10)
+    o_c, X_c, Y_c, st_c = cases.run_engine(O.oracle_api(), pa, np.asfortranarray(X0), np.asfortranarray(Y0), params)
+    o_g, X_g, Y_g, st_g = cases.run_engine(hip(), pa, np.asfortranarray(X0), np.asfortranarray(Y0), params, tiled=1)
+    assert st_g["tiled"] & 64 and len(o_g) == len(o_c)
+    assert cases.rel_err(o_g, o_c) < TOL and cases.fro_err(X_g, X_c) < TOL and cases.fro_err(Y_g, Y_c) < TOL
+
+
+def test_cached_row_sweep_in_row_chunks_sparse_solver_and_rows_too_long(monkeypatch):
+    _cached(monkeypatch, True)
+    rng = np.random.default_rng(5)
+    pa, X0, Y0 = random_problem(rng, 240, 64, 32, 0.5)
+    api = hip()
+    # (a) glrm_hip_step_x_range in chunks = one full sweep
+    import torch
+    res = []
+    for chunks in (1, 3):
+        h = api.create(pa, tiled=1)
+        assert api.kernel_stats(h)["tiled"] & 64
+        api.set_factors(h, X0, Y0)
+        api.reset_stepsizes(h, 1.0)
+        for _ in range(3):
+            if chunks == 1:
+                api.step_x(h, 0.01)
+            else:
+                for c in range(chunks):
+                    api.step_x_range(h, c * 80, (c + 1) * 80, 0.01)
+            api.step_y(h, 0.01)
+        X, Y = np.zeros_like(X0), np.zeros_like(Y0)
+        api.get_factors(h, X, Y)
+        api.destroy(h)
+        res.append((X, Y))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    # (b) SparseProxGradParams (fixed step, no line search) against the oracle
+    sp = L.SparseProxGradParams(max_iter=12)
+    outs = []
+    for a_ in (O.oracle_api(), api):
+        h = a_.create(pa, tiled=1) if a_ is api else a_.create(pa)
+        X, Y = np.array(X0, order="F"), np.array(Y0, order="F")
+        obj, _ = a_.fit_sparse(h, sp, X, Y)
+        a_.destroy(h)
+        outs.append((np.array(obj), X, Y))
+    assert len(outs[0][0]) == len(outs[1][0]) and cases.rel_err(outs[1][0], outs[0][0]) < TOL and cases.fro_err(outs[1][1], outs[0][1]) < TOL
+    # (c) a row longer than the LDS budget (160 KB = 640 vectors at k = 32 ... a fully observed 700-column row): falls back
+    pa2, X2, Y2 = random_problem(rng, 40, 700, 32, 1.1)
+    h = api.create(pa2, tiled=1)
+    assert not api.kernel_stats(h)["tiled"] & 64
+    api.destroy(h)
