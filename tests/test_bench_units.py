@@ -22,6 +22,9 @@ def test_algorithmic_bytes_match_the_survey():
     ("gather", dict(nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=128.8), "l2"),     # C4 X half-step: Y = 51 MB, cache resident
     ("tiled", dict(nnz=5 * 10**8, nseg=10_000, nopp=1_000_000, k=32, ld=32, ms=9.7), "lds"),     # C2 Y half-step
     ("dense", dict(nnz=10**10, nseg=1_000_000, nopp=10_000, k=32, ld=32, ms=42.3, m=1_000_000, n=10_000), "mfma"),
+    ("dense", dict(nnz=10**10, nseg=1_000_000, nopp=10_000, k=32, ld=32, ms=24.4, m=1_000_000, n=10_000, quad_gram=True), "mfma"),
+    ("cached", dict(nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=85.3), "l2"),      # C4 X half-step, one gather pass
+    ("cached", dict(nnz=10**9, nseg=10_000_000, nopp=2_000_000, k=64, ld=64, ms=120.0), "hbm"),  # the same with Y = 1 GB: HBM gathers
 ])
 def test_roofline_fractions_are_fractions(family, kw, bound):
     r = bench.kernel_roofline(family, **kw)
@@ -76,3 +79,19 @@ def _fast_clock():
     import time as _t
     t0, p0, real = _t.time(), _t.perf_counter(), _t.perf_counter  # perf_counter: bench.time.time itself is what gets patched
     return lambda: t0 + (real() - p0) * 50.0  # the 10-second sampling window of cpu_baseline in 0.2 s
+
+
+def test_cached_family_prices_one_gather_pass():
+    two = bench.kernel_roofline("gather", nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=100.0)
+    one = bench.kernel_roofline("cached", nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=100.0)
+    l2 = lambda r: next(c for c in r["candidates"] if c["bound"] == "l2")
+    assert l2(one)["per_launch"] * 2 == l2(two)["per_launch"] == 2 * 10**9 * 8 * 64
+    assert any(c["bound"] == "lds" for c in one["candidates"])  # the passes read the row out of LDS / registers
+
+
+def test_quad_gram_prices_the_flop_that_are_left():
+    a = bench.kernel_roofline("dense", nnz=10**10, nseg=10**6, nopp=10**4, k=32, ld=32, ms=40.0, m=10**6, n=10**4)
+    b = bench.kernel_roofline("dense", nnz=10**10, nseg=10**6, nopp=10**4, k=32, ld=32, ms=40.0, m=10**6, n=10**4, quad_gram=True)
+    mf = lambda r: next(c for c in r["candidates"] if c["bound"] == "mfma")
+    assert mf(a)["per_launch"] == 6.0 * 10**6 * 10**4 * 32 and mf(b)["per_launch"] == 4.0 * 10**6 * 10**4 * 32
+    assert mf(a)["measured_ceiling"]["v_mfma_f64_16x16x4_f64"] == 50.3
