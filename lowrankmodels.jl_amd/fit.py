@@ -233,8 +233,12 @@ class ShardedFit:
             c = nrows[0] // self.x_chunks
             self._stage = [torch.empty(self.world * c * self.ld, dtype=torch.float64, device=self.device) for _ in range(self.x_chunks)]
             self._comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        # GLRM_GATHER: auto (in-place all-gather on nccl = RCCL, one broadcast per owner otherwise) | allgather | broadcast | p2p (every
+        # owner sends its block straight to every peer in ONE group of point-to-point operations: ncclSend / ncclRecv on RCCL -- all
+        # seven xGMI links of a GPU carry a block at once, the direct exchange of DESIGN.md section 6 on the torch host)
         mode = os.environ.get("GLRM_GATHER", "auto")
-        self._inplace_ok = self.world > 1 and mode != "broadcast" and (mode == "allgather" or dist.get_backend(group) == "nccl")
+        self._p2p = self.world > 1 and mode == "p2p"
+        self._inplace_ok = self.world > 1 and mode not in ("broadcast", "p2p") and (mode == "allgather" or dist.get_backend(group) == "nccl")
 
     def close(self):
         if self.h is not None:
@@ -248,6 +252,28 @@ class ShardedFit:
         if self.world == 1:
             return
         dist, sizes = self.dist, [(bounds[r + 1] - bounds[r]) * unit for r in range(self.world)]
+        if self._p2p:  # ragged blocks are fine: every transfer carries its own size
+            g = lambda r: dist.get_global_rank(self.group, r) if self.group is not None else r
+            own = buf[bounds[self.rank] * unit: bounds[self.rank + 1] * unit]
+            ops = []
+            for r in range(self.world):
+                if r == self.rank:
+                    continue
+                if sizes[self.rank]:
+                    ops.append(dist.P2POp(dist.isend, own, g(r), group=self.group))
+                if sizes[r]:
+                    ops.append(dist.P2POp(dist.irecv, buf[bounds[r] * unit: bounds[r + 1] * unit], g(r), group=self.group))
+            if ops:
+                # only ProcessGroupNCCL orders point-to-point transfers with the CUDA stream; gloo (the plumbing-check backend) reads
+                # and writes device tensors from the host, so the stream is drained on both sides of the exchange there
+                host_sync = self.device.type == "cuda" and dist.get_backend(self.group) != "nccl"
+                if host_sync:
+                    self.torch.cuda.synchronize(self.device)
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+                if host_sync:
+                    self.torch.cuda.synchronize(self.device)
+            return
         if self._inplace_ok and len(set(sizes)) == 1 and sizes[0] > 0:
             own = buf[bounds[self.rank] * unit: bounds[self.rank + 1] * unit]
             # NCCL / RCCL allow sendbuff == recvbuff + rank * count; GLRM_GATHER_INPLACE=0 sends a copy of the block instead

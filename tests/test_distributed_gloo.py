@@ -42,7 +42,7 @@ def test_partition_balances_nnz():
     assert L.partition(np.zeros(11, dtype=np.int64), 2) == [0, 5, 10]
 
 
-@pytest.mark.parametrize("mode", ["auto", "allgather"])
+@pytest.mark.parametrize("mode", ["auto", "allgather", "p2p"])
 def test_two_ranks_equal_one_rank(tmp_path, mode):
     names = ["c1", "mixed", "kmeans"]
     ranks = run_world(tmp_path, names, 2, {"GLRM_GATHER": mode})
@@ -74,9 +74,11 @@ def test_c4_recipe_shards_equal_one_rank(tmp_path, nproc):
         assert np.array_equal(z["c4_obj"][1:], np.array(ch.objective[1:]))
 
 
-def test_three_ranks_ragged_blocks(tmp_path):
-    """m, n not divisible by the world size -> ragged blocks -> one broadcast per owner."""
-    ranks = run_world(tmp_path, ["nnmf"], 3)
+@pytest.mark.parametrize("mode", ["auto", "p2p"])
+def test_three_ranks_ragged_blocks(tmp_path, mode):
+    """m, n not divisible by the world size -> ragged blocks -> one broadcast per owner (auto) or one group of point-to-point
+    transfers, every owner straight to every peer (p2p)."""
+    ranks = run_world(tmp_path, ["nnmf"], 3, {"GLRM_GATHER": mode})
     kwargs, params = cases.build_golden_case("nnmf")
     g = L.GLRM(**kwargs)
     X, Y, ch = L.fit_b(g, params, verbose=False, engine=O.oracle_api())

@@ -33,7 +33,7 @@ def torchrun(n):
             "--master-port", str(free_port()), "bench.py", "--gpus", str(n)]
 
 
-@pytest.mark.parametrize("x_chunks,gather", [(4, "allgather"), (1, "broadcast")])
+@pytest.mark.parametrize("x_chunks,gather", [(4, "allgather"), (1, "broadcast"), (1, "p2p")])
 def test_two_ranks_on_one_gpu_equal_one_rank(x_chunks, gather):
     """Weak-scaling flags (--rows-per-gpu): two ranks x 30 000 rows = one rank x 60 000 rows of the C2 recipe."""
     common = ["--config", "C2", "--steps", "3", "--warmup", "2", "--cols", "2000", "--obs-per-row", "100", "--tiled", "2"] + QUIET
