@@ -46,7 +46,10 @@
 extern "C" {
 #endif
 
-#define GLRM_HIP_ABI_VERSION 1
+/* 2: glrm_options grew by quad_gram / reserved (round 2), glrm_signature + glrm_hip_signature / glrm_hip_finalize and
+ *    GLRM_PROBLEM_DEFER_SETUP were added (round 3).  A host built against ABI 1 fails the version check instead of handing over
+ *    a 32-byte glrm_options. */
+#define GLRM_HIP_ABI_VERSION 2
 
 typedef enum glrm_status {
   GLRM_OK = 0,
@@ -128,6 +131,9 @@ typedef struct glrm_domain {
 } glrm_domain; /* 24 bytes */
 
 #define GLRM_PROBLEM_DEVICE_ARRAYS 1 /* flags bit 0: rowptr..colvals are DEVICE pointers (copied, not adopted) */
+#define GLRM_PROBLEM_DEFER_SETUP 2   /* flags bit 1: this is one shard of a sharded fit -- glrm_hip_create only uploads it; the host
+                                        combines the shards' glrm_signature and calls glrm_hip_finalize on every shard before the
+                                        first step (see glrm_signature below) */
 
 /*
  * One shard of a GLRM.  A single-GPU problem is the shard
@@ -208,6 +214,23 @@ typedef struct glrm_options {
 
 typedef struct glrm_handle glrm_handle;
 
+/*
+ * What the engine's kernel choice looks at besides (m, n, k, losses, options).  The sweep families (gather, LDS-tiled,
+ * phase-aligned passes, cached rows) add the same numbers in different orders, so a sharded fit is bit-identical to the
+ * single-shard fit only if every shard makes the SAME choice: the choice is therefore a function of the WHOLE problem's signature,
+ * never of the shard's.  (Per-segment choices -- waves per segment, which rows the cached sweep holds in registers -- are functions
+ * of the segment's own length.)  A host that shards a problem creates every shard with GLRM_PROBLEM_DEFER_SETUP, reads each
+ * shard's signature, combines them (sum the counts, max the rest) and hands the result to glrm_hip_finalize on every shard.  The
+ * in-library multi-device fit (glrm_hip_multi_*) and lowrankmodels.jl_amd/fit.py::ShardedFit do exactly that.
+ * The reference has no counterpart: its threads share one address space (src/algorithms/proxgrad_multithread.jl:118,163).
+ */
+typedef struct glrm_signature {
+  int64_t nnz_rows, nnz_cols;       /* observations in the row / column view                  (whole problem: sum over shards) */
+  int64_t max_row_len, max_col_len; /* longest row / column list                              (max over shards) */
+  int32_t rows_unordered;           /* 1: some row list is not ordered by LDS tile            (max over shards) */
+  int32_t cols_unordered;           /* 1: some column list is not ordered by LDS tile         (max over shards) */
+} glrm_signature; /* 40 bytes */
+
 /* ---- whole-fit API (what the Julia `fit!` shim calls) -------------------------------- */
 
 int glrm_hip_version(void);
@@ -216,6 +239,13 @@ const char* glrm_hip_last_error(void);
 /* Copies the shard's Omega views, values and descriptors to the device. */
 int glrm_hip_create(glrm_handle** out, const glrm_problem* p, const glrm_options* o);
 void glrm_hip_destroy(glrm_handle* h); /* NULL is a no-op */
+/* This shard's contribution to the signature of the whole problem (any handle, any time after create). */
+int glrm_hip_signature(glrm_handle* h, glrm_signature* local);
+/* Second half of glrm_hip_create for a handle created with GLRM_PROBLEM_DEFER_SETUP: chooses the kernel families from the
+ * signature of the WHOLE problem (NULL = this shard is the whole problem) and allocates their buffers.  Every step-level call on
+ * a deferred handle fails with GLRM_ERR_INVALID until this has run; calling it twice, or on a handle created without the flag,
+ * is GLRM_ERR_INVALID as well. */
+int glrm_hip_finalize(glrm_handle* h, const glrm_signature* whole);
 
 /*
  * fit!(glrm, ProxGradParams) for a single-shard handle (src/algorithms/proxgrad.jl:34-220).
@@ -314,8 +344,9 @@ int glrm_hip_synchronize(glrm_handle* h);
  * by observation count, uploads block s to device_ids[s] and keeps a replica of X and Y on every device.  glrm_hip_multi_fit is
  * fit!(glrm, ProxGradParams) (src/algorithms/proxgrad.jl:34-220) on that layout: every shard runs the X half-step of its rows on
  * its own device from its own host thread and stream, the updated row blocks are exchanged (all-gather), then the same for the
- * columns; the recorded objective is a fixed-order sum of the gathered per-column values, so objective[], X and Y are bit-identical
- * to glrm_hip_fit on one device for every n_shards.
+ * columns; the recorded objective is a fixed-order sum of the gathered per-column values and the kernel families are chosen from the whole
+ * problem (glrm_signature), so objective[1:], X and Y are bit-identical to glrm_hip_fit on one device for every n_shards;
+ * objective[0] (initial loss + penalties, summed per shard block) agrees to rounding.
  *
  * Exchange (glrm_multi_options.exchange): 0 = direct -- every device pushes its block to each peer with hipMemcpyPeerAsync on a
  * copy stream per (source, destination) pair, i.e. all 7 xGMI links of a GPU carry one 1/N slice at once; 1 = RCCL ncclAllGather

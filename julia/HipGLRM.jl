@@ -28,6 +28,7 @@ import LowRankModels: fit!, GLRM, AbstractParams, ConvergenceHistory, update_ch!
 export HipProxGradParams, hip_release!
 
 const LIB = get(ENV, "GLRM_HIP_LIB", "libglrm_hip.so")
+const ABI_VERSION = 2                         # GLRM_HIP_ABI_VERSION of the include/glrm_hip.h these struct mirrors were written against
 
 # mirrors of the C structs (include/glrm_hip.h)
 struct CLoss; kind::Int32; dim::Int32; scale::Float64; p0::Float64; p1::Float64; end   # dim = embedding_dim (0/1: scalar)
@@ -46,6 +47,9 @@ struct CParams
 end
 struct COptions; device_id::Int32; profile::Int32; waves_row::Int32; waves_col::Int32; stream::Ptr{Cvoid}; caller_stream::Int32; tiled::Int32; quad_gram::Int32; reserved::Int32; end
 struct CMultiOptions; n_shards::Int32; exchange::Int32; device_ids::Ptr{Int32}; x_chunks::Int32; reserved::Int32; end
+# glrm_signature: only hosts that shard a problem THEMSELVES (one handle per shard, GLRM_PROBLEM_DEFER_SETUP) need it; this shim hands
+# the whole problem to glrm_hip_multi_create, which does that internally.  Mirrored so that tests/test_julia_shim.py checks it too.
+struct CSignature; nnz_rows::Int64; nnz_cols::Int64; max_row_len::Int64; max_col_len::Int64; rows_unordered::Int32; cols_unordered::Int32; end
 
 "The 7 ProxGradParams fields (src/algorithms/proxgrad.jl:4-12) + where to run: `device_id` (one GPU) or `ngpus` / `device_ids`."
 mutable struct HipProxGradParams <: AbstractParams
@@ -114,6 +118,11 @@ end
 
 lasterr() = unsafe_string(ccall((:glrm_hip_last_error, LIB), Cstring, ()))
 check(rc) = rc == 0 ? nothing : error("glrm_hip [$rc]: " * lasterr())
+# a library built from another header revision would read these structs with a different layout: refuse it up front
+function check_abi()
+    v = ccall((:glrm_hip_version, LIB), Cint, ())
+    v == ABI_VERSION || error("libglrm_hip.so speaks ABI $v, HipGLRM.jl was written against ABI $ABI_VERSION (include/glrm_hip.h)")
+end
 
 fallback(glrm, p; kw...) = fit!(glrm, ProxGradParams(p.stepsize; max_iter=p.max_iter, inner_iter_X=p.inner_iter_X, inner_iter_Y=p.inner_iter_Y,
                                              abs_tol=p.abs_tol, rel_tol=p.rel_tol, min_stepsize=p.min_stepsize); kw...)
@@ -159,6 +168,7 @@ function handle(glrm::GLRM, desc, p::HipProxGradParams)
         return e.h
     end
     e === nothing ? finalizer(hip_release!, glrm) : destroy(e)
+    check_abi()
     A = glrm.A; m, n = size(A); h = Ref{Ptr{Cvoid}}(C_NULL)
     rowptr, colidx, rowvals = dense ? (Int64[], Int32[], Float64[]) : flatten(glrm.observed_features, (e, j) -> value(glrm.losses[j], A[e, j]))
     colptr, rowidx, colvals = dense ? (Int64[], Int32[], Float64[]) : flatten(glrm.observed_examples, (j, e) -> value(glrm.losses[j], A[e, j]))
@@ -193,9 +203,16 @@ function fit!(glrm::GLRM, p::HipProxGradParams; ch::ConvergenceHistory=Convergen
                 (Ptr{Cvoid}, Ref{CParams}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}),
                 h, prm, X, Y, obj, sec, cap, nrec))
     X === glrm.X || copyto!(glrm.X, X)
+    scaled_abs_tol = p.abs_tol * sum(length, glrm.observed_features)                  # src/algorithms/proxgrad.jl:72
     for i in 1:nrec[]
         update_ch!(ch, i == 1 ? 0.0 : sec[i] - sec[i-1], obj[i])
-        (verbose && i > 1 && (i - 1) % 10 == 0 && i < nrec[]) && println("Iteration $(i-1): objective value = $(obj[i])")
+        # the reference prints every 10th iteration it did NOT stop at (:210-216) -- including iteration max_iter when the run ends there
+        it = i - 1
+        if verbose && it >= 1 && it % 10 == 0
+            dec = obj[i-1] - obj[i]
+            stopped = it > 10 && (dec < scaled_abs_tol || dec / obj[i] < p.rel_tol)
+            stopped || println("Iteration $it: objective value = $(obj[i])")
+        end
     end
     return glrm.X, glrm.Y, ch
 end

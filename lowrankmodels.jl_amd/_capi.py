@@ -11,11 +11,12 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 GLRM_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_COMM, ERR_OOM, ERR_NONFINITE = -1, -2, -3, -4, -5, -6
 PROBLEM_DEVICE_ARRAYS = 1
+PROBLEM_DEFER_SETUP = 2
 
 
 class GLRMError(RuntimeError):
@@ -72,6 +73,26 @@ class COptions(C.Structure):
                 ("reserved", C.c_int32)]
 
 
+class CSignature(C.Structure):
+    """glrm_signature: what the kernel choice reads from the WHOLE problem (sum the counts over shards, max the rest)."""
+    _fields_ = [("nnz_rows", C.c_int64), ("nnz_cols", C.c_int64), ("max_row_len", C.c_int64), ("max_col_len", C.c_int64),
+                ("rows_unordered", C.c_int32), ("cols_unordered", C.c_int32)]
+    SUM_FIELDS = ("nnz_rows", "nnz_cols")
+
+    def astuple(self):
+        return tuple(int(getattr(self, f)) for f, _ in self._fields_)
+
+    @classmethod
+    def combine(cls, parts):
+        """The whole problem's signature from the shards' (each a CSignature or its astuple())."""
+        parts = [p.astuple() if isinstance(p, cls) else tuple(int(v) for v in p) for p in parts]
+        out = cls()
+        for i, (f, _) in enumerate(cls._fields_):
+            vals = [p[i] for p in parts]
+            setattr(out, f, sum(vals) if f in cls.SUM_FIELDS else max(vals))
+        return out
+
+
 class CMultiOptions(C.Structure):
     _fields_ = [("n_shards", C.c_int32), ("exchange", C.c_int32), ("device_ids", C.c_void_p), ("x_chunks", C.c_int32), ("reserved", C.c_int32)]
 
@@ -91,7 +112,7 @@ class CKernelStats(C.Structure):
 #: every symbol include/glrm_hip.h declares (suffix after the prefix); the CPU test-suite checks
 #: that the built library exports all of them.
 ABI_SYMBOLS = (
-    "version", "last_error", "create", "destroy", "fit", "fit_sparse", "objective", "factor_ld", "bind_buffers",
+    "version", "last_error", "create", "destroy", "signature", "finalize", "fit", "fit_sparse", "objective", "factor_ld", "bind_buffers",
     "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "gradstep_x", "gradstep_y", "col_losses", "row_penalties",
     "col_penalties", "set_regularizers", "subset", "init_svd", "error_metric", "impute", "sum", "synchronize", "kernel_stats",
     "multi_create", "multi_fit", "multi_set_regularizers", "multi_info", "multi_destroy",
@@ -145,6 +166,8 @@ class Api:
             "last_error": (C.c_char_p, []),
             "create": (C.c_int, [C.POINTER(H), C.POINTER(CProblem), C.POINTER(COptions)]),
             "destroy": (None, [H]),
+            "signature": (C.c_int, [H, C.POINTER(CSignature)]),
+            "finalize": (C.c_int, [H, C.POINTER(CSignature)]),
             "fit": (C.c_int, [H, C.POINTER(CParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                               C.POINTER(C.c_int64)]),
             "fit_sparse": (C.c_int, [H, C.POINTER(CSparseParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
@@ -211,17 +234,29 @@ class Api:
             p.dense_A, p.dense_ld, p.dense_colmajor, p.dense_reserved = _ptr(prob.dense_A), prob.dense_ld, prob.dense_colmajor, 0
         return p
 
-    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=None, tiled=0, quad_gram=0):
+    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=None, tiled=0, quad_gram=0, defer=False):
         """``stream=None``: the handle creates a private stream.  ``stream=<int>``: launch on exactly that
         hipStream_t -- 0 is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns
-        for the default stream), so kernels stay ordered with the caller's other work on it."""
+        for the default stream), so kernels stay ordered with the caller's other work on it.
+        ``defer=True`` (one shard of a sharded fit): only upload; the host combines :meth:`signature` over the shards and
+        calls :meth:`finalize` on every one of them (GLRM_PROBLEM_DEFER_SETUP)."""
         if prob.dense_A is not None and not self.dense_ok:
             raise GLRMError(ERR_UNSUPPORTED, "this engine takes observation lists only")
         p = self._cproblem(prob)
+        if defer:
+            p.flags |= PROBLEM_DEFER_SETUP
         o = COptions(device_id, profile, waves_row, waves_col, (stream or None), 0 if stream is None else 1, tiled, int(quad_gram), 0)
         h = C.c_void_p()
         self._ck(self._f["create"](C.byref(h), C.byref(p), C.byref(o)))
         return h
+
+    def signature(self, h) -> CSignature:
+        sig = CSignature()
+        self._ck(self._f["signature"](h, C.byref(sig)))
+        return sig
+
+    def finalize(self, h, whole: "CSignature | None" = None):
+        self._ck(self._f["finalize"](h, C.byref(whole) if whole is not None else None))
 
     # -- one process, several devices (glrm_*_multi_*) -----------------------------------------
     def multi_create(self, prob: "ProblemArrays", n_shards, device_ids=None, exchange=0, x_chunks=0, profile=0, waves_row=0,

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "glrm_engine.hpp"
 #include "glrm_tiled.hpp"
@@ -38,17 +39,17 @@ int glrm_setup_blocked(glrm_handle* h) {
   const int64_t cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   const int T = tile_rows_b(h->kp);
   auto decide = [&](bool rows) -> bool {
+    // Everything below is read from the WHOLE problem (m, n, k, glrm_signature, options), never from the shard, so that every
+    // shard count runs the same family (the families differ in summation order).
     if (rows ? h->tiled_row : h->tiled_col) return false;          // the LDS-tiled sweep already owns this view
-    if (rows && h->cached_row) return false;                       // the row sweep runs out of LDS (glrm_cached.hip)
+    if (rows && h->cached_want) return false;                      // the short rows run on the cached sweep (glrm_cached.hip)
     if (!(rows ? h->rows_sorted : h->cols_sorted)) return false;   // a group must meet the opposing factor front to back
-    const int64_t nseg = rows ? h->ml : h->nl, nnz = rows ? h->nnz_r : h->nnz_c, nopp = rows ? h->n : h->m;
-    if (nseg <= 0 || nnz <= 0) return false;
+    const int64_t nnz = rows ? h->sig.nnz_rows : h->sig.nnz_cols, nopp = rows ? h->n : h->m;
+    if (nnz <= 0) return false;
     if (want > 0) return ((want >> (rows ? 0 : 1)) & 1) != 0;
-    // The choice is made from the GLOBAL problem (m, n, mean list length), not from the shard, so that every shard count runs the
-    // same family (the families differ in summation order).
     const double opp_bytes = (double)nopp * h->kp * 8;
     const int64_t nseg_glob = rows ? h->m : h->n;
-    const double mean_len = (double)nnz / (double)nseg;
+    const double mean_len = (double)nnz / (double)nseg_glob;
     if (opp_bytes <= 32.0 * 1024 * 1024 || mean_len * (double)nseg_glob < 2e8) return false; // small factor: LDS tiles or plain L2 hits do better
     // observations that meet one vector of the opposing factor while the groups the chip holds (4 waves per SIMD) walk past it, per XCD
     const double resident = std::min<double>((double)nseg_glob, (double)cus * 16 * (64 / h->G));
@@ -106,8 +107,9 @@ template <int G, int R, int LOSS, bool GRAD>
 static int launch_blocked_inst(glrm_handle* h, TiledArgs a) {
   constexpr int KP = G * R, T = tile_rows_b(KP), SPB = BNW * (64 / G);
   auto kernel = tiled_col_pass_kernel<G, R, BNW, T, LOSS, GRAD, true>;
-  static int64_t cap = 0; // per instantiation
-  if (cap == 0) cap = slice_capacity(kernel, h->device, SPB);
+  static std::atomic<int64_t> cap_cache{0}; // per instantiation; shards of one process call this concurrently (same value on every device of a node)
+  int64_t cap = cap_cache.load(std::memory_order_relaxed);
+  if (cap == 0) { cap = slice_capacity(kernel, h->device, SPB); cap_cache.store(cap, std::memory_order_relaxed); }
   const int64_t nseg = a.nseg;
   for (int sup = 0; sup < a.nsup; ++sup) {
     for (int64_t s0 = 0; s0 < nseg; s0 += cap) {

@@ -6,7 +6,7 @@
 // a row's half-step read the SAME vectors: Y does not change during the X half-step.  So the row's vectors are fetched once and kept
 // on chip for the gradient pass, the prox and every trial of the backtracking line search; the gather traffic of the half-step drops
 // from (1 + trials) passes to one.  Two homes for the row:
-//   registers (regcached_sweep_kernel, the default when the longest row of the shard needs <= 13 trips of the lane layout): a 64-lane
+//   registers (regcached_sweep_kernel, the default; rows of <= 13 trips of the lane layout): a 64-lane
 //             wave may use 512 VGPRs per lane; two waves share a row, each holding every other trip's vectors, all loads of a wave
 //             in flight together; the passes are straight-line code over registers.  C4 X half-step 120.6 -> 85.4 ms.
 //   LDS       (cached_sweep_kernel; rows up to the LDS budget): one wave per row, the row gathered with LDS-DMA.  C4: 110.5 ms.
@@ -47,8 +47,18 @@ struct CachedArgs {
   int32_t* trials;
   int32_t* accepts;
   int cap; // LDS variant: vectors a wave's buffer holds (a multiple of the vectors one DMA instruction moves);
-           // register variant: trips of 64 / G observations the longest row of the shard needs
+           // register variant: trips of 64 / G observations the longest row of this launch needs
+  const int32_t* seglist; // nullable: the launch covers the local rows seglist[0..nseg) -- the rows short enough for the cached
+                          // sweep when the shard also holds longer ones -- restricted to [seg_lo, seg_hi) (glrm_hip_step_x_range)
+  int64_t seg_lo, seg_hi;
 };
+
+__device__ __forceinline__ int64_t cached_segment(const CachedArgs& a, int64_t slot) { // -1: nothing to do for this workgroup
+  if (slot >= a.nseg) return -1;
+  if (!a.seglist) return slot;
+  const int64_t seg = a.seglist[slot];
+  return (seg < a.seg_lo || seg >= a.seg_hi) ? -1 : seg;
+}
 
 // One pass over the row out of LDS: J = sum of losses at u = <xv, y_t>, and (GRAD) g = sum of dL * y_t.
 template <int G, int R, int LOSS, bool GRAD>
@@ -129,8 +139,8 @@ __global__ void __launch_bounds__(64) cached_sweep_kernel(const CachedArgs a) {
   constexpr int KP = G * R, KPB = KP * 8, CPV = KPB / 16, VPI = 64 / CPV; // 16-byte chunks per vector, vectors per DMA instruction
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x;
-  const int64_t seg = blockIdx.x;
-  if (seg >= a.nseg) return;
+  const int64_t seg = cached_segment(a, blockIdx.x);
+  if (seg < 0) return;
   const int j = lane % G, gi = lane / G;
   const int64_t beg = a.ptr[seg];
   const int len = (int)(a.ptr[seg + 1] - beg);
@@ -335,8 +345,8 @@ __global__ void __launch_bounds__(WAVES * 64) regcached_sweep_kernel(const Cache
   constexpr int KP = G * R, NG = (64 / G) * WAVES;
   __shared__ __attribute__((aligned(16))) double red[WAVES == 1 ? 2 : WAVES * (KP + 2)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t seg = blockIdx.x;
-  if (seg >= a.nseg) return;
+  const int64_t seg = cached_segment(a, blockIdx.x);
+  if (seg < 0) return;
   const int j = lane % G, gi = wave * (64 / G) + lane / G;
   const int64_t beg = a.ptr[seg];
   const int len = (int)(a.ptr[seg + 1] - beg);
@@ -437,7 +447,7 @@ int launch_reg_inst(const CachedArgs& a, hipStream_t st) { // a.cap = trips of o
   // Two waves per row (each holds every other trip's vectors: half the registers, two waves per SIMD, so one wave's loads overlap the
   // other's arithmetic).  Measured at C4, X half-step: one wave per row 101.5 ms, two 85.4 ms, four 130.3 ms (phase-aligned passes 120.6).
   // ALWAYS two, also for rows one wave could hold: the wave count fixes the order of the sums, and it must not depend on the
-  // longest row of the shard.  GLRM_HIP_CACHED_WAVES = 1 | 4 are the experiment switches.
+  // longest row of the launch (MAXT only adds empty trips).  GLRM_HIP_CACHED_WAVES = 1 | 4 are the experiment switches.
   const int waves = env_int("GLRM_HIP_CACHED_WAVES", 2);
   if (waves == 4 && (a.cap + 3) / 4 <= 4) {
     hipLaunchKernelGGL((regcached_sweep_kernel<G, R, LOSS, 4, 4>), dim3((unsigned)a.nseg), dim3(256), 0, st, a);
@@ -485,43 +495,48 @@ int launch_layout(int loss, const CachedArgs& a, hipStream_t st) {
 
 } // namespace
 
-// Decide whether the row sweep of this handle runs out of LDS.  Auto (GLRM_HIP_CACHED unset): rows are not LDS-tiled, the opposing
-// factor is beyond the Infinity-Cache-friendly sizes where the plain gathers already do well (> 32 MB), the view is large, and EVERY
-// row of the shard fits a buffer of at most ~52 KB (three waves per CU: enough bytes in flight to stay bandwidth-bound).  The choice
-// does not change any sum of the uniform-QuadLoss row sweep (same order as the gather sweep), so shards may differ in it.
+// Does the WHOLE problem run its short rows on the cached sweep (glrm_handle::cached_want)?  Auto (GLRM_HIP_CACHED unset): the rows
+// are not LDS-tiled, the opposing factor is beyond the sizes where the plain gathers already do well (> 32 MB) and the row view
+// holds >= 1e8 observations -- all read from glrm_signature and (m, n, k), never from the shard.  WHICH rows it takes is a
+// function of the row's own length (glrm_cached_maxlen): registers hold up to 13 trips of the lane layout (104 observations at
+// k = 64, 208 at k <= 32); the LDS variant (GLRM_HIP_CACHED_REGS=0) up to its buffer.  Longer rows run the gather sweep with the
+// waves their length asks for.  A row is therefore always summed in the same order, whatever shard holds it.
 int glrm_setup_cached(glrm_handle* h) {
-  h->cached_row = 0;
-  const int want = env_int("GLRM_HIP_CACHED", h->tiled_opt == 1 ? 0 : -1); // -1 auto, 0 off, 1 wherever the rows fit (160 KB)
-  if (want == 0 || h->tiled_row || h->ml <= 0 || h->nnz_r <= 0) return GLRM_OK;
+  h->cached_row = h->cached_want = 0;
+  const int want = env_int("GLRM_HIP_CACHED", h->tiled_opt == 1 ? 0 : -1); // -1 auto, 0 off, 1 wherever the rows fit
+  if (want == 0 || h->tiled_row || h->sig.nnz_rows <= 0) return GLRM_OK;
   if (!((h->G == 4 || h->G == 8) && h->R == 8)) return GLRM_OK;
-  std::vector<int64_t> ptr((size_t)h->ml + 1);
-  HIPCK(hipMemcpyAsync(ptr.data(), h->rowptr, ((size_t)h->ml + 1) * 8, hipMemcpyDeviceToHost, h->stream));
-  HIPCK(hipStreamSynchronize(h->stream));
-  int64_t maxlen = 0;
-  for (int64_t s = 0; s < h->ml; ++s) maxlen = std::max(maxlen, ptr[s + 1] - ptr[s]);
-  const int vpi = 64 / (h->kp * 8 / 16);
-  const int64_t cap = (maxlen + vpi - 1) / vpi * vpi;
-  const int64_t bytes = cap * (h->kp * 8 + 12);
-  const int64_t budget = want > 0 ? 160 * 1024 : 53 * 1024;
-  if (cap <= 0 || bytes > budget) return GLRM_OK;
   if (want < 0) {
     const double opp_bytes = (double)h->n * h->kp * 8;
-    const double nnz_glob = (double)h->nnz_r * (double)h->m / (double)h->ml; // judged on the whole problem, not on the shard
-    if (opp_bytes <= 32.0 * 1024 * 1024 || nnz_glob < 1e8) return GLRM_OK;
+    if (opp_bytes <= 32.0 * 1024 * 1024 || (double)h->sig.nnz_rows < 1e8) return GLRM_OK;
   }
-  h->cached_row = 1;
-  h->cached_cap = (int)cap;
-  // rows of at most 13 trips of the lane layout fit the wave's registers without spills (regcached_sweep_kernel)
-  const int ng = 64 / h->G;
-  const int64_t trips = (maxlen + ng - 1) / ng;
-  if (trips <= 13 && env_int("GLRM_HIP_CACHED_REGS", 1)) {
-    h->cached_row = 2;
-    h->cached_cap = (int)trips;
-  }
+  h->cached_want = 1;
+  h->cached_row = env_int("GLRM_HIP_CACHED_REGS", 1) ? 2 : 1;
   return GLRM_OK;
 }
 
-int glrm_run_cached(glrm_handle* h, int loss, double min_stepsize) {
+// longest row the cached sweep takes
+int64_t glrm_cached_maxlen(const glrm_handle* h) {
+  if (h->cached_row == 2) return glrm_cached_reg_maxlen(h->G);
+  const int vpi = 64 / (h->kp * 8 / 16);
+  const int64_t budget = env_int("GLRM_HIP_CACHED", -1) > 0 ? 160 * 1024 : 53 * 1024; // auto: three waves per CU
+  return budget / (h->kp * 8 + 12) / vpi * vpi;
+}
+
+// the launch parameter of the cached kernels for a longest row of `maxlen` observations
+void glrm_cached_set_cap(glrm_handle* h, int64_t maxlen) {
+  if (h->cached_row == 2) {
+    const int ng = 64 / h->G;
+    h->cached_cap = (int)((maxlen + ng - 1) / ng);
+  } else {
+    const int vpi = 64 / (h->kp * 8 / 16);
+    h->cached_cap = (int)((maxlen + vpi - 1) / vpi * vpi);
+    if (h->cached_cap < vpi) h->cached_cap = vpi;
+  }
+}
+
+// seglist == nullptr: every local row (restricted to the range of glrm_hip_step_x_range, if one is set); otherwise the rows listed
+int glrm_run_cached(glrm_handle* h, int loss, double min_stepsize, const int32_t* seglist, int64_t nlist, hipStream_t st) {
   CachedArgs a{};
   a.nseg = h->ml;
   a.ptr = h->rowptr;
@@ -540,7 +555,14 @@ int glrm_run_cached(glrm_handle* h, int loss, double min_stepsize) {
   a.trials = h->trials_r;
   a.accepts = h->accepts_r;
   a.cap = h->cached_cap;
-  if (h->rng_e >= 0) { // glrm_hip_step_x_range: local rows [rng_b, rng_e)
+  a.seg_lo = 0;
+  a.seg_hi = h->ml;
+  if (seglist) {
+    a.seglist = seglist;
+    a.nseg = nlist;
+    if (h->rng_e >= 0) { a.seg_lo = h->rng_b; a.seg_hi = h->rng_e; }
+    if (a.nseg <= 0 || a.seg_hi <= a.seg_lo) return GLRM_OK;
+  } else if (h->rng_e >= 0) { // glrm_hip_step_x_range: local rows [rng_b, rng_e)
     const int64_t s0 = h->rng_b;
     a.nseg = h->rng_e - s0;
     if (a.nseg <= 0) return GLRM_OK;
@@ -549,8 +571,8 @@ int glrm_run_cached(glrm_handle* h, int loss, double min_stepsize) {
     a.trials += s0; a.accepts += s0;
   }
   int rc;
-  if (h->cached_row == 2) rc = h->G == 4 ? launch_reg_layout<4, 8>(loss, a, h->stream) : launch_reg_layout<8, 8>(loss, a, h->stream);
-  else rc = h->G == 4 ? launch_layout<4, 8>(loss, a, h->stream) : launch_layout<8, 8>(loss, a, h->stream);
+  if (h->cached_row == 2) rc = h->G == 4 ? launch_reg_layout<4, 8>(loss, a, st) : launch_reg_layout<8, 8>(loss, a, st);
+  else rc = h->G == 4 ? launch_layout<4, 8>(loss, a, st) : launch_layout<8, 8>(loss, a, st);
   if (rc) return rc;
   HIPCK(hipGetLastError());
   return GLRM_OK;

@@ -84,7 +84,8 @@ struct glrm_handle {
   int64_t vps_r = 0, vps_c = 0;           // opposing vectors per super-tile
   double *part_r = nullptr, *gsum_r = nullptr, *trial_r = nullptr, *jold_r = nullptr;
   int32_t *active_r = nullptr, *ntrial_r = nullptr;
-  int cached_row = 0, cached_cap = 0; // row sweep out of LDS (glrm_cached.hip): vectors a wave's buffer holds
+  int cached_row = 0, cached_cap = 0; // cached gather row sweep (glrm_cached.hip): 0 off, 1 LDS, 2 registers; trips / vectors a row may have
+  int cached_want = 0;                // the whole problem runs its short rows on the cached sweep (decided from glrm_signature, never from the shard)
   // glrm_options.quad_gram: trials from the quadratic form (glrm_dense.hpp: dense_gram_*)
   bool dense_gram = false;
   double *gramH = nullptr, *gram_part = nullptr; // [kp*kp], [GRAM_BLOCKS][kp*kp]
@@ -105,10 +106,17 @@ struct glrm_handle {
   double *partials = nullptr, *dscalar = nullptr;
   unsigned long long* dcount = nullptr;
   int32_t *trials_r = nullptr, *accepts_r = nullptr, *trials_c = nullptr, *accepts_c = nullptr;
-  int waves_row = 1, waves_col = 4;
-  int32_t *seglist_r = nullptr, *seglist_c = nullptr; // gather sweeps, skewed lengths: [short segments..., long segments (longest first)]
-  int64_t nlong_r = 0, nlong_c = 0;
-  hipStream_t side_stream = nullptr;  // the long segments' launch runs beside the short segments' launch
+  // Gather sweeps: the waves that share a segment are a function of the segment's OWN length (1 below 1536 observations, 4 below
+  // 98304, else 8; glrm_options.waves_* pins one count for all), so the order of a segment's sums never depends on which shard
+  // holds it.  Class 0 = rows the cached sweep holds on chip.  ncls_* counts the local segments per class; when more than one class
+  // is populated seglist_* lists the segments class by class (ascending ids inside a class) and each class gets its own launch.
+  int waves_row = 1, waves_col = 4;   // the class most local segments fall into (reported by glrm_hip_kernel_stats)
+  int32_t *seglist_r = nullptr, *seglist_c = nullptr;
+  int64_t ncls_r[4] = {0, 0, 0, 0}, ncls_c[4] = {0, 0, 0, 0};
+  bool finalized = false;             // false between a GLRM_PROBLEM_DEFER_SETUP create and glrm_hip_finalize
+  glrm_signature sig_local{}, sig{};  // this shard's contribution / the whole problem's
+  int order_unit = 0;                 // opposing vectors per unit of the tile-order check (glrm_tiled.hip)
+  hipStream_t side_stream = nullptr;  // the launches of the minority classes run beside the main launch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int profile = 0;
   // hipGraph of one outer iteration (gather sweeps on a private stream): small fits are launch bound
@@ -135,7 +143,16 @@ inline int env_int(const char* name, int dflt) {
 }
 
 
-// LDS-tiled sweeps (glrm_tiled.hip)
+// per-segment class of the gather sweeps (see glrm_handle::seglist_r)
+constexpr int64_t GLRM_WAVES4_FROM = 1536, GLRM_WAVES8_FROM = 98304;
+__host__ __device__ inline int glrm_wave_class(int64_t len) { return len < GLRM_WAVES4_FROM ? 1 : (len < GLRM_WAVES8_FROM ? 2 : 3); }
+constexpr int glrm_class_waves(int cls) { return cls <= 1 ? 1 : (cls == 2 ? 4 : 8); }
+// rows the register-cached sweep takes: at most 13 trips of the lane layout, 64 / G observations each
+inline int64_t glrm_cached_reg_maxlen(int G) { return (int64_t)13 * (64 / G); }
+
+// LDS-tiled sweeps (glrm_tiled.hip).  prepare: tile configuration + the tile-order check of this shard's lists (create);
+// setup: family choice from h->sig and buffers (finalize)
+int glrm_prepare_tiled(glrm_handle* h);
 int glrm_setup_tiled(glrm_handle* h);
 int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only);
 
@@ -147,8 +164,10 @@ int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, d
 int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals);
 
 // cached gather row sweep (glrm_cached.hip)
-int glrm_setup_cached(glrm_handle* h);
-int glrm_run_cached(glrm_handle* h, int loss, double min_stepsize);
+int glrm_setup_cached(glrm_handle* h);                 // finalize: cached_want / cached_row from h->sig
+int64_t glrm_cached_maxlen(const glrm_handle* h);      // longest row the cached sweep takes (a function of k and the variant)
+void glrm_cached_set_cap(glrm_handle* h, int64_t maxlen);
+int glrm_run_cached(glrm_handle* h, int loss, double min_stepsize, const int32_t* seglist, int64_t nlist, hipStream_t st);
 // dense MFMA path (glrm_dense.hip)
 int glrm_setup_dense(glrm_handle* h, const glrm_problem* p);
 int glrm_run_dense(glrm_handle* h, bool rows, double min_stepsize, int eval_only);

@@ -56,8 +56,9 @@ struct SweepArgs {
   double min_stepsize;
   int32_t* trials;       // per local segment accumulators (nullable)
   int32_t* accepts;
-  const int32_t* seglist; // nullable: the launch covers segments seglist[0..nseg) instead of 0..nseg (skewed lengths: the few very
-                          // long segments get their own launch with 8 waves each)
+  const int32_t* seglist; // nullable: the launch covers the local segments seglist[0..nseg) instead of 0..nseg -- the segments of ONE
+                          // wave class when the shard holds several (glrm_handle::seglist_r) -- restricted to [seg_lo, seg_hi)
+  int64_t seg_lo, seg_hi; // (glrm_hip_step_x_range on such a shard; otherwise [0, local segments))
 };
 
 
@@ -255,7 +256,11 @@ __global__ void __launch_bounds__(WAVES == 1 ? 256 : WAVES * 64) sweep_kernel(co
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); // wave-uniform -> SGPR
   const int64_t slot = WAVES == 1 ? (int64_t)blockIdx.x * 4 + wave : (int64_t)blockIdx.x;
   if (slot >= a.nseg) return; // wave-uniform (WAVES==1) or block-uniform
-  const int64_t seg = a.seglist ? (int64_t)a.seglist[slot] : slot;
+  int64_t seg = slot;
+  if (a.seglist) {
+    seg = (int64_t)a.seglist[slot];
+    if (seg < a.seg_lo || seg >= a.seg_hi) return; // wave-uniform (WAVES==1) or block-uniform
+  }
   const int j = lane % G, gi = lane / G;
   const int gg = (WAVES == 1 ? 0 : wave * NG) + gi;
   const int64_t beg = a.ptr[seg], len = a.ptr[seg + 1] - beg;
@@ -420,6 +425,36 @@ __global__ void isum_kernel(const int32_t* v, int64_t n, unsigned long long* out
   if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
 }
 
+// Per-view statistics for glrm_signature and the class plan of the gather sweeps: out[0] = longest list, out[1..3] = segments per wave
+// class (forced_cls > 0 pins the class), out[4] = segments the cached sweep takes (len <= cache_maxlen; cache_maxlen < 0: none; they are
+// not counted in out[1..3]), out[5] = longest of those.
+__global__ void seg_stats_kernel(const int64_t* ptr, int64_t nseg, int forced_cls, int64_t cache_maxlen, unsigned long long* out) {
+  unsigned long long mx = 0, c1 = 0, c2 = 0, c3 = 0, cc = 0, mc = 0;
+  for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < nseg; s += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t len = ptr[s + 1] - ptr[s];
+    mx = (unsigned long long)len > mx ? (unsigned long long)len : mx;
+    if (cache_maxlen >= 0 && len <= cache_maxlen) {
+      ++cc;
+      mc = (unsigned long long)len > mc ? (unsigned long long)len : mc;
+    } else {
+      const int cls = forced_cls > 0 ? forced_cls : glrm_wave_class(len);
+      c1 += cls == 1; c2 += cls == 2; c3 += cls == 3;
+    }
+  }
+  for (int d = 32; d > 0; d >>= 1) {
+    const unsigned long long o0 = __shfl_xor(mx, d, 64), o5 = __shfl_xor(mc, d, 64);
+    mx = o0 > mx ? o0 : mx; mc = o5 > mc ? o5 : mc;
+    c1 += __shfl_xor(c1, d, 64); c2 += __shfl_xor(c2, d, 64); c3 += __shfl_xor(c3, d, 64); cc += __shfl_xor(cc, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out + 0, mx); atomicMax(out + 5, mc);
+    if (c1) atomicAdd(out + 1, c1);
+    if (c2) atomicAdd(out + 2, c2);
+    if (c3) atomicAdd(out + 3, c3);
+    if (cc) atomicAdd(out + 4, cc);
+  }
+}
+
 // =============================================================================== host side
 
 thread_local char g_err[768];
@@ -458,14 +493,6 @@ static int pick_layout(int k, int& G, int& R) {
   }
   R = kp / G;
   return 0;
-}
-
-static int pick_waves(int requested, int64_t nnz, int64_t nseg) {
-  if (requested == 1 || requested == 4 || requested == 8) return requested;
-  const double avg = nseg > 0 ? (double)nnz / (double)nseg : 0.0;
-  if (avg < 1536) return 1;
-  if (avg < 98304) return 4;
-  return 8;
 }
 
 template <typename T>
@@ -570,28 +597,71 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
   delete h;
 }
 
-// Skewed lengths (a few very popular columns / very active rows): segments longer than max(2048, 4 x mean) are listed apart and
-// swept by an 8-wave launch of their own on a side stream, concurrently with the launch of the short ones; with one launch for all, the waves-per-segment choice follows the mean and the longest
-// segment becomes the tail of the sweep.  The split changes which kernel instance runs a segment, hence its summation grouping,
-// but it is a function of the segment lengths alone.
-static int split_long_segments(glrm_handle* h, bool rows) {
-  const int64_t nseg = rows ? h->ml : h->nl, nnz = rows ? h->nnz_r : h->nnz_c;
-  if (nseg < 8 || nnz <= 0 || (rows ? h->waves_row : h->waves_col) == 8 || !env_int("GLRM_HIP_SPLIT_LONG", 1)) return GLRM_OK;
+static int view_stats(glrm_handle* h, bool rows, int forced_cls, int64_t cache_maxlen, unsigned long long (&st)[6]) {
+  for (auto& v : st) v = 0;
+  const int64_t nseg = rows ? h->ml : h->nl;
+  if (nseg <= 0) return GLRM_OK;
+  unsigned long long* d = nullptr;
+  HIPCK(hipMalloc((void**)&d, sizeof st));
+  hipError_t e = hipMemsetAsync(d, 0, sizeof st, h->stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(seg_stats_kernel, dim3(1024), dim3(256), 0, h->stream, rows ? h->rowptr : h->colptr, nseg, forced_cls, cache_maxlen, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(st, d, sizeof st, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(GLRM_ERR_HIP, "segment statistics failed: %s", hipGetErrorString(e));
+  return GLRM_OK;
+}
+
+static int forced_class(int waves_opt) { return waves_opt == 1 ? 1 : (waves_opt == 4 ? 2 : (waves_opt == 8 ? 3 : 0)); }
+
+// The class plan of a view that runs on the gather sweeps (and, for rows, the cached sweep): every segment is swept by the number of
+// waves its OWN length asks for (glrm_wave_class; glrm_options.waves_* pins one count), rows short enough for the cached sweep by that
+// one -- so a segment is summed in the same order whichever shard holds it.  One populated class: one launch over all local segments.
+// Several (skewed lengths: a few very popular columns / very active rows next to many short ones): seglist = the segments class by
+// class, one launch per class, the minority classes on a side stream beside the main launch.
+static int build_class_plan(glrm_handle* h, bool rows) {
+  int64_t* ncls = rows ? h->ncls_r : h->ncls_c;
+  const int64_t nseg = rows ? h->ml : h->nl;
+  const int forced = forced_class(rows ? h->opts.waves_row : h->opts.waves_col);
+  const bool cached = rows && h->cached_row != 0;
+  const int64_t cmax = cached ? glrm_cached_maxlen(h) : -1;
+  unsigned long long st[6];
+  int rc = view_stats(h, rows, forced, cmax, st);
+  if (rc) return rc;
+  ncls[0] = (int64_t)st[4]; ncls[1] = (int64_t)st[1]; ncls[2] = (int64_t)st[2]; ncls[3] = (int64_t)st[3];
+  if (cached) {
+    if (ncls[0] == 0) h->cached_row = 0; // this shard holds no row the cached sweep takes
+    else glrm_cached_set_cap(h, (int64_t)st[5]);
+  }
+  int best = 1, populated = 0;
+  for (int c = 0; c < 4; ++c) populated += ncls[c] > 0;
+  for (int c = 2; c < 4; ++c) if (ncls[c] > ncls[best]) best = c;
+  (rows ? h->waves_row : h->waves_col) = forced ? glrm_class_waves(forced) : glrm_class_waves(best);
+  if (populated > 1 && !env_int("GLRM_HIP_SPLIT_LONG", 1)) { // experiment switch: ONE launch on the majority wave class (not shard-invariant)
+    const int64_t all = ncls[0] + ncls[1] + ncls[2] + ncls[3];
+    if (cached) h->cached_row = 0;
+    for (int c = 0; c < 4; ++c) ncls[c] = 0;
+    ncls[best] = all;
+    populated = 1;
+  }
+  if (populated <= 1) return GLRM_OK;
   std::vector<int64_t> ptr((size_t)nseg + 1);
   HIPCK(hipMemcpyAsync(ptr.data(), rows ? h->rowptr : h->colptr, ((size_t)nseg + 1) * 8, hipMemcpyDeviceToHost, h->stream));
   HIPCK(hipStreamSynchronize(h->stream));
-  const double mean = (double)nnz / (double)nseg;
-  const int64_t thr = (int64_t)std::max(2048.0, 4.0 * mean);
-  std::vector<int32_t> shorts, longs;
-  for (int64_t s = 0; s < nseg; ++s) (ptr[s + 1] - ptr[s] > thr ? longs : shorts).push_back((int32_t)s);
-  if (longs.empty() || (int64_t)longs.size() * 2 > nseg) return GLRM_OK;
-  std::stable_sort(longs.begin(), longs.end(), [&](int32_t x, int32_t y) { return ptr[x + 1] - ptr[x] > ptr[y + 1] - ptr[y]; }); // longest first
-  shorts.insert(shorts.end(), longs.begin(), longs.end());
+  std::vector<int32_t> lst((size_t)nseg);
+  int64_t pos[4] = {0, ncls[0], ncls[0] + ncls[1], ncls[0] + ncls[1] + ncls[2]};
+  for (int64_t s = 0; s < nseg; ++s) {
+    const int64_t len = ptr[s + 1] - ptr[s];
+    const int c = (cmax >= 0 && len <= cmax) ? 0 : (forced ? forced : glrm_wave_class(len));
+    lst[(size_t)pos[c]++] = (int32_t)s;
+  }
   int32_t** dst = rows ? &h->seglist_r : &h->seglist_c;
   HIPCK(hipMalloc((void**)dst, (size_t)nseg * 4));
-  HIPCK(hipMemcpyAsync(*dst, shorts.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, h->stream));
-  HIPCK(hipStreamSynchronize(h->stream));
-  (rows ? h->nlong_r : h->nlong_c) = (int64_t)longs.size();
+  HIPCK(hipMemcpyAsync(*dst, lst.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipStreamSynchronize(h->stream)); // lst is a local
   if (!h->side_stream) {
     HIPCK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     HIPCK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -661,19 +731,47 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   HIPCK(hipMemsetAsync(h->accepts_r, 0, ml1 * 4, st));
   HIPCK(hipMemsetAsync(h->trials_c, 0, nl1 * 4, st));
   HIPCK(hipMemsetAsync(h->accepts_c, 0, nl1 * 4, st));
-  h->waves_row = pick_waves(o ? o->waves_row : 0, h->nnz_r, h->ml);
-  h->waves_col = pick_waves(o ? o->waves_col : 0, h->nnz_c, h->nl);
-  if (!p->dense_A) {
-    if (!(o && o->waves_row) && (rc = split_long_segments(h, true))) return rc;
-    if (!(o && o->waves_col) && (rc = split_long_segments(h, false))) return rc;
-  }
   int rc2 = glrm_setup_multi(h, p);
   if (rc2) return rc2;
-  if (!h->multi) rc2 = p->dense_A ? glrm_setup_dense(h, p) : glrm_setup_tiled(h);
-  if (rc2) return rc2;
-  if (!h->multi && !p->dense_A && (rc2 = glrm_setup_cached(h))) return rc2;
-  if (!h->multi && !p->dense_A && (rc2 = glrm_setup_blocked(h))) return rc2;
+  // this shard's contribution to the signature of the whole problem (include/glrm_hip.h: glrm_signature)
+  h->sig_local = glrm_signature{};
+  if (p->dense_A) {
+    h->sig_local.nnz_rows = h->ml * h->n; h->sig_local.nnz_cols = h->nl * h->m;
+    h->sig_local.max_row_len = h->ml > 0 ? h->n : 0; h->sig_local.max_col_len = h->nl > 0 ? h->m : 0;
+    if ((rc2 = glrm_setup_dense(h, p))) return rc2;
+  } else {
+    unsigned long long st6[6];
+    if ((rc = view_stats(h, true, 0, -1, st6))) return rc;
+    h->sig_local.max_row_len = (int64_t)st6[0];
+    if ((rc = view_stats(h, false, 0, -1, st6))) return rc;
+    h->sig_local.max_col_len = (int64_t)st6[0];
+    h->sig_local.nnz_rows = h->nnz_r; h->sig_local.nnz_cols = h->nnz_c;
+    if (!h->multi && (rc2 = glrm_prepare_tiled(h))) return rc2;
+  }
   HIPCK(hipStreamSynchronize(st)); // host descriptor / index arrays may be released by the caller now
+  return GLRM_OK;
+}
+
+// Second half of create: kernel families and their buffers, chosen from the signature of the WHOLE problem.
+static int finalize_impl(glrm_handle* h, const glrm_signature* whole) {
+  h->sig = whole ? *whole : h->sig_local;
+  if (h->sig.nnz_rows < h->sig_local.nnz_rows || h->sig.nnz_cols < h->sig_local.nnz_cols || h->sig.max_row_len < h->sig_local.max_row_len ||
+      h->sig.max_col_len < h->sig_local.max_col_len || h->sig.rows_unordered < h->sig_local.rows_unordered ||
+      h->sig.cols_unordered < h->sig_local.cols_unordered)
+    return fail(GLRM_ERR_INVALID, "the signature of the whole problem cannot be smaller than this shard's (sum the counts, max the rest)");
+  int rc;
+  if (!h->multi && !h->dense) {
+    if ((rc = glrm_setup_tiled(h))) return rc;
+    if ((rc = glrm_setup_cached(h))) return rc;
+    if ((rc = glrm_setup_blocked(h))) return rc;
+    if (!h->tiled_row && !h->blocked_row && (rc = build_class_plan(h, true))) return rc;
+    if (!h->tiled_col && !h->blocked_col && (rc = build_class_plan(h, false))) return rc;
+  } else {
+    h->waves_row = h->opts.waves_row ? h->opts.waves_row : 1;
+    h->waves_col = h->opts.waves_col ? h->opts.waves_col : 4;
+  }
+  HIPCK(hipStreamSynchronize(h->stream));
+  h->finalized = true;
   return GLRM_OK;
 }
 
@@ -711,6 +809,7 @@ extern "C" int glrm_hip_create(glrm_handle** out, const glrm_problem* p, const g
   if (!h) return fail(GLRM_ERR_OOM, "out of host memory");
   h->device = dev;
   rc = create_impl(h, p, o);
+  if (!rc && !(p->flags & GLRM_PROBLEM_DEFER_SETUP)) rc = finalize_impl(h, nullptr);
   if (rc) {
     char keep[sizeof g_err];
     memcpy(keep, g_err, sizeof keep);
@@ -721,6 +820,22 @@ extern "C" int glrm_hip_create(glrm_handle** out, const glrm_problem* p, const g
   *out = h;
   return GLRM_OK;
 }
+
+extern "C" int glrm_hip_signature(glrm_handle* h, glrm_signature* local) {
+  if (!h || !local) return fail(GLRM_ERR_INVALID, "NULL argument");
+  *local = h->sig_local;
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_finalize(glrm_handle* h, const glrm_signature* whole) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (h->finalized) return fail(GLRM_ERR_INVALID, "the handle is already set up (glrm_hip_finalize follows a GLRM_PROBLEM_DEFER_SETUP create, once)");
+  DeviceGuard dg(h->device);
+  return finalize_impl(h, whole);
+}
+
+#define GLRM_NEED_FINALIZED(h) \
+  do { if (!(h)->finalized) return fail(GLRM_ERR_INVALID, "the handle was created with GLRM_PROBLEM_DEFER_SETUP: call glrm_hip_finalize first"); } while (0)
 
 // ------------------------------------------------------------------ buffers and factors
 
@@ -909,6 +1024,7 @@ struct RoctxRange {
 // which: 0 = row sweep (X half-step), 1 = column sweep (Y half-step)
 static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_only) {
   RoctxRange range(eval_only ? "glrm col_losses" : (which == 0 ? "glrm step_x" : "glrm step_y"));
+  GLRM_NEED_FINALIZED(h);
   int rc = ensure_owned(h);
   if (rc) return rc;
   SweepArgs a{};
@@ -932,14 +1048,21 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
   a.min_stepsize = min_stepsize;
   a.trials = eval_only ? nullptr : (rows ? h->trials_r : h->trials_c);
   a.accepts = rows ? h->accepts_r : h->accepts_c;
+  a.seg_lo = 0;
+  a.seg_hi = a.nseg;
   if (rows && h->rng_e >= 0) { // glrm_hip_step_x_range: local rows [rng_b, rng_e)
     const int64_t s0 = h->rng_b;
-    a.nseg = h->rng_e - s0;
-    if (a.nseg <= 0) return GLRM_OK;
-    a.ptr += s0; a.alpha += s0; a.own_offset += s0;
-    if (!a.reg_single) a.regs += s0;
-    if (a.trials) a.trials += s0;
-    a.accepts += s0;
+    if (h->rng_e - s0 <= 0) return GLRM_OK;
+    if (h->seglist_r) { // several classes: the class launches filter their lists by the range
+      a.seg_lo = s0; a.seg_hi = h->rng_e;
+    } else {
+      a.nseg = h->rng_e - s0;
+      a.seg_hi = a.nseg;
+      a.ptr += s0; a.alpha += s0; a.own_offset += s0;
+      if (!a.reg_single) a.regs += s0;
+      if (a.trials) a.trials += s0;
+      a.accepts += s0;
+    }
   }
   int loss;
   if (h->loss_quad_uniform) { loss = LOSS_QUAD_UNIFORM; a.loss_by_segment = 0; }
@@ -965,28 +1088,43 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
   } else if (tiled) {
     rc = glrm_run_tiled(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
     if (rc) return rc;
-  } else if (rows && h->cached_row && !eval_only) {
-    rc = glrm_run_cached(h, loss, min_stepsize);
-    if (rc) return rc;
   } else if (rows ? (h->blocked_row && !eval_only) : h->blocked_col) {
     rc = glrm_run_blocked(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
     if (rc) return rc;
   } else {
+    // gather sweeps (and the cached row sweep), class by class -- see build_class_plan
+    const int64_t* ncls = rows ? h->ncls_r : h->ncls_c;
     const int32_t* lst = rows ? h->seglist_r : h->seglist_c;
-    const int64_t nlong = rows ? h->nlong_r : h->nlong_c;
-    if (lst && !(rows && h->rng_e >= 0)) { // skewed lengths: short segments with the usual waves, the long ones with 8 waves each
-      const int64_t nall = a.nseg;
-      // fork: the few long segments (8 waves each) on the side stream, beside the short segments on the main stream; join
+    const int unroll = rows ? h->unroll_row : h->unroll_col;
+    if (!lst) { // one class holds every local segment
+      int cls = 1;
+      for (int c = 0; c < 4; ++c) if (ncls[c] > 0) cls = c;
+      if (cls == 0 && !eval_only) {
+        if ((rc = glrm_run_cached(h, loss, min_stepsize, nullptr, 0, h->stream))) return rc;
+      } else {
+        launch_sweep(h->G, h->R, cls == 0 ? 1 : glrm_class_waves(cls), loss, cls <= 1 ? unroll : 1, a, h->stream);
+      }
+    } else {
+      // fork: the minority classes on the side stream, beside the majority class on the main stream; join
+      int main_cls = 0;
+      for (int c = 1; c < 4; ++c) if (ncls[c] > ncls[main_cls]) main_cls = c;
       HIPCK(hipEventRecord(h->ev_fork, h->stream));
       HIPCK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
-      a.seglist = lst + (nall - nlong); a.nseg = nlong;
-      launch_sweep(h->G, h->R, 8, loss, 1, a, h->side_stream);
+      int64_t off = 0;
+      for (int c = 0; c < 4; off += ncls[c], ++c) {
+        if (ncls[c] <= 0) continue;
+        hipStream_t st = c == main_cls ? h->stream : h->side_stream;
+        if (c == 0 && !eval_only) {
+          if ((rc = glrm_run_cached(h, loss, min_stepsize, lst + off, ncls[0], st))) return rc;
+        } else {
+          SweepArgs b = a;
+          b.seglist = lst + off;
+          b.nseg = ncls[c];
+          launch_sweep(h->G, h->R, c == 0 ? 1 : glrm_class_waves(c), loss, c <= 1 ? unroll : 1, b, st);
+        }
+      }
       HIPCK(hipEventRecord(h->ev_join, h->side_stream));
-      a.seglist = lst; a.nseg = nall - nlong;
-      if (a.nseg > 0) launch_sweep(h->G, h->R, rows ? h->waves_row : h->waves_col, loss, rows ? h->unroll_row : h->unroll_col, a, h->stream);
       HIPCK(hipStreamWaitEvent(h->stream, h->ev_join, 0));
-    } else {
-      launch_sweep(h->G, h->R, rows ? h->waves_row : h->waves_col, loss, rows ? h->unroll_row : h->unroll_col, a, h->stream);
     }
   }
   HIPCK(hipGetLastError());

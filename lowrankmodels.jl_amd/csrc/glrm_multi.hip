@@ -36,17 +36,16 @@ int glrm_setup_multi(glrm_handle* h, const glrm_problem* p) {
 }
 
 // A column longer than one chunk (8192 observations; GLRM_HIP_MULTI_CHUNK overrides, 0 = never) is swept by several
-// workgroups.  The rule looks at single columns only and the chunk is a constant, so results do not depend on the sharding.
+// workgroups.  The chunk is a constant, so the grouping of a column's partial sums depends on its own list only.
 static int setup_split(glrm_handle* h) {
   if (h->mtrial || h->col_nsplit < 0) return GLRM_OK;
   const int64_t chunk = env_int("GLRM_HIP_MULTI_CHUNK", 8192);
-  std::vector<int64_t> cp((size_t)h->nl + 1);
-  HIPCK(hipMemcpy(cp.data(), h->colptr, ((size_t)h->nl + 1) * 8, hipMemcpyDeviceToHost));
-  int64_t longest = 0;
-  for (int64_t f = 0; f < h->nl; ++f) longest = cp[f + 1] - cp[f] > longest ? cp[f + 1] - cp[f] : longest;
+  // split or not is decided from the longest column of the WHOLE problem (glrm_signature) and the global column count, so that every
+  // shard of a sharded fit runs the same kernels
+  const int64_t longest = h->sig.max_col_len;
   const size_t blk = (size_t)h->dmax * h->kp;
   const int64_t nsplit = chunk > 0 ? (longest + chunk - 1) / chunk : 1;
-  if (nsplit <= 1 || nsplit > 65535 || (size_t)h->nl * nsplit * blk * 8 > ((size_t)2 << 30)) { h->col_nsplit = -1; return GLRM_OK; }
+  if (nsplit <= 1 || nsplit > 65535 || (size_t)h->n * nsplit * blk * 8 > ((size_t)2 << 30)) { h->col_nsplit = -1; return GLRM_OK; }
   h->col_chunk = chunk;
   h->col_nsplit = (int)nsplit;
   HIPCK(hipMalloc((void**)&h->mtrial, (size_t)h->d * h->kp * 8));

@@ -393,9 +393,19 @@ static int multi_create_impl(glrm_multi* mh, const glrm_problem* p, const glrm_o
     oo.device_id = mh->dev[s];
     oo.stream = (void*)mh->st[s];
     oo.caller_stream = 1;
+    q.flags |= GLRM_PROBLEM_DEFER_SETUP; // the kernel families are chosen below, from the signature of the WHOLE problem
     return glrm_hip_create(&mh->sh[s], &q, &oo);
   });
   if (rc) return rc;
+  glrm_signature whole{};
+  for (int s = 0; s < n; ++s) {
+    glrm_signature l{};
+    if ((rc = glrm_hip_signature(mh->sh[s], &l))) return rc;
+    whole.nnz_rows += l.nnz_rows; whole.nnz_cols += l.nnz_cols;
+    whole.max_row_len = std::max(whole.max_row_len, l.max_row_len); whole.max_col_len = std::max(whole.max_col_len, l.max_col_len);
+    whole.rows_unordered = std::max(whole.rows_unordered, l.rows_unordered); whole.cols_unordered = std::max(whole.cols_unordered, l.cols_unordered);
+  }
+  if ((rc = run_all(mh, [&](int s) -> int { return glrm_hip_finalize(mh->sh[s], &whole); }))) return rc;
   mh->ld = glrm_hip_factor_ld(mh->sh[0]);
   for (int s = 0; s < n; ++s) {
     HIPCK(hipSetDevice(mh->dev[s]));

@@ -64,9 +64,9 @@ static int make_segperm(glrm_handle* h, bool rows, int32_t** out) {
   return GLRM_OK;
 }
 
-int glrm_setup_tiled(glrm_handle* h) {
+// create phase: the tile configuration and whether this shard's lists are in tile order (glrm_signature::rows_unordered / cols_unordered)
+int glrm_prepare_tiled(glrm_handle* h) {
   hipStream_t st = h->stream;
-  int rc0 = GLRM_OK;
   h->tile_cfg = env_int("GLRM_HIP_TILE_CFG", 1);
   h->tile_cfg12 = h->tile_cfg == 2; // experiment: 12-wave heterogeneous row sweep
   // Loader waves of the double-buffered tiled sweeps (0 = single tile, everybody stages; glrm_tiled.hpp).  Default: two loader waves on
@@ -82,6 +82,7 @@ int glrm_setup_tiled(glrm_handle* h) {
   // order granularity of the index lists: the entries of staged tile t must precede those of tile t+1; with loader waves the
   // staged unit is HALF a tile (a list ordered by half tile is ordered by tile as well)
   const int T0 = h->tile_lw > 0 ? tile_rows(h->kp, h->tile_cfg) / 2 : tile_rows(h->kp, h->tile_cfg);
+  h->order_unit = T0;
   HIPCK(hipMalloc((void**)&h->dflag, 2 * sizeof(int)));
   HIPCK(hipMemsetAsync(h->dflag, 0, 2 * sizeof(int), st));
   if (h->ml > 0) hipLaunchKernelGGL(check_sorted_kernel, dim3((unsigned)h->ml), dim3(64), 0, st, h->rowptr, h->colidx, h->ml, T0, h->dflag);
@@ -90,14 +91,25 @@ int glrm_setup_tiled(glrm_handle* h) {
   int flags[2] = {0, 0};
   HIPCK(hipMemcpyAsync(flags, h->dflag, sizeof flags, hipMemcpyDeviceToHost, st));
   HIPCK(hipStreamSynchronize(st));
-  h->rows_sorted = flags[0] == 0;
-  h->cols_sorted = flags[1] == 0;
+  h->sig_local.rows_unordered = flags[0] != 0;
+  h->sig_local.cols_unordered = flags[1] != 0;
+  return GLRM_OK;
+}
+
+// finalize phase.  Everything that selects a family is read from h->sig -- the signature of the WHOLE problem -- and from (m, n, k,
+// options): every shard of a sharded fit lands on the same family.
+int glrm_setup_tiled(glrm_handle* h) {
+  hipStream_t st = h->stream;
+  int rc0 = GLRM_OK;
+  const int T0 = h->order_unit;
+  h->rows_sorted = !h->sig.rows_unordered;
+  h->cols_sorted = !h->sig.cols_unordered;
 
   const int T = tile_rows(h->kp, h->tile_cfg);
   // expected observations of one segment inside one tile; the tiled sweeps pay off when a staged
   // vector is reused by several of the workgroup's segments
-  const double per_tile_r = h->ml > 0 ? (double)h->nnz_r / (double)h->ml * T / (double)h->n : 0.0;
-  const double per_tile_c = h->nl > 0 ? (double)h->nnz_c / (double)h->nl * T / (double)h->m : 0.0;
+  const double per_tile_r = (double)h->sig.nnz_rows / (double)h->m * T / (double)h->n;
+  const double per_tile_c = (double)h->sig.nnz_cols / (double)h->n * T / (double)h->m;
   // h->tiled_opt (glrm_options.tiled): 0 auto, 1 gather sweeps only, 2 tiled wherever the index lists are sorted.
   // GLRM_HIP_TILED (tuning): bit0 rows, bit1 columns; overrides the option.
   int want = h->tiled_opt == 1 ? 0 : (h->tiled_opt == 2 ? 3 : -1);
@@ -106,8 +118,8 @@ int glrm_setup_tiled(glrm_handle* h) {
   // enough observations to amortise their per-tile barriers; below ~2e7 observations per view the gather sweeps win (100k x 5k
   // at 1e7 observations: 1.06 vs 1.23 ms per iteration; 300k x 3k at 4.5e7: 4.6 vs 3.1 ms).
   const int spb_auto = ((h->tile_cfg ? 16 : 8) - h->tile_lw) * (64 / h->tG);
-  const bool big_r = h->nnz_r >= 20000000 && h->ml >= (int64_t)512 * spb_auto;
-  const bool big_c = h->nnz_c >= 20000000 && h->nl >= 256;
+  const bool big_r = h->sig.nnz_rows >= 20000000 && h->m >= (int64_t)512 * spb_auto;
+  const bool big_c = h->sig.nnz_cols >= 20000000 && h->n >= 256;
   bool want_row = want < 0 ? (per_tile_r >= 4.0 && big_r) : (want & 1) != 0;
   bool want_col = want < 0 ? (per_tile_c >= 4.0 && big_c) : ((want >> 1) & 1) != 0;
   // Lists in arbitrary order (obs tuples pushed in sampling order): the engine's private copy is brought into tile order by a
@@ -115,13 +127,22 @@ int glrm_setup_tiled(glrm_handle* h) {
   // explicit tiled = 2 keeps its meaning "wherever the lists allow" (GLRM_HIP_TILE_SORT=0 disables, =2 sorts for tiled = 2 as well).
   const int tsort = env_int("GLRM_HIP_TILE_SORT", 1);
   const bool may_sort = tsort == 2 || (tsort == 1 && want < 0);
-  if (want_row && !h->rows_sorted && may_sort) {
-    const int rc = glrm_tile_sort_view(st, h->rowptr, h->ml, h->nnz_r, T0, h->n, &h->colidx, &h->rowvals);
-    if (rc == GLRM_OK) h->rows_sorted = true; else if (rc != GLRM_ERR_UNSUPPORTED) return rc;
+  // (a shard whose own lists are already in tile order gets them back unchanged -- the sort is stable -- so the decision may be
+  // taken for the whole problem; a list too long for the segmented sort anywhere keeps every shard on the gather sweeps)
+  const int64_t sort_limit = env_int("GLRM_HIP_TILE_SORT_BATCH", 0) > 0 ? env_int("GLRM_HIP_TILE_SORT_BATCH", 0) : 1500000000ll;
+  if (want_row && !h->rows_sorted && may_sort && h->sig.max_row_len <= sort_limit) {
+    if (h->sig_local.rows_unordered) {
+      const int rc = glrm_tile_sort_view(st, h->rowptr, h->ml, h->nnz_r, T0, h->n, &h->colidx, &h->rowvals);
+      if (rc) return rc;
+    }
+    h->rows_sorted = true;
   }
-  if (want_col && !h->cols_sorted && may_sort) {
-    const int rc = glrm_tile_sort_view(st, h->colptr, h->nl, h->nnz_c, T0, h->m, &h->rowidx, &h->colvals);
-    if (rc == GLRM_OK) h->cols_sorted = true; else if (rc != GLRM_ERR_UNSUPPORTED) return rc;
+  if (want_col && !h->cols_sorted && may_sort && h->sig.max_col_len <= sort_limit) {
+    if (h->sig_local.cols_unordered) {
+      const int rc = glrm_tile_sort_view(st, h->colptr, h->nl, h->nnz_c, T0, h->m, &h->rowidx, &h->colvals);
+      if (rc) return rc;
+    }
+    h->cols_sorted = true;
   }
   h->tiled_row = (h->rows_sorted && want_row) ? 1 : 0;
   h->tiled_col = (h->cols_sorted && want_col) ? 1 : 0;

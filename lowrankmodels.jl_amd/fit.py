@@ -220,7 +220,15 @@ class ShardedFit:
         o = dict(opts or {})
         if self.device.type == "cuda":
             o["device_id"] = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        self.h = api.create(prob, stream=stream, **o)
+        # One shard of a sharded fit: upload only, then choose the kernel families from the signature of the WHOLE problem (the
+        # families add in different orders; every rank must land on the same one -- include/glrm_hip.h, glrm_signature).  The
+        # all-gather below is set-up traffic (six integers per rank), not a data-path collective.
+        self.h = api.create(prob, stream=stream, defer=self.world > 1, **o)
+        if self.world > 1:
+            mine = api.signature(self.h).astuple()
+            parts = [None] * self.world
+            dist.all_gather_object(parts, mine, group=group)
+            api.finalize(self.h, _capi.CSignature.combine(parts))
         self.ld = api.factor_ld(self.h)
         z = lambda cnt: torch.zeros(cnt, dtype=torch.float64, device=self.device)
         self.dX, self.dY, self.dObjCol, self.dObjRow = z(self.m * self.ld), z(self.d * self.ld), z(self.n), z(self.m)

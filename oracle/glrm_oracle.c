@@ -479,6 +479,40 @@ int glrm_cpu_create(glrm_cpu_handle** out, const glrm_problem* p, const glrm_opt
   return GLRM_OK;
 }
 
+/* The twins of glrm_hip_signature / glrm_hip_finalize (include/glrm_hip.h).  The oracle has ONE code path per half-step -- the
+ * reference's -- so there is nothing to choose from the signature of the whole problem; the entry points exist so that the hosts'
+ * sharded set-up (create with GLRM_PROBLEM_DEFER_SETUP, combine, finalize) runs unchanged on the checker.  Tile order is an engine
+ * notion: the oracle reports "not ascending" for the *_unordered fields. */
+int glrm_cpu_signature(glrm_cpu_handle* h, glrm_signature* local) {
+  if (!h || !local) return fail(GLRM_ERR_INVALID, "NULL argument");
+  memset(local, 0, sizeof *local);
+  const int64_t ml = h->row_end - h->row_begin, nl = h->col_end - h->col_begin;
+  local->nnz_rows = h->rowptr[ml];
+  local->nnz_cols = h->colptr[nl];
+  for (int64_t e = 0; e < ml; ++e) {
+    const int64_t len = h->rowptr[e + 1] - h->rowptr[e];
+    if (len > local->max_row_len) local->max_row_len = len;
+    for (int64_t t = h->rowptr[e] + 1; t < h->rowptr[e + 1]; ++t) if (h->colidx[t] < h->colidx[t - 1]) local->rows_unordered = 1;
+  }
+  for (int64_t f = 0; f < nl; ++f) {
+    const int64_t len = h->colptr[f + 1] - h->colptr[f];
+    if (len > local->max_col_len) local->max_col_len = len;
+    for (int64_t t = h->colptr[f] + 1; t < h->colptr[f + 1]; ++t) if (h->rowidx[t] < h->rowidx[t - 1]) local->cols_unordered = 1;
+  }
+  return GLRM_OK;
+}
+
+int glrm_cpu_finalize(glrm_cpu_handle* h, const glrm_signature* whole) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (whole) {
+    glrm_signature l;
+    glrm_cpu_signature(h, &l);
+    if (whole->nnz_rows < l.nnz_rows || whole->nnz_cols < l.nnz_cols || whole->max_row_len < l.max_row_len || whole->max_col_len < l.max_col_len)
+      return fail(GLRM_ERR_INVALID, "the signature of the whole problem cannot be smaller than this shard's (sum the counts, max the rest)");
+  }
+  return GLRM_OK;
+}
+
 /* 1 = allocate XY = X'Y (m x n) and evaluate full rows / columns of it in every objective
  * call, exactly the reference's cost model (src/algorithms/proxgrad.jl:65-66,157,202;
  * src/evaluate_fit.jl:29,45).  The numbers produced are identical to the sparse mode. */

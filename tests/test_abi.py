@@ -28,7 +28,7 @@ def ensure_built():
 def test_hip_library_exports_every_declared_symbol():
     ensure_built()
     names = declared("glrm_hip.h", "glrm_hip_")
-    assert len(names) == len(_capi.ABI_SYMBOLS) == 33
+    assert len(names) == len(_capi.ABI_SYMBOLS) == 35
     assert sorted("glrm_hip_" + s for s in _capi.ABI_SYMBOLS) == names
     lib = ctypes.CDLL(os.path.join(PKG, "libglrm_hip.so"))
     for n in names:
@@ -58,6 +58,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_capi.CParams) == 56 and ctypes.sizeof(_capi.COptions) == 40
     assert ctypes.sizeof(_capi.CProblem) == 8 * 2 + 4 * 2 + 8 * 4 + 8 * 6 + 8 * 6 + 8 * 2 + 4 * 2
     assert ctypes.sizeof(_capi.CKernelStats) == 8 * 2 + 8 * 2 + 8 * 6 + 4 * 4
+    assert ctypes.sizeof(_capi.CSignature) == 40 and ctypes.sizeof(_capi.CMultiOptions) == 24
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
