@@ -292,6 +292,102 @@ def pmc_traffic(args, kernel_re, per_halfstep=False, child_env=None):
                            f"WRITE_SIZE ({out['WRITE_SIZE'][0]:.4g} KiB), {'total of' if per_halfstep else 'mean over'} {out['FETCH_SIZE'][1]} dispatches matching /{kernel_re}/{' divided by the half-steps of the child run' if per_halfstep else ''}")
 
 
+# ----------------------------------------------------------------------------- one rank's shard geometry on one GPU
+
+# xGMI on an 8-GPU MI355X node (MI355X_MICROARCH.md): every GPU has 7 links, one per peer, ~153 GB/s each and direction.
+XGMI_LINK_GBS = 153.0
+
+
+def exchange_model_ms(block_bytes, n):
+    """Time for every rank to publish its block to its n - 1 peers.  direct: the owner pushes the block over all its links at once (one
+    link per peer carries one block).  ring: the block travels n - 1 hops, one link pair busy per step (what a ring all-gather does)."""
+    if n <= 1:
+        return {"direct": 0.0, "ring": 0.0}
+    one = block_bytes / (XGMI_LINK_GBS * 1e9) * 1e3
+    return {"direct": one, "ring": one * (n - 1)}
+
+
+def emulate_rank(args):
+    """No multi-GPU node is needed to know what ONE rank of the sharded fit computes per half-step: this builds rank r's shard of the
+    N-way problem (strong scaling: m/N rows and n/N columns of the full problem, X and Y fully replicated, the kernel families chosen
+    from the signature of the WHOLE problem exactly as the N-rank job would) on one GPU and times step_x / step_y with HIP events.
+    What it cannot measure is the exchange: that is modelled (exchange_model_ms) and printed beside the measurement.  The other
+    ranks' blocks of X and Y are never updated here, so the objective is not the job's -- only the kernels' work is."""
+    import torch
+    from lowrankmodels.jl_amd import _capi, synth
+    from lowrankmodels.jl_amd.fit import ShardedFit
+    N, r = args.of, args.emulate_rank
+    if N < 1 or not 0 <= r < N:
+        raise SystemExit("--emulate-rank r needs --of N with 0 <= r < N")
+    if args.config == "C3":
+        raise SystemExit("--emulate-rank covers the list configs (C2, C4, C5)")
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    cfg = dict(CONFIGS[args.config])
+    if args.cols or args.obs_per_row or args.k:
+        cfg.update(cols=args.cols or cfg["cols"], q=args.obs_per_row or cfg["q"], k=args.k or cfg["k"])
+    k, q, n, reg = cfg["k"], cfg["q"], cfg["cols"], cfg["reg"]
+    m = args.rows or cfg["rows"]
+    if m % N or n % N or n % q:
+        raise SystemExit("rows and cols must be divisible by the number of shards, cols by the observations per row")
+    rbs = [m // N * i for i in range(N + 1)]
+    cbs = [n // N * i for i in range(N + 1)]
+    api = _capi.hip_api()
+    w = synth.DeviceWorkload(m, n, k, q, rows=(rbs[r], rbs[r + 1]), cols=(cbs[r], cbs[r + 1]), seed=args.seed,
+                             value_model=cfg["value_model"], loss_mix=cfg["loss_mix"], rx=reg, ry=reg, device=device)
+    whole = w.whole_signature()
+    sf = ShardedFit(api, w.problem(), rbs, cbs, device=device, stream=torch.cuda.current_stream().cuda_stream,
+                    opts=dict(profile=1, waves_row=args.waves_row, waves_col=args.waves_col, tiled=args.tiled), x_chunks=1,
+                    whole_signature=whole)
+    nnz_r, nnz_c = w.nnz_rows, w.nnz_cols
+    w.free_sources()
+    X0, Y0 = w.init_factors(sf.ld)
+    if nonneg_start(cfg):
+        X0.abs_().mul_(1.0 / k ** 0.5); Y0.abs_().mul_(1.0 / k ** 0.5)
+    sf.dX.copy_(X0); sf.dY.copy_(Y0)
+    del X0, Y0
+    api.reset_stepsizes(sf.h, 1.0)
+
+    class P:
+        stepsize, inner_iter_X, inner_iter_Y, min_stepsize = 1.0, 1, 1, 0.01
+
+    for _ in range(args.warmup):
+        sf.iteration(P)
+    api.kernel_stats(sf.h, reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sf.iteration(P)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / args.steps * 1e3
+    st = api.kernel_stats(sf.h)
+    sf.close()
+    ms_x, ms_y = st["ms_x"] / args.steps, st["ms_y"] / args.steps
+    flags, ld = st["tiled"], st["ld"]
+    fam_r = "tiled" if flags & 1 else "cached" if flags & 64 else "blocked" if flags & 16 else "gather"
+    fam_c = "tiled" if flags & 2 else "blocked" if flags & 32 else "gather"
+    ex_x = exchange_model_ms((m // N) * ld * 8, N)
+    ex_y = exchange_model_ms((n // N) * ld * 8 + (n // N) * 8, N)
+    bytes_x = nnz_r * (12 + 8 * k) * (1 if fam_r == "cached" else 2)
+    bytes_y = nnz_c * (12 + 8 * k) * 2
+    out = {"mode": "emulate-rank", "rank": r, "of": N, "config": args.config, "m": m, "n": n, "k": k, "shard_rows": m // N, "shard_cols": n // N,
+           "shard_observations": {"rows": nnz_r, "cols": nnz_c}, "steps": args.steps, "warmup": args.warmup,
+           "measured_ms": {"step_x": ms_x, "step_y": ms_y, "iteration_wall_incl_host": wall},
+           "families": {"row_sweep": fam_r, "col_sweep": fam_c, "flags": flags, "waves_row": st["waves_row"], "waves_col": st["waves_col"]},
+           "mean_trials": {"per_row": st["trials_x"] / max(args.steps * (m // N), 1), "per_col": st["trials_y"] / max(args.steps * (n // N), 1)},
+           "algorithmic_GBps": {"step_x": bytes_x / (ms_x * 1e-3) / 1e9 if ms_x > 0 else None, "step_y": bytes_y / (ms_y * 1e-3) / 1e9 if ms_y > 0 else None,
+                                "passes_priced": {"step_x": 1 if fam_r == "cached" else 2, "step_y": 2}},
+           "exchange_model_ms": {"X_block": ex_x, "Y_block_and_objectives": ex_y, "link_GBps": XGMI_LINK_GBS,
+                                 "note": "MODELLED, not measured: no multi-GPU node was available; direct = the owner pushes its block over its 7 "
+                                         "links at once, ring = n - 1 hops over one link pair"},
+           "predicted_iteration_ms": {"direct_no_overlap": ms_x + ms_y + ex_x["direct"] + ex_y["direct"],
+                                      "ring_no_overlap": ms_x + ms_y + ex_x["ring"] + ex_y["ring"]},
+           "predicted_updates_per_s_all_ranks": {"direct_no_overlap": 2.0 * m * q / ((ms_x + ms_y + ex_x["direct"] + ex_y["direct"]) * 1e-3),
+                                                 "ring_no_overlap": 2.0 * m * q / ((ms_x + ms_y + ex_x["ring"] + ex_y["ring"]) * 1e-3)},
+           "whole_signature": dict(zip(("nnz_rows", "nnz_cols", "max_row_len", "max_col_len", "rows_unordered", "cols_unordered"), whole.astuple()))}
+    print(json.dumps(out), flush=True)
+
+
 # ----------------------------------------------------------------------------- main
 
 def main():
@@ -318,7 +414,12 @@ def main():
     ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"], help="HBM traffic of the dominant kernel from rocprofv3 PMC child passes")
     ap.add_argument("--pmc-timeout", type=int, default=240)
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000)
+    ap.add_argument("--emulate-rank", type=int, default=-1, help="with --of N: ONE GPU runs rank r's shard of the N-way sharded problem "
+                    "(m/N rows, n/N columns, full replicas of X and Y, kernel families chosen from the whole problem) and times its half-steps")
+    ap.add_argument("--of", type=int, default=0, help="number of shards emulated by --emulate-rank")
     args = ap.parse_args()
+    if args.emulate_rank >= 0:
+        return emulate_rank(args)
 
     import torch
     import torch.distributed as dist

@@ -61,11 +61,23 @@ int glrm_setup_dense(glrm_handle* h, const glrm_problem* p) {
   const bool whole = h->rb == 0 && h->re == h->m && h->cb == 0 && h->ce == h->n;
   const int cm = p->dense_colmajor ? 1 : 0;
   const int64_t ld = p->dense_ld;
-  if (!on_dev) {
-    for (int64_t i = h->rb; i < h->re; ++i)
-      for (int64_t j = 0; j < h->n; ++j)
-        if (std::isnan(p->dense_A[cm ? i + j * ld : i * ld + j]))
-          return fail(GLRM_ERR_NONFINITE, "Observed value in entry (%lld, %lld) is NaN.", (long long)i, (long long)j);
+  if (!on_dev) { // walk along the contiguous dimension of the caller's storage order (column-major: what the Julia shim passes)
+    bool bad = false;
+    int64_t bi = 0, bj = 0;
+    if (cm) {
+      for (int64_t j = 0; j < h->n && !bad; ++j) {
+        const double* col = p->dense_A + j * ld;
+        for (int64_t i = h->rb; i < h->re; ++i)
+          if (std::isnan(col[i])) { bad = true; bi = i; bj = j; break; }
+      }
+    } else {
+      for (int64_t i = h->rb; i < h->re && !bad; ++i) {
+        const double* row = p->dense_A + i * ld;
+        for (int64_t j = 0; j < h->n; ++j)
+          if (std::isnan(row[j])) { bad = true; bi = i; bj = j; break; }
+      }
+    }
+    if (bad) return fail(GLRM_ERR_NONFINITE, "Observed value in entry (%lld, %lld) is NaN.", (long long)bi, (long long)bj);
   }
   int rc = GLRM_OK;
   if (on_dev) {

@@ -203,7 +203,7 @@ class ShardedFit:
     gathered per-column values, so it does not depend on the number of ranks.
     """
 
-    def __init__(self, api, prob, row_bounds, col_bounds, group=None, device=None, stream=None, opts=None, x_chunks=1):
+    def __init__(self, api, prob, row_bounds, col_bounds, group=None, device=None, stream=None, opts=None, x_chunks=1, whole_signature=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist, self.api, self.group = torch, dist, api, group
@@ -223,8 +223,13 @@ class ShardedFit:
         # One shard of a sharded fit: upload only, then choose the kernel families from the signature of the WHOLE problem (the
         # families add in different orders; every rank must land on the same one -- include/glrm_hip.h, glrm_signature).  The
         # all-gather below is set-up traffic (six integers per rank), not a data-path collective.
-        self.h = api.create(prob, stream=stream, defer=self.world > 1, **o)
-        if self.world > 1:
+        # `whole_signature`: a caller that already knows the whole problem's signature (bench.py --emulate-rank: one process holding
+        # ONE shard of an N-shard problem) passes it instead.
+        sharded = self.world > 1 or whole_signature is not None
+        self.h = api.create(prob, stream=stream, defer=sharded, **o)
+        if whole_signature is not None:
+            api.finalize(self.h, whole_signature)
+        elif self.world > 1:
             mine = api.signature(self.h).astuple()
             parts = [None] * self.world
             dist.all_gather_object(parts, mine, group=group)

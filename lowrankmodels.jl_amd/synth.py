@@ -97,6 +97,20 @@ class DeviceWorkload:
         self.rx = np.array([rx], dtype=_capi.REG_DTYPE)
         self.ry = np.array([ry], dtype=_capi.REG_DTYPE)
 
+    def whole_signature(self) -> "_capi.CSignature":
+        """glrm_signature of the WHOLE m x n problem this shard was cut from, computed from the generator (every row holds exactly q
+        sorted observations; the column counts of all n columns are generated once more, counts only)."""
+        torch = self.torch
+        with torch.cuda.device(self.device):
+            counts = torch.zeros(self.n + 1, dtype=torch.int64, device=self.device)
+            _ck(synth_lib().glrm_synth_hip_col_counts(C.byref(self.spec), 0, self.n, counts.data_ptr(),
+                                                      torch.cuda.current_stream(self.device).cuda_stream))
+            longest = int(counts.max().item())
+        sig = _capi.CSignature()
+        sig.nnz_rows = sig.nnz_cols = self.m * self.q
+        sig.max_row_len, sig.max_col_len = self.q, longest
+        return sig
+
     def problem(self) -> _capi.ProblemArrays:
         p = lambda t: int(t.data_ptr())
         return _capi.ProblemArrays(self.m, self.n, self.k, p(self.rowptr), p(self.colidx), p(self.rowvals), p(self.colptr),

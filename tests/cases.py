@@ -280,3 +280,62 @@ def rel_err(a, b):
 def fro_err(a, b):
     nb = np.linalg.norm(b)
     return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / (nb if nb > 0 else 1.0))
+
+
+# ---------------------------------------------------------------------------------- sharded set-up (hosts' protocol)
+
+def shard_of(pa, rb, re, cb, ce):
+    """Rows [rb, re) and columns [cb, ce) of a whole-problem ProblemArrays as one shard (list problems, host arrays)."""
+    from lowrankmodels.jl_amd import _capi
+    r0, r1, c0, c1 = int(pa.rowptr[rb]), int(pa.rowptr[re]), int(pa.colptr[cb]), int(pa.colptr[ce])
+    rx = pa.rx if len(pa.rx) == 1 else np.ascontiguousarray(pa.rx[rb:re])
+    ry = pa.ry if len(pa.ry) == 1 else np.ascontiguousarray(pa.ry[cb:ce])
+    return _capi.ProblemArrays(pa.m, pa.n, pa.k, np.ascontiguousarray(pa.rowptr[rb:re + 1] - r0), np.ascontiguousarray(pa.colidx[r0:r1]),
+                               np.ascontiguousarray(pa.rowvals[r0:r1]), np.ascontiguousarray(pa.colptr[cb:ce + 1] - c0),
+                               np.ascontiguousarray(pa.rowidx[c0:c1]), np.ascontiguousarray(pa.colvals[c0:c1]),
+                               pa.losses, rx, ry, rb, re, cb, ce)
+
+
+def run_shards_on_one_device(api, pa, X0, Y0, params, row_bounds, col_bounds, x_chunks=1, **create_kw):
+    """What a sharding host does (include/glrm_hip.h, glrm_signature), with every shard on device 0 and the "exchange" being the
+    shared buffers: create each shard with GLRM_PROBLEM_DEFER_SETUP, combine the signatures, finalize, then step all shards through
+    the outer iterations.  Returns (objective[1:], X, Y, [kernel_stats per shard])."""
+    import torch
+    from lowrankmodels.jl_amd import _capi
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    ns = len(row_bounds) - 1
+    hs = [api.create(shard_of(pa, row_bounds[s], row_bounds[s + 1], col_bounds[s], col_bounds[s + 1]), stream=stream, defer=True, **create_kw)
+          for s in range(ns)]
+    try:
+        whole = _capi.CSignature.combine([api.signature(h) for h in hs])
+        for h in hs:
+            api.finalize(h, whole)
+        ld = api.factor_ld(hs[0])
+        d = pa.d
+        dX, dY = torch.zeros(pa.m * ld, dtype=torch.float64, device=dev), torch.zeros(d * ld, dtype=torch.float64, device=dev)
+        dC, dR = torch.zeros(pa.n, dtype=torch.float64, device=dev), torch.zeros(pa.m, dtype=torch.float64, device=dev)
+        for h in hs:
+            api.bind_buffers(h, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())
+        api.set_factors(hs[0], X0, Y0)
+        for h in hs:
+            api.reset_stepsizes(h, params.stepsize)
+        objs = []
+        for _ in range(params.max_iter):
+            for s, h in enumerate(hs):
+                ml = row_bounds[s + 1] - row_bounds[s]
+                if x_chunks > 1:
+                    for j in range(x_chunks):
+                        api.step_x_range(h, ml * j // x_chunks, ml * (j + 1) // x_chunks, params.min_stepsize)
+                else:
+                    api.step_x(h, params.min_stepsize)
+            for h in hs:
+                api.step_y(h, params.min_stepsize)
+            objs.append(api.sum(hs[0], dC.data_ptr(), pa.n))
+        X, Y = np.zeros_like(X0), np.zeros_like(Y0)
+        api.get_factors(hs[0], X, Y)
+        stats = [api.kernel_stats(h) for h in hs]
+    finally:
+        for h in hs:
+            api.destroy(h)
+    return np.array(objs), X, Y, stats

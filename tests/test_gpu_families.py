@@ -1,0 +1,237 @@
+"""-m gpu: oracle parity for exactly the kernel families the BASELINE north-star configuration (C4: 10M x 100k, rank 64, 100 sorted
+observations per row, NonNegConstraint) dispatches at full size -- the phase-aligned gather passes (csrc/glrm_blocked.hip,
+`tiled_col_pass_kernel<..., L2 = true>`) and the two-wave register-cached row sweep `regcached_sweep_kernel<8, 8, *, 7, 2>`
+(csrc/glrm_cached.hip) -- forced onto problems the oracle finishes in seconds, with super-tiles and launch slices shrunk so that
+several of each are exercised; and the shard-invariance of every kernel choice on ragged data (bit-identical
+for any number of shards).  Reference being restated: src/algorithms/proxgrad.jl:118-201, src/evaluate_fit.jl:24-55.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import lowrankmodels.jl_amd as L
+import oracle as O
+from lowrankmodels.jl_amd import _capi
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+BLOCKED_ROWS, BLOCKED_COLS, CACHED = 16, 32, 64
+
+
+def hip():
+    return _capi.hip_api()
+
+
+def force_blocked(monkeypatch, tps="1", fill="3"):
+    """Phase-aligned passes on both views; one LDS-tile unit per super-tile (many super-tiles: the partial sums per (segment, super-tile)
+    and their fixed-order reduction are exercised) and 3 % of the chip's residency per launch slice (many slices per pass)."""
+    monkeypatch.setenv("GLRM_HIP_BLOCKED", "3")
+    monkeypatch.setenv("GLRM_HIP_BLOCKED_TPS", tps)
+    monkeypatch.setenv("GLRM_HIP_BLOCKED_FILL", fill)
+    monkeypatch.setenv("GLRM_HIP_CACHED", "0")
+
+
+def against_oracle(pa, X0, Y0, params, want_flags, tol=TOL, **create_kw):
+    O.set_threads(4)
+    o_c, X_c, Y_c, st_c = cases.run_engine(O.oracle_api(), pa, X0, Y0, params)
+    o_g, X_g, Y_g, st_g = cases.run_engine(hip(), pa, X0, Y0, params, **create_kw)
+    assert st_g["tiled"] & want_flags == want_flags, (st_g["tiled"], want_flags)
+    assert len(o_g) == len(o_c)
+    e = (cases.rel_err(o_g, o_c), cases.fro_err(X_g, X_c), cases.fro_err(Y_g, Y_c))
+    assert max(e) < tol, e
+    for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
+        assert abs(st_g[key] - st_c[key]) <= max(5, 0.03 * st_c[key]), (key, st_g[key], st_c[key])
+    assert st_g["nnz_rows"] == st_c["nnz_rows"] and st_g["nnz_cols"] == st_c["nnz_cols"]
+    return e
+
+
+def c4_problem(m, n, q, k=64):
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, q, value_model=1)
+    one = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(3, 0, 1.0)], dtype=_capi.REG_DTYPE)  # NonNegConstraint, src/regularizers.jl:101-114
+    pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, one, reg, reg)
+    return pa, np.asfortranarray(np.abs(X0) / 8.0), np.asfortranarray(np.abs(Y0) / 8.0), X0, Y0
+
+
+# ------------------------------------------------------------------------------------------------ phase-aligned gather passes
+
+@pytest.mark.parametrize("start", ["nonneg", "randn"])
+def test_phase_aligned_passes_c4_recipe(monkeypatch, start):
+    """The C4 recipe at 20 000 x 2 000 on the family that runs the full-size Y half-step (and, with the cached sweep off, the X
+    half-step): 7 / 70 super-tiles per view, ~60 slices per pass.  `randn`: the reference default start, objective Inf, collapse to X = 0."""
+    force_blocked(monkeypatch)
+    pa, Xn, Yn, Xr, Yr = c4_problem(20000, 2000, 100)
+    X0, Y0 = (Xn, Yn) if start == "nonneg" else (Xr, Yr)
+    against_oracle(pa, X0, Y0, L.ProxGradParams(max_iter=12), BLOCKED_ROWS | BLOCKED_COLS, tiled=1)
+
+
+def test_phase_aligned_passes_c4_golden_fixture(monkeypatch):
+    force_blocked(monkeypatch)
+    pa, X0, Y0, params, z = cases.load_case(os.path.join(GOLDEN, "c4.npz"))
+    obj, X, Y, st = cases.run_engine(hip(), pa, X0, Y0, params, tiled=1)
+    assert st["tiled"] & (BLOCKED_ROWS | BLOCKED_COLS) == BLOCKED_ROWS | BLOCKED_COLS
+    assert len(obj) == len(z["objective"]) and cases.rel_err(obj, z["objective"]) < TOL
+    assert cases.fro_err(X, z["X"]) < TOL and cases.fro_err(Y, z["Y"]) < TOL
+
+
+@pytest.mark.parametrize("k", [32, 64])
+def test_phase_aligned_passes_mixed_losses_sorted_lists(monkeypatch, k):
+    """Quad / Logistic / OrdinalHinge columns (the C5 recipe), a loss descriptor per column: the per-observation and the per-segment
+    loss variants of the pass kernels, four- and eight-lane layouts."""
+    force_blocked(monkeypatch)
+    m, n, q = 2500, 2000, 100
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, q, value_model=0, loss_mix=1)
+    kinds = [L.QuadLoss().descriptor(), L.LogisticLoss().descriptor(), L.OrdinalHingeLoss(1, 5).descriptor()]
+    losses = np.array([kinds[f % 3] for f in range(n)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 1.0)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, losses, reg, reg)
+    against_oracle(pa, 0.3 * X0, 0.3 * Y0, L.ProxGradParams(max_iter=10), BLOCKED_ROWS | BLOCKED_COLS, tiled=1)
+    hub = np.array([L.HuberLoss(1.0, crossover=0.5).descriptor()], dtype=_capi.LOSS_DTYPE)   # one non-quadratic loss: the segment-uniform variant
+    pa2 = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, hub, reg, reg)
+    against_oracle(pa2, 0.3 * X0, 0.3 * Y0, L.ProxGradParams(max_iter=8), BLOCKED_ROWS | BLOCKED_COLS, tiled=1)
+
+
+def test_phase_aligned_passes_row_chunks_and_sparse_solver(monkeypatch):
+    """glrm_hip_step_x_range in chunks = one full sweep (bitwise), and fit!(::SparseProxGradParams) -- the fixed-step gradient passes
+    of the same family -- against the oracle."""
+    force_blocked(monkeypatch)
+    pa, X0, Y0, _, _ = c4_problem(6000, 1500, 100)
+    api = hip()
+    res = []
+    for chunks in (None, [(0, 1000), (1000, 1001), (1001, 4096), (4096, 6000)]):
+        h = api.create(pa, tiled=1)
+        assert api.kernel_stats(h)["tiled"] & (BLOCKED_ROWS | BLOCKED_COLS) == BLOCKED_ROWS | BLOCKED_COLS
+        api.set_factors(h, X0, Y0)
+        api.reset_stepsizes(h, 1.0)
+        for _ in range(3):
+            if chunks is None:
+                api.step_x(h, 0.01)
+            else:
+                for b, e in chunks:
+                    api.step_x_range(h, b, e, 0.01)
+            api.step_y(h, 0.01)
+        X, Y = np.zeros_like(X0), np.zeros_like(Y0)
+        api.get_factors(h, X, Y)
+        st = api.kernel_stats(h)
+        api.destroy(h)
+        res.append((X, Y, st["trials_x"], st["accepts_x"]))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]) and res[0][2:] == res[1][2:]
+    sp = L.SparseProxGradParams(max_iter=12)
+    outs = []
+    for a_ in (O.oracle_api(), api):
+        h = a_.create(pa, tiled=1) if a_ is api else a_.create(pa)
+        X, Y = np.array(X0, order="F"), np.array(Y0, order="F")
+        obj, _ = a_.fit_sparse(h, sp, X, Y)
+        a_.destroy(h)
+        outs.append((np.array(obj), X, Y))
+    assert len(outs[0][0]) == len(outs[1][0]) and cases.rel_err(outs[1][0], outs[0][0]) < TOL
+    assert cases.fro_err(outs[1][1], outs[0][1]) < TOL and cases.fro_err(outs[1][2], outs[0][2]) < TOL
+
+
+# ------------------------------------------------------------------------------------------------ register-cached row sweep, MAXT = 7
+
+def test_regcached_two_waves_seven_trips_at_full_c4_density(monkeypatch):
+    """3 000 x 100 000, rank 64, 100 observations per row: a row is 13 trips of the eight-lane layout, so the cached sweep runs as
+    regcached_sweep_kernel<8, 8, 0, 7, 2> -- the instantiation of the full-size C4 X half-step -- and is compared with the oracle."""
+    monkeypatch.setenv("GLRM_HIP_CACHED", "1")
+    pa, X0, Y0, _, _ = c4_problem(3000, 100000, 100)
+    h = hip().create(pa)
+    st = hip().kernel_stats(h)
+    hip().destroy(h)
+    assert st["tiled"] & CACHED and st["ld"] == 64 and not st["tiled"] & 3
+    against_oracle(pa, X0, Y0, L.ProxGradParams(max_iter=6), CACHED)
+
+
+# ------------------------------------------------------------------------------------------------ shard invariance on ragged data
+
+def ragged_problem(rng, m, n, k, q, long_rows=(), long_len=150, long_cols=(), nonneg=True):
+    """q sorted observations per row, except `long_rows` (long_len each) and `long_cols` (fully observed)."""
+    A = rng.random((m, n))
+    feats = []
+    for e in range(m):
+        cnt = long_len if e in long_rows else q
+        feats.append(np.sort(rng.choice(n, size=cnt, replace=False)))
+    mask = np.zeros((m, n), dtype=bool)
+    for e, f in enumerate(feats):
+        mask[e, f] = True
+    for c in long_cols:
+        mask[:, c] = True
+    I, J = np.nonzero(mask)
+    X0, Y0 = np.abs(rng.standard_normal((k, m))) / 8, np.abs(rng.standard_normal((k, n))) / 8
+    reg = L.NonNegConstraint() if nonneg else L.QuadReg(0.1)
+    g = L.GLRM(A, L.QuadLoss(), reg, reg, k, obs=(I, J), X=X0, Y=Y0)
+    return g.problem_arrays(), np.asfortranarray(X0), np.asfortranarray(Y0)
+
+
+@pytest.mark.parametrize("cached", ["1", "auto"])
+@pytest.mark.parametrize("x_chunks", [1, 3])
+def test_two_shards_equal_one_shard_with_heavy_tailed_rows(monkeypatch, cached, x_chunks):
+    """One 150-observation row among 100-observation rows at rank 64: the cached sweep holds rows of up to 104 observations in
+    registers (two waves per row), the long row runs the gather sweep -- decided per ROW, so the shard that holds the long row and the
+    shard that does not sum every row exactly like the single-shard fit.  Round 2 chose the family from the shard's longest row:
+    the two halves then ran different kernels."""
+    if cached == "1":
+        monkeypatch.setenv("GLRM_HIP_CACHED", "1")
+    rng = np.random.default_rng(2024)
+    m, n, k = 600, 400, 64
+    pa, X0, Y0 = ragged_problem(rng, m, n, k, 100, long_rows=(17,), long_len=150)
+    params = L.ProxGradParams(max_iter=6)
+    api = hip()
+    o1, X1, Y1, st1 = cases.run_engine(api, pa, X0, Y0, params, tiled=0)
+    if cached == "1":
+        assert st1["tiled"] & CACHED
+    for rb, cb in (([0, 300, m], [0, 200, n]), ([0, 10, 20, m], [0, 399, 399, n])):
+        o2, X2, Y2, sts = cases.run_shards_on_one_device(api, pa, X0, Y0, params, rb, cb, x_chunks=x_chunks, tiled=0)
+        assert all(s["tiled"] == st1["tiled"] for s in sts if s["nnz_rows"] > 0), ([s["tiled"] for s in sts], st1["tiled"])
+        assert np.array_equal(X1, X2) and np.array_equal(Y1, Y2) and np.array_equal(o1[1:], o2)
+    # and the whole thing against the oracle
+    against_oracle(pa, X0, Y0, params, st1["tiled"] & CACHED, tiled=0)
+
+
+def test_two_shards_equal_one_shard_with_skewed_segment_lengths():
+    """A few long columns and one long row (>= 1536 observations: four waves each) next to short ones (one wave): the wave count is a
+    function of the segment's own length, so a shard whose MEAN length differs from the whole problem's picks the same kernels.  Also
+    through glrm_hip_step_x_range (the pipelined hosts) and the in-library multi-shard fit on one device."""
+    rng = np.random.default_rng(7)
+    m, n, k = 5000, 1700, 16
+    pa, X0, Y0 = ragged_problem(rng, m, n, k, 20, long_rows=(4321,), long_len=1600, long_cols=(3, 900), nonneg=False)
+    params = L.ProxGradParams(max_iter=5)
+    api = hip()
+    o1, X1, Y1, st1 = cases.run_engine(api, pa, X0, Y0, params, tiled=1)
+    assert st1["waves_row"] == 1 and st1["waves_col"] == 1
+    for x_chunks in (1, 4):
+        o2, X2, Y2, sts = cases.run_shards_on_one_device(api, pa, X0, Y0, params, [0, 4000, m], [0, 10, n], x_chunks=x_chunks, tiled=1)
+        assert np.array_equal(X1, X2) and np.array_equal(Y1, Y2) and np.array_equal(o1[1:], o2)
+    mh = api.multi_create(pa, 3, device_ids=[0, 0, 0], tiled=1)
+    try:
+        X3, Y3 = np.array(X0, order="F"), np.array(Y0, order="F")
+        o3, _ = api.multi_fit(mh, params, X3, Y3)
+    finally:
+        api.multi_destroy(mh)
+    assert np.array_equal(X1, X3) and np.array_equal(Y1, Y3) and np.array_equal(o1[1:], o3[1:])
+    assert o3[0] == pytest.approx(o1[0], rel=1e-12)
+    against_oracle(pa, X0, Y0, params, 0, tiled=1)
+
+
+def test_deferred_handle_refuses_to_step_before_finalize():
+    rng = np.random.default_rng(3)
+    pa, X0, Y0 = ragged_problem(rng, 60, 40, 8, 10)
+    api = hip()
+    h = api.create(cases.shard_of(pa, 0, 30, 0, 20), defer=True)
+    try:
+        with pytest.raises(_capi.GLRMError) as ei:
+            api.step_x(h, 0.01)
+        assert ei.value.code == _capi.ERR_INVALID and "glrm_hip_finalize" in ei.value.message
+        small = _capi.CSignature()                       # smaller than the shard's own contribution: refused
+        with pytest.raises(_capi.GLRMError):
+            api.finalize(h, small)
+        api.finalize(h, api.signature(h))
+        with pytest.raises(_capi.GLRMError):
+            api.finalize(h, None)                        # twice
+        api.set_factors(h, X0, Y0)
+        api.step_x(h, 0.01)
+    finally:
+        api.destroy(h)

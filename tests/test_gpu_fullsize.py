@@ -160,3 +160,196 @@ def test_c2_full_size_three_iterations_against_the_oracle():
     rel = np.max(np.abs(obj_g - obj_c) / np.abs(obj_c))
     assert rel < 1e-5, (obj_g, obj_c)
     assert np.linalg.norm(Xg - Xc) / np.linalg.norm(Xc) < 1e-5 and np.linalg.norm(Yg - Yc) / np.linalg.norm(Yc) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[3] (C4, the north-star target) and configs[2] (C3, dense) at FULL size: the kernel families the auto choice picks
+# there are asserted, and one X half-step + one Y half-step are compared with the oracle on sampled rows / columns (the oracle runs
+# exactly those segments: same observations in the same order, same values, same opposing vectors).
+
+def _oracle_row_step(oapi, n, k, colidx, vals, x_row, Yh, loss, reg, p):
+    """One X half-step of a single row on the oracle: returns the new x (k)."""
+    pa = _capi.ProblemArrays(1, n, k, np.array([0, len(colidx)], dtype=np.int64), np.ascontiguousarray(colidx, dtype=np.int32),
+                             np.ascontiguousarray(vals, dtype=np.float64), np.zeros(n + 1, dtype=np.int64), np.zeros(0, np.int32), np.zeros(0), loss, reg, reg)
+    ho = oapi.create(pa)
+    oapi.set_factors(ho, np.asfortranarray(x_row.reshape(k, 1)), np.asfortranarray(Yh))
+    oapi.reset_stepsizes(ho, p.stepsize)
+    oapi.step_x(ho, p.min_stepsize)
+    xo, yo = np.zeros((k, 1), order="F"), np.zeros((k, n), order="F")
+    oapi.get_factors(ho, xo, yo)
+    oapi.destroy(ho)
+    return xo[:, 0]
+
+
+def _oracle_col_step(oapi, k, X_rows, vals, y_col, loss, reg, p):
+    """One Y half-step of a single column on the oracle, on the COMPACT problem that holds just the rows the column observes
+    (re-numbered 0..len-1 in list order: same sums in the same order).  Returns (new y (k), obj_by_col)."""
+    ln = X_rows.shape[0]
+    pa = _capi.ProblemArrays(ln, 1, k, np.zeros(ln + 1, dtype=np.int64), np.zeros(0, np.int32), np.zeros(0),
+                             np.array([0, ln], dtype=np.int64), np.arange(ln, dtype=np.int32), np.ascontiguousarray(vals, dtype=np.float64), loss, reg, reg)
+    ho = oapi.create(pa)
+    oc = np.zeros(1)
+    oapi.bind_buffers(ho, None, None, oc, None)
+    oapi.set_factors(ho, np.asfortranarray(X_rows.T), np.asfortranarray(y_col.reshape(k, 1)))
+    oapi.reset_stepsizes(ho, p.stepsize)
+    oapi.step_y(ho, p.min_stepsize)
+    xo, yo = np.zeros((k, ln), order="F"), np.zeros((k, 1), order="F")
+    oapi.get_factors(ho, xo, yo)
+    oapi.destroy(ho)
+    return yo[:, 0], oc[0]
+
+
+def test_c4_full_size_families_and_oracle_spot_check():
+    """BASELINE configs[3]: 10M x 100k, rank 64, QuadLoss, 1e9 observations, NonNegConstraint on X and Y, bench.py's start.  The auto
+    choice must put the X half-step on the cached gather sweep (regcached_sweep_kernel<8, 8, 0, 7, 2>) and the Y half-step on the
+    phase-aligned gather passes -- the kernels behind the bench line; their first half-steps are compared with the oracle on sampled
+    rows and columns (1e-9), the recorded objective with an independent re-evaluation, and two runs bit for bit."""
+    import gc
+    import torch
+    gc.collect(); torch.cuda.empty_cache()
+    m, n, k, q = 10_000_000, 100_000, 64, 100
+    api = _capi.hip_api()
+    nn = (3, 0, 1.0)
+    w = synth.DeviceWorkload(m, n, k, q, value_model=1, rx=nn, ry=nn)
+    assert w.nnz_rows == w.nnz_cols == m * q
+    h = api.create(w.problem(), stream=torch.cuda.current_stream().cuda_stream)
+    ld = api.factor_ld(h)
+    st = api.kernel_stats(h)
+    assert ld == 64 and st["tiled"] & 64 and st["tiled"] & 32 and not st["tiled"] & (1 | 2 | 4 | 8 | 16), st["tiled"]
+    dX, dY = w.init_factors(ld)
+    dX.abs_().mul_(1.0 / k ** 0.5); dY.abs_().mul_(1.0 / k ** 0.5)
+    dC, dR = torch.zeros(n, dtype=torch.float64, device=dX.device), torch.zeros(m, dtype=torch.float64, device=dX.device)
+    api.bind_buffers(h, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())
+    X_init, Y_init = dX.clone(), dY.clone()
+    p = L.ProxGradParams()
+    one = np.array([synth.QUAD], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([nn], dtype=_capi.REG_DTYPE)
+    oapi = O.oracle_api()
+    X2 = lambda t: t.view(m, ld)
+
+    # X half-step on sampled rows
+    rows = np.array([0, 1, 17, 4242, 5_000_000, m - 1])
+    rows_t = torch.as_tensor(rows, device=dX.device)
+    Yh = Y_init.cpu().numpy().reshape(n, ld)[:, :k].T
+    Xh_rows = X2(X_init)[rows_t].cpu().numpy()[:, :k]
+    rp = w.rowptr[torch.as_tensor(np.concatenate([rows, rows + 1]), device=dX.device)].cpu().numpy()
+    api.reset_stepsizes(h, p.stepsize)
+    api.step_x(h, p.min_stepsize)
+    X_after_rows = X2(dX)[rows_t].cpu().numpy()[:, :k]
+    for i, e in enumerate(rows):
+        b, e1 = int(rp[i]), int(rp[len(rows) + i])
+        ci, va = w.colidx[b:e1].cpu().numpy(), w.rowvals[b:e1].cpu().numpy()
+        assert len(ci) == q and np.all(np.diff(ci) > 0)
+        xo = _oracle_row_step(oapi, n, k, ci, va, Xh_rows[i], Yh, one, reg, p)
+        np.testing.assert_allclose(X_after_rows[i], xo, rtol=1e-9, atol=1e-12)
+        assert np.any(X_after_rows[i] != Xh_rows[i])      # the row really moved
+
+    # Y half-step on sampled columns
+    cols = np.array([0, 3, 50_000, n - 1])
+    cp = w.colptr[torch.as_tensor(np.concatenate([cols, cols + 1]), device=dX.device)].cpu().numpy()
+    col_data = []
+    for i, f in enumerate(cols):
+        b, e1 = int(cp[i]), int(cp[len(cols) + i])
+        ri = w.rowidx[b:e1]
+        assert torch.all(ri[1:] > ri[:-1])
+        col_data.append((X2(dX)[ri.long()].cpu().numpy()[:, :k], w.colvals[b:e1].cpu().numpy()))
+    w.free_sources()
+    api.step_y(h, p.min_stepsize)
+    Y_after = dY.cpu().numpy().reshape(n, ld)
+    objc = dC.cpu().numpy()
+    for i, f in enumerate(cols):
+        yo, oc = _oracle_col_step(oapi, k, col_data[i][0], col_data[i][1], Yh[:, f], one, reg, p)
+        np.testing.assert_allclose(Y_after[f, :k], yo, rtol=1e-9, atol=1e-12)
+        assert objc[f] == pytest.approx(oc, rel=1e-9)
+
+    # recorded objective = independent re-evaluation; two runs identical; descent
+    def run(iters):
+        dX.copy_(X_init); dY.copy_(Y_init)
+        api.reset_stepsizes(h, p.stepsize)
+        objs = []
+        for _ in range(iters):
+            api.step_x(h, p.min_stepsize)
+            api.step_y(h, p.min_stepsize)
+            objs.append(api.sum(h, dC.data_ptr(), n))
+        return objs, dX.clone(), dY.clone()
+
+    o1, X1, Y1 = run(4)
+    o2, Xb, Yb = run(4)
+    assert o1 == o2 and torch.equal(X1, Xb) and torch.equal(Y1, Yb)
+    assert all(o1[i + 1] < o1[i] for i in range(3)), o1
+    api.col_losses(h)
+    loss = api.sum(h, dC.data_ptr(), n)
+    api.col_penalties(h)
+    pen = api.sum(h, dC.data_ptr(), n)
+    assert pen == 0.0 and loss + pen == pytest.approx(o1[-1], rel=1e-10)
+    st = api.kernel_stats(h)
+    assert st["nnz_rows"] == m * q and st["trials_x"] >= st["accepts_x"] > 0
+    api.destroy(h)
+
+
+@pytest.mark.parametrize("quad_gram", [0, 1])
+def test_c3_full_size_dense_path_and_oracle_spot_check(quad_gram):
+    """BASELINE configs[2]: 1M x 10k, rank 32, fully observed QuadLoss, ZeroReg -- 80 GB of A handed over as the dense matrix, the
+    half-steps on the fp64 matrix cores (X'Y - A is never materialised).  Sampled rows and columns of the first half-steps against the
+    oracle's list path on the same fully observed segments."""
+    import gc
+    import torch
+    gc.collect(); torch.cuda.empty_cache()
+    m, n, k = 1_000_000, 10_000, 32
+    api = _capi.hip_api()
+    zr = (0, 0, 1.0)
+    w = synth.DenseDeviceWorkload(m, n, k, rx=zr, ry=zr)
+    rows = np.array([0, 5, 31, 999_983, m - 1])
+    cols = np.array([0, 7, 4_999, n - 1])
+    A2 = w.A.view(m, n)
+    A_rows = A2[torch.as_tensor(rows, device=w.A.device)].cpu().numpy()
+    A_cols = A2[:, torch.as_tensor(cols, device=w.A.device)].t().contiguous().cpu().numpy()
+    del A2
+    h = api.create(w.problem(), stream=torch.cuda.current_stream().cuda_stream, quad_gram=quad_gram)
+    w.free_sources()
+    ld = api.factor_ld(h)
+    st = api.kernel_stats(h)
+    assert ld == 32 and st["tiled"] == 4, st["tiled"]
+    dX, dY = w.init_factors(ld)
+    dC, dR = torch.zeros(n, dtype=torch.float64, device=dX.device), torch.zeros(m, dtype=torch.float64, device=dX.device)
+    api.bind_buffers(h, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())
+    X_init, Y_init = dX.clone(), dY.clone()
+    p = L.ProxGradParams()
+    one = np.array([synth.QUAD], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([zr], dtype=_capi.REG_DTYPE)
+    oapi = O.oracle_api()
+    Yh = Y_init.cpu().numpy().reshape(n, ld)[:, :k].T
+    Xh = X_init.cpu().numpy().reshape(m, ld)[:, :k]
+    api.reset_stepsizes(h, p.stepsize)
+    api.step_x(h, p.min_stepsize)
+    X_after = dX.cpu().numpy().reshape(m, ld)[:, :k].copy()
+    tol = dict(rtol=1e-9, atol=1e-12) if not quad_gram else dict(rtol=1e-7, atol=1e-10)  # quad_gram: trials from the quadratic form
+    for i, e in enumerate(rows):
+        xo = _oracle_row_step(oapi, n, k, np.arange(n, dtype=np.int32), A_rows[i], Xh[e], Yh, one, reg, p)
+        np.testing.assert_allclose(X_after[e], xo, **tol)
+    api.step_y(h, p.min_stepsize)
+    Y_after = dY.cpu().numpy().reshape(n, ld)
+    objc = dC.cpu().numpy()
+    for i, f in enumerate(cols):
+        yo, oc = _oracle_col_step(oapi, k, X_after, A_cols[i], Yh[:, f], one, reg, p)
+        np.testing.assert_allclose(Y_after[f, :k], yo, **tol)
+        assert objc[f] == pytest.approx(oc, rel=1e-9 if not quad_gram else 1e-7)
+
+    def run(iters):
+        dX.copy_(X_init); dY.copy_(Y_init)
+        api.reset_stepsizes(h, p.stepsize)
+        objs = []
+        for _ in range(iters):
+            api.step_x(h, p.min_stepsize)
+            api.step_y(h, p.min_stepsize)
+            objs.append(api.sum(h, dC.data_ptr(), n))
+        return objs, dX.clone(), dY.clone()
+
+    o1, X1, Y1 = run(3)
+    o2, Xb, Yb = run(3)
+    assert o1 == o2 and torch.equal(X1, Xb) and torch.equal(Y1, Yb)
+    assert o1[2] < o1[1] < o1[0], o1
+    api.col_losses(h)
+    loss = api.sum(h, dC.data_ptr(), n)
+    assert loss == pytest.approx(o1[-1], rel=1e-9 if not quad_gram else 1e-7)
+    api.destroy(h)
