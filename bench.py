@@ -45,6 +45,13 @@ L2_PEAK_GBS = 34500.0
 LDS_PEAK_GBS = 150000.0
 MFMA_F64_PEAK_TFLOPS = 78.6
 MALL_BYTES = 256 * 2 ** 20
+MALL_GATHER_GBS = 8200.0   # measured, not spec: random 512-byte reads out of the Infinity Cache (profiles/r02_ubench_gather.txt)
+
+
+def passes_priced(family):
+    """Passes over the segment's observations the family has to make per half-step: gradient + first trial = 2,
+    except the cached row sweep, which fetches a row once and runs every pass from registers."""
+    return 1 if family == "cached" else 2
 
 CONFIGS = {
     # name: rows, cols, rank, observations per row, value model, loss mix, regularizer descriptor (kind, wrap, scale)
@@ -127,20 +134,20 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
                           measured_ceiling=dict(padded_rows=63000.0, conflict_free=118000.0, unit="GB/s",
                                                 source="profiles/r02_ubench_lanerow.txt")))
     elif family == "cached":
-        # csrc/glrm_cached.hip: the row's opposing vectors are gathered ONCE per half-step into LDS; every pass reads them there.
+        # csrc/glrm_cached.hip (regcached_sweep_kernel): the row's (index, value) list AND its opposing vectors are fetched ONCE per
+        # half-step and kept in registers for the gradient pass and every line-search trial: P = 1 for this family.
+        stream1 = nnz * 12 + 2 * nseg * ld * 8
         gathers = nnz * 8 * k
         if opp > MALL_BYTES:
-            cands.append(dict(bound="hbm", achieved=(stream + gathers) / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=stream + gathers,
-                              what="P x 12 B x |Omega| + own factor r/w + ONE k-vector gather per update (the passes read it from LDS)"))
+            cands.append(dict(bound="hbm", achieved=(stream1 + gathers) / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=stream1 + gathers,
+                              what="12 B x |Omega| + own factor r/w + ONE k-vector gather per update from HBM (every pass reads it from registers)"))
         else:
-            cands.append(dict(bound="hbm", achieved=(stream + opp) / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=stream + opp,
-                              what="compulsory HBM bytes: P x 12 B x |Omega| + own factor r/w + opposing factor once"))
-            cands.append(dict(bound="l2", achieved=gathers / t / 1e9, peak=L2_PEAK_GBS, unit="GB/s", per_launch=gathers,
-                              what="ONE k-vector gather per update served by L2 / Infinity Cache (opposing factor %.0f MB <= 256 MiB; random "
-                                   "512-byte reads from the Infinity Cache measured 8.2 TB/s, profiles/r02_ubench_gather.txt), priced at the L2 peak"
-                                   % (opp / 1e6)))
-        cands.append(dict(bound="lds", achieved=nnz * P * 8 * ld / t / 1e9, peak=LDS_PEAK_GBS, unit="GB/s", per_launch=nnz * P * 8 * ld,
-                          what="LDS reads: one cached vector (8 ld bytes) per update and pass"))
+            cands.append(dict(bound="hbm", achieved=(stream1 + opp) / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=stream1 + opp,
+                              what="compulsory HBM bytes: 12 B x |Omega| (one pass) + own factor r/w + opposing factor once"))
+            cands.append(dict(bound="infinity_cache", achieved=gathers / t / 1e9, peak=MALL_GATHER_GBS, unit="GB/s", per_launch=gathers,
+                              peak_is="MEASURED ceiling of random 8k-byte reads from a table that lives in the Infinity Cache (tools/ubench_gather.hip, "
+                                      "profiles/r02_ubench_gather.txt: 8.2 TB/s at 512 B; MI355X_MICROARCH.md gives no spec bandwidth for that level)",
+                              what="ONE k-vector gather per update served by the Infinity Cache (opposing factor %.0f MB <= 256 MiB)" % (opp / 1e6)))
     else:
         # 'gather' and 'blocked' share one byte model: every update fetches its k-vector from the memory system.  The phase-aligned
         # passes ('blocked') only change WHERE the window all groups read at a time sits: in the Infinity Cache (measured 8.2 TB/s
@@ -162,6 +169,25 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
     return dict(best=best, candidates=cands, algorithmic_GBps=alg / t / 1e9)
 
 
+def step_model(fam_r, fam_c, nnz_r, nnz_c, nseg_r, nseg_c, k, ld, ms_per_step, world):
+    """The bytes ONE outer iteration of one rank has to move under the kernel families that ran it, and the self-check that the step's
+    wall-clock does not beat the HBM peak with them.  SURVEY.md 8(d) prices every half-step at P = 2 passes x (12 + 8k) B per update;
+    the cached row sweep makes ONE pass (the row's list and vectors stay in registers for every trial), so with it the 8(d) figure is
+    no longer a lower bound for the X half-step -- published here so that the check can be redone from the JSON alone."""
+    px, py = passes_priced(fam_r), passes_priced(fam_c)
+    bx = nnz_r * px * (12 + 8 * k) + 2 * nseg_r * ld * 8
+    by = nnz_c * py * (12 + 8 * k) + 2 * nseg_c * ld * 8
+    t = ms_per_step * 1e-3
+    gbps = (bx + by) / t / 1e9
+    survey = (nnz_r + nnz_c) * 2 * (12 + 8 * k) / t / 1e9
+    return {"passes": {"x": px, "y": py}, "bytes_per_step_per_rank": {"x": bx, "y": by, "total": bx + by},
+            "bytes_are": "passes x (12 + 8k) B per update + own factor read and write, per rank (rank 0's shard)",
+            "GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS, "within_peak": bool(gbps <= HBM_PEAK_GBS),
+            "survey_8d_P2_GBps": survey,
+            "note": ("includes host round trips, the objective sum and (N > 1) the exchange in ms_per_step; survey_8d_P2_GBps may exceed the "
+                     "peak when a family makes fewer than two passes -- it is kept for comparison with earlier rounds only")}
+
+
 # ----------------------------------------------------------------------------- CPU legs (rank 0, N = 1 only)
 
 def _oracle_problem(ms, n, k, q, cfg, seed):
@@ -169,7 +195,7 @@ def _oracle_problem(ms, n, k, q, cfg, seed):
     import oracle as O
     from lowrankmodels.jl_amd import _capi, synth
     rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(ms, n, k, q, seed=seed, value_model=cfg["value_model"],
-                                                                            loss_mix=cfg["loss_mix"])
+                                                                            loss_mix=cfg["loss_mix"], transpose=True)
     if nonneg_start(cfg):
         X0, Y0 = np.asfortranarray(np.abs(X0) * (1.0 / k ** 0.5)), np.asfortranarray(np.abs(Y0) * (1.0 / k ** 0.5))
     reg = np.array([cfg["reg"]], dtype=_capi.REG_DTYPE)
@@ -177,17 +203,9 @@ def _oracle_problem(ms, n, k, q, cfg, seed):
     return pa, X0, Y0
 
 
-def cpu_baseline(args, cfg, k, q, n):
-    """The oracle (CPU restatement of the reference, oracle/) timed on the host cores on a bounded sample of the same recipe: the
-    first `ms` rows x all n columns of the same generator (columns are therefore ms/m as long as in the full problem)."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+def _time_oracle(pa, X0, Y0, cores, budget_s):
+    """Outer iterations of the oracle on `pa`, X and Y half-steps timed apart.  Returns (iterations, seconds_x, seconds_y)."""
     import oracle as O
-    cores = O.usable_cores()  # affinity mask and cgroup CPU quota, not the hardware thread count of the host
-    target_obs = (2.5e6 if k <= 32 else 1.2e6) * cores  # ~10-20 s of CPU work at the oracle's rate
-    ms = int(min(max(args.cpu_sample_rows, target_obs / q), args.rows))
-    ms = max(ms - ms % 8, 8)
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    pa, X0, Y0 = _oracle_problem(ms, n, k, q, cfg, args.seed)
     api = O.oracle_api()
     O.set_threads(cores)
     h = api.create(pa)
@@ -195,57 +213,139 @@ def cpu_baseline(args, cfg, k, q, n):
     api.reset_stepsizes(h, 1.0)
     for _ in range(2):  # warm-up iterations: past the first line searches from the random start, like the GPU's warm-up
         api.step_x(h, 0.01); api.step_y(h, 0.01)
-    iters, t0 = 0, time.time()
-    while iters < 3 or (time.time() - t0 < 10.0 and iters < 500):
-        api.step_x(h, 0.01)
-        api.step_y(h, 0.01)
+    iters, tx, ty, t0 = 0, 0.0, 0.0, time.time()
+    while iters < 3 or (time.time() - t0 < budget_s and iters < 500):
+        a = time.time(); api.step_x(h, 0.01)
+        b = time.time(); api.step_y(h, 0.01)
+        c = time.time()
+        tx += b - a; ty += c - b
         iters += 1
-    dt = time.time() - t0
     api.destroy(h)
-    nobs = int(pa.rowptr[-1]) + int(pa.colptr[-1])
-    return {"value": iters * nobs / dt, "unit": "observed-entry updates/s", "cores": cores, "kind": "port",
-            "sample": f"first {ms} rows x all {n} columns of the same generator and recipe ({int(pa.rowptr[-1])} observations, "
-                      f"rank {k}), {iters} outer iterations after 2 warm-up, OpenMP over rows then columns; "
-                      "the reference itself is Julia and cannot run here (no oracle/_ref)"}
+    return iters, tx, ty
 
 
-def jref_leg(args, cfg, api, device):
-    """SURVEY.md 8(d), second leg of the metric.  On a scaled-down problem of the same recipe (same generator, rank, density, losses,
-    regularizers) the CPU oracle runs default ProxGradParams() to its own stop (src/algorithms/proxgrad.jl:210-213): J_ref =
-    ch.objective[end].  The HIP engine then runs the same problem from the same X0, Y0 with the stop rule off and reports the first
-    iteration whose recorded objective is <= J_ref (1 + 1e-5), and the wall-clock to it."""
+def cpu_baseline(args, cfg, k, q, n, m_full):
+    """The oracle (CPU restatement of the reference, oracle/) timed on the host cores on TWO bounded samples of the same recipe, because no
+    single affordable sample has both the rows and the columns of the benchmark problem:
+      rows sample     the first `ms` rows x all n columns: rows as long as in the full problem (q observations, Y as large), columns ms/m as long
+      columns sample  all m rows x the first `ns` columns (the first ns / (n / q) strata of the generator): columns as long as in the full
+                      problem and X at its full size (5 GB at C4: not cache resident), rows ns / n as long
+    `value` combines the X half-step rate of the rows sample with the Y half-step rate of the columns sample (harmonic: one update of
+    each per observed entry and iteration); both samples' own rates are reported beside it."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    cores = O.usable_cores()  # affinity mask and cgroup CPU quota, not the hardware thread count of the host
+    target_obs = getattr(args, "cpu_target_obs", 0) or (2.5e6 if k <= 32 else 1.2e6) * cores  # ~10 s of CPU work per sample at the oracle's rate
+    ms = int(min(max(args.cpu_sample_rows, target_obs / q), args.rows))
+    ms = max(ms - ms % 8, 8)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    pa, X0, Y0 = _oracle_problem(ms, n, k, q, cfg, args.seed)
+    it_a, tx_a, ty_a = _time_oracle(pa, X0, Y0, cores, 8.0)
+    obs_a = int(pa.rowptr[-1])
+    del pa, X0, Y0
+    rate_x_a, rate_y_a = it_a * obs_a / tx_a, it_a * obs_a / ty_a
+    out = {"unit": "observed-entry updates/s", "cores": cores, "kind": "port",
+           "rows_sample": {"sample": f"first {ms} rows x all {n} columns ({obs_a} observations, rank {k}), {it_a} outer iterations after 2 warm-up",
+                           "x_halfstep_updates_per_s": rate_x_a, "y_halfstep_updates_per_s": rate_y_a,
+                           "updates_per_s": it_a * 2 * obs_a / (tx_a + ty_a)}}
+    rate_y = rate_y_a
+    S = n // q                                   # stratum width of the generator: row e observes one column per stratum
+    qs = min(q, max(1, int(round(target_obs / m_full))))
+    if args.cpu_cols_sample and ms < m_full and m_full * k * 8 * 4 < 64e9:  # (ms == m_full: the rows sample already is the whole problem)
+        ns = qs * S
+        pb, Xb, Yb = _oracle_problem(m_full, ns, k, qs, cfg, args.seed)   # same Omega / values / start as the full problem on these columns
+        it_b, tx_b, ty_b = _time_oracle(pb, Xb, Yb, cores, 8.0)
+        obs_b = int(pb.rowptr[-1])
+        del pb, Xb, Yb
+        rate_y = it_b * obs_b / ty_b
+        out["columns_sample"] = {"sample": f"all {m_full} rows x the first {ns} columns ({obs_b} observations, {m_full * q // n} per column as in the full "
+                                           f"problem, X at full size {m_full * k * 8 / 1e9:.2f} GB), {it_b} outer iterations after 2 warm-up",
+                                 "x_halfstep_updates_per_s": it_b * obs_b / tx_b, "y_halfstep_updates_per_s": rate_y,
+                                 "updates_per_s": it_b * 2 * obs_b / (tx_b + ty_b)}
+    out["value"] = 2.0 / (1.0 / rate_x_a + 1.0 / rate_y)
+    out["sample"] = ("X half-step rate of the rows sample combined with the Y half-step rate of the "
+                     + ("columns sample" if "columns_sample" in out else "rows sample (no columns sample was run)")
+                     + " (2 / (1/rate_x + 1/rate_y)); OpenMP over rows then columns; the reference itself is Julia and cannot run here (no oracle/_ref)")
+    return out
+
+
+def load_jref_fixture(config, seed):
+    """tests/golden/jref_<config>.json (tools/make_jref.py): the CPU oracle's run to its own stop on >= 1e8 observations of the recipe."""
+    path = os.path.join(ROOT, "tests", "golden", f"jref_{config}.json")
+    if not os.path.exists(path):
+        return None
+    fx = json.load(open(path))
+    c = CONFIGS[config]
+    ok = fx["seed"] == seed and fx["k"] == c["k"] and fx["value_model"] == c["value_model"] and fx["loss_mix"] == c["loss_mix"] and tuple(fx["reg"]) == tuple(c["reg"])
+    return fx if ok else None
+
+
+def jref_leg(args, cfg, api, device, fixture=None):
+    """SURVEY.md 8(d), second leg of the metric: iterations and wall-clock until the GPU's recorded objective is <= J_ref (1 + 1e-5), where
+    J_ref = ch.objective[end] of the CPU oracle running default ProxGradParams() to its OWN stop (src/algorithms/proxgrad.jl:210-213) on
+    the same problem from the same X0, Y0; the GPU runs with the stop rule off.
+    With a committed fixture (tests/golden/jref_<config>.json: a problem of the recipe with >= 1e8 observations, minutes of CPU time,
+    run once by tools/make_jref.py) the problem is regenerated on the device from the same counter-based generator; without one the
+    oracle runs a small problem of the recipe here (cfg["jref"])."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
-    import oracle as O
     from lowrankmodels.jl_amd.params import ProxGradParams
     k = cfg["k"]
-    ms, n, q = cfg["jref"]
-    pa, X0, Y0 = _oracle_problem(ms, n, k, q, cfg, args.seed)
-    cores = O.usable_cores()
-    O.set_threads(cores)
-    oapi = O.oracle_api()
-    prm = ProxGradParams()
-    Xc, Yc = X0.copy(order="F"), Y0.copy(order="F")
-    h = oapi.create(pa)
-    t0 = time.time()
-    obj_cpu, _ = oapi.fit(h, prm, Xc, Yc)
-    t_cpu = time.time() - t0
-    oapi.destroy(h)
-    j_ref = float(obj_cpu[-1])
-    Xg, Yg = X0.copy(order="F"), Y0.copy(order="F")
-    h = api.create(pa, device_id=device.index or 0)
-    prm_gpu = ProxGradParams(max_iter=max(len(obj_cpu) + 20, 30), abs_tol=-1e300, rel_tol=-1e300)  # stop rule off (no decrease is ever below these)
+    if fixture is not None:
+        import torch
+        from lowrankmodels.jl_amd import synth
+        ms, n, q = fixture["m"], fixture["n"], fixture["q"]
+        j_ref, it_cpu = float(fixture["J_ref"]), int(fixture["iterations_to_own_stop"])
+        reg = cfg["reg"]
+        w = synth.DeviceWorkload(ms, n, k, q, seed=args.seed, value_model=cfg["value_model"], loss_mix=cfg["loss_mix"], rx=reg, ry=reg, device=device)
+        h = api.create(w.problem(), device_id=device.index or 0)
+        ld = api.factor_ld(h)
+        dX, dY = w.init_factors(ld)
+        w.free_sources()
+        if nonneg_start(cfg):
+            dX.abs_().mul_(1.0 / k ** 0.5); dY.abs_().mul_(1.0 / k ** 0.5)
+        Xg = np.asfortranarray(dX.cpu().numpy().reshape(ms, ld)[:, :k].T)
+        Yg = np.asfortranarray(dY.cpu().numpy().reshape(n, ld)[:, :k].T)
+        del dX, dY
+        cpu = {"cpu_iterations_to_own_stop": it_cpu, "cpu_seconds": fixture["cpu_seconds"], "cpu_cores": fixture["cpu_cores"],
+               "cpu_where": fixture["cpu_where"], "fixture": f"tests/golden/jref_{fixture['config']}.json (tools/make_jref.py)",
+               "cpu_objective_initial": fixture["objective"][0]}
+        nobs = fixture["observations"]
+    else:
+        import oracle as O
+        ms, n, q = cfg["jref"]
+        pa, X0, Y0 = _oracle_problem(ms, n, k, q, cfg, args.seed)
+        cores = O.usable_cores()
+        O.set_threads(cores)
+        oapi = O.oracle_api()
+        Xc, Yc = X0.copy(order="F"), Y0.copy(order="F")
+        h = oapi.create(pa)
+        t0 = time.time()
+        obj_cpu, _ = oapi.fit(h, ProxGradParams(), Xc, Yc)
+        t_cpu = time.time() - t0
+        oapi.destroy(h)
+        j_ref, it_cpu = float(obj_cpu[-1]), len(obj_cpu) - 1
+        Xg, Yg = X0.copy(order="F"), Y0.copy(order="F")
+        h = api.create(pa, device_id=device.index or 0)
+        cpu = {"cpu_iterations_to_own_stop": it_cpu, "cpu_seconds": t_cpu, "cpu_cores": cores, "cpu_where": "this host, in this run"}
+        nobs = int(pa.rowptr[-1])
+    prm_gpu = ProxGradParams(max_iter=max(it_cpu + 20, 30), abs_tol=-1e300, rel_tol=-1e300)  # stop rule off (no decrease is ever below these)
     t0 = time.time()
     obj_gpu, sec_gpu = api.fit(h, prm_gpu, Xg, Yg)
     t_gpu = time.time() - t0
     api.destroy(h)
     hit = np.flatnonzero(obj_gpu <= j_ref * (1 + 1e-5))
     it = int(hit[0]) if len(hit) else None
-    return {"problem": f"{ms} x {n}, rank {k}, {q} observations per row ({int(pa.rowptr[-1])} observed), same generator / losses / regularizers",
-            "J_ref": j_ref, "cpu_iterations_to_own_stop": len(obj_cpu) - 1, "cpu_seconds": t_cpu, "cpu_cores": cores,
-            "gpu_first_iteration_at_or_below_J_ref": it, "gpu_seconds_to_J_ref": float(sec_gpu[it]) if it is not None else None,
-            "gpu_objective_there": float(obj_gpu[it]) if it is not None else None, "gpu_fit_wall_s_incl_transfers": t_gpu,
-            "rule": "first GPU iteration with objective <= J_ref (1 + 1e-5); J_ref = oracle, default ProxGradParams(), own stop rule"}
+    out = {"problem": f"{ms} x {n}, rank {k}, {q} observations per row ({nobs} observed), same generator / losses / regularizers / start",
+           "J_ref": j_ref, **cpu,
+           "gpu_first_iteration_at_or_below_J_ref": it, "gpu_seconds_to_J_ref": float(sec_gpu[it]) if it is not None else None,
+           "gpu_objective_there": float(obj_gpu[it]) if it is not None else None, "gpu_objective_initial": float(obj_gpu[0]),
+           "gpu_objective_at_cpu_stop_iteration": float(obj_gpu[min(it_cpu, len(obj_gpu) - 1)]),
+           "gpu_ms_per_iteration": 1e3 * float(sec_gpu[-1]) / max(len(sec_gpu) - 1, 1), "gpu_fit_wall_s_incl_transfers": t_gpu,
+           "rule": "first GPU iteration with objective <= J_ref (1 + 1e-5); J_ref = oracle, default ProxGradParams(), own stop rule"}
+    if cpu.get("cpu_seconds") and it is not None and sec_gpu[it] > 0:
+        out["speedup_to_J_ref_vs_cpu"] = cpu["cpu_seconds"] / float(sec_gpu[it])
+    return out
 
 
 # ----------------------------------------------------------------------------- PMC traffic (rank 0, N = 1 only)
@@ -411,9 +511,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-convergence-run", action="store_true")
     ap.add_argument("--no-jref", action="store_true")
+    ap.add_argument("--jref-small", action="store_true", help="to_ref_objective on the small in-run problem even when a fixture is committed")
     ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"], help="HBM traffic of the dominant kernel from rocprofv3 PMC child passes")
     ap.add_argument("--pmc-timeout", type=int, default=240)
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000)
+    ap.add_argument("--no-cpu-cols-sample", dest="cpu_cols_sample", action="store_false", help="cpu_baseline: skip the all-rows x few-columns sample")
     ap.add_argument("--emulate-rank", type=int, default=-1, help="with --of N: ONE GPU runs rank r's shard of the N-way sharded problem "
                     "(m/N rows, n/N columns, full replicas of X and Y, kernel families chosen from the whole problem) and times its half-steps")
     ap.add_argument("--of", type=int, default=0, help="number of shards emulated by --emulate-rank")
@@ -561,7 +663,8 @@ def main():
                  ("col", "tiled"): ("tiled_col_pass_kernel x2 + col_reduce/col_decide (Y half-step, LDS-tiled)", "tiled_col_pass_kernel"),
                  ("row", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (X half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
                  ("col", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (Y half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
-                 ("row", "cached"): ("cached_sweep_kernel (X half-step, the row's opposing vectors gathered once into LDS)", "cached_sweep_kernel"),
+                 ("row", "cached"): ("regcached_sweep_kernel<G, R, LOSS, 7, 2> (X half-step: the row's list and opposing vectors fetched once into "
+                                     "registers, two waves per row; rows beyond 13 trips run sweep_kernel)", "regcached_sweep_kernel"),
                  ("row", "dense"): ("dense_pass_kernel (X half-step, fp64 MFMA)", "dense_pass_kernel"),
                  ("col", "dense"): ("dense_pass_kernel (Y half-step, fp64 MFMA)", "dense_pass_kernel"),
                  ("row", "general"): ("multi_sweep_kernel (X half-step)", "multi_sweep_kernel"),
@@ -610,18 +713,20 @@ def main():
                         "col_sweep": None if not rl_c else {kk: rl_c["best"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac")},
                         "mean_trials_per_row": st["trials_x"] / max(args.steps * nseg_r, 1),
                         "mean_trials_per_col": st["trials_y"] / max(args.steps * nseg_c, 1)},
+            "step_model": step_model(fam_r, fam_c, nnz_r, nnz_c, nseg_r, nseg_c, k, ld, 1e3 * elapsed / args.steps, world) if args.config != "C3" else None,
             "objective": {"initial": obj0, "after_warmup_and_steps": objs[-1] if objs else None},
             "to_reference_stop": conv,
             "setup_s": {"generate": t_gen, "create": t_create},
         }
         if world == 1 and not args.no_jref and args.config != "C3":
             try:
-                out["to_ref_objective"] = jref_leg(args, cfg, api, device)
+                scaled = bool(args.cols or args.obs_per_row or args.k)
+                out["to_ref_objective"] = jref_leg(args, cfg, api, device, fixture=None if scaled or args.jref_small else load_jref_fixture(args.config, args.seed))
             except Exception as e:
                 out["to_ref_objective"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             c3 = args.config == "C3"  # the oracle has no dense hand-over: its list path on the same fully observed recipe
-            out["cpu_baseline"] = cpu_baseline(args, cfg, k, q if not c3 else n, n)
+            out["cpu_baseline"] = cpu_baseline(args, cfg, k, q if not c3 else n, n, m)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -98,6 +98,9 @@ int glrm_synth_cpu_rows(const glrm_synth_spec* s, int64_t row_begin, int64_t row
 int glrm_synth_cpu_col_counts(const glrm_synth_spec* s, int64_t col_begin, int64_t col_end, int64_t* colptr);
 int glrm_synth_cpu_cols(const glrm_synth_spec* s, int64_t col_begin, int64_t col_end, const int64_t* colptr,
                         int32_t* rowidx, double* vals);
+/* the same column view from the row view of rows [0, m) (stable counting sort, O(nnz)); needs every listed column inside [col_begin, col_end) */
+int glrm_synth_cpu_cols_from_rows(int64_t m, int64_t col_begin, int64_t col_end, const int64_t* rowptr, const int32_t* colidx,
+                                  const double* rowvals, int64_t* colptr, int32_t* rowidx, double* colvals);
 /* X0 (k x m, leading dimension ld) and Y0 (k x n): iid N(0,1) by Box-Muller, streams 7 / 8
  * (the reference default is randn, src/glrm.jl:31). */
 int glrm_synth_cpu_init(const glrm_synth_spec* s, uint64_t init_seed, int ld, double* X, double* Y);

@@ -246,17 +246,75 @@ class ShardedFit:
             c = nrows[0] // self.x_chunks
             self._stage = [torch.empty(self.world * c * self.ld, dtype=torch.float64, device=self.device) for _ in range(self.x_chunks)]
             self._comm_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
-        # GLRM_GATHER: auto (in-place all-gather on nccl = RCCL, one broadcast per owner otherwise) | allgather | broadcast | p2p (every
-        # owner sends its block straight to every peer in ONE group of point-to-point operations: ncclSend / ncclRecv on RCCL -- all
-        # seven xGMI links of a GPU carry a block at once, the direct exchange of DESIGN.md section 6 on the torch host)
+        # GLRM_GATHER: how the updated blocks reach the other ranks.
+        #   allgather  one in-place all_gather_into_tensor (RCCL picks the algorithm: on a ring the 1/N slice travels N - 1 hops)
+        #   p2p        every owner sends its block straight to every peer in ONE group of point-to-point operations (ncclSend / ncclRecv
+        #              on RCCL): all seven xGMI links of a GPU carry a block at once -- the direct exchange of DESIGN.md section 6
+        #   broadcast  one broadcast per owner (what ragged blocks fall back to)
+        #   auto       nccl with more than two ranks: BOTH are timed once at set-up on the X block (a few ms each) and the faster one is
+        #              kept on every rank (the probe is published as `exchange_probe_ms`); otherwise all-gather on nccl, broadcasts elsewhere
         mode = os.environ.get("GLRM_GATHER", "auto")
         self._p2p = self.world > 1 and mode == "p2p"
         self._inplace_ok = self.world > 1 and mode not in ("broadcast", "p2p") and (mode == "allgather" or dist.get_backend(group) == "nccl")
+        self.exchange_ms = {"x": 0.0, "y": 0.0, "objective": 0.0}   # time the rank's stream spent in the exchanges (profile runs)
+        self._timed = []                                            # (kind, start event, end event) awaiting a synchronisation
+        self._profile = bool(o.get("profile")) and self.device.type == "cuda"
+        self.exchange_probe_ms = None
+        if self.world > 2 and mode == "auto" and self.device.type == "cuda" and dist.get_backend(group) == "nccl":
+            self._probe_exchange()
+
+    def _probe_exchange(self):
+        """Time one all-gather and one point-to-point exchange of the X blocks (contents: whatever dX holds, it is rewritten by
+        set_factors afterwards) and keep the faster on every rank; a failing p2p path leaves the all-gather in place."""
+        torch, dist = self.torch, self.dist
+        res = {}
+        for name in ("allgather", "p2p"):
+            self._p2p = name == "p2p"
+            try:
+                for rep in range(2):  # first repetition: connection set-up
+                    torch.cuda.synchronize(self.device)
+                    dist.barrier(group=self.group)
+                    t0 = time.perf_counter()
+                    self._gather(self.dX, self.row_bounds, self.ld)
+                    torch.cuda.synchronize(self.device)
+                    dt = (time.perf_counter() - t0) * 1e3
+                t = torch.tensor([dt], dtype=torch.float64, device=self.device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+                res[name] = float(t.item())
+            except Exception as e:  # noqa: BLE001 -- an unsupported path must not take the fit down
+                res[name] = float("inf")
+                res[name + "_error"] = repr(e)
+        flag = torch.tensor([1.0 if res["p2p"] < res["allgather"] else 0.0], dtype=torch.float64, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)   # every rank must have seen p2p win
+        self._p2p = bool(flag.item() > 0.5)
+        res["chosen"] = "p2p" if self._p2p else "allgather"
+        self.exchange_probe_ms = res
 
     def close(self):
         if self.h is not None:
             self.api.destroy(self.h)
             self.h = None
+
+    def _timed_gather(self, kind, buf, bounds, unit):
+        """_gather bracketed by events on the rank's stream when the handle profiles (bench runs): the collectives are enqueued on the
+        stream the sweeps run on, so the elapsed time between the events is what the exchange added to the iteration."""
+        if not (self._profile and self.world > 1):
+            return self._gather(buf, bounds, unit)
+        a, b = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+        a.record()
+        self._gather(buf, bounds, unit)
+        b.record()
+        self._timed.append((kind, a, b))
+
+    def exchange_times(self):
+        """Summed exchange time per kind in ms since the last call (synchronises)."""
+        if self._timed:
+            self.torch.cuda.synchronize(self.device)
+            for kind, a, b in self._timed:
+                self.exchange_ms[kind] += a.elapsed_time(b)
+            self._timed = []
+        out, self.exchange_ms = self.exchange_ms, {"x": 0.0, "y": 0.0, "objective": 0.0}
+        return out
 
     def _gather(self, buf, bounds, unit):
         """Make ``buf`` (global length) identical on every rank: rank r contributed
@@ -266,26 +324,7 @@ class ShardedFit:
             return
         dist, sizes = self.dist, [(bounds[r + 1] - bounds[r]) * unit for r in range(self.world)]
         if self._p2p:  # ragged blocks are fine: every transfer carries its own size
-            g = lambda r: dist.get_global_rank(self.group, r) if self.group is not None else r
-            own = buf[bounds[self.rank] * unit: bounds[self.rank + 1] * unit]
-            ops = []
-            for r in range(self.world):
-                if r == self.rank:
-                    continue
-                if sizes[self.rank]:
-                    ops.append(dist.P2POp(dist.isend, own, g(r), group=self.group))
-                if sizes[r]:
-                    ops.append(dist.P2POp(dist.irecv, buf[bounds[r] * unit: bounds[r + 1] * unit], g(r), group=self.group))
-            if ops:
-                # only ProcessGroupNCCL orders point-to-point transfers with the CUDA stream; gloo (the plumbing-check backend) reads
-                # and writes device tensors from the host, so the stream is drained on both sides of the exchange there
-                host_sync = self.device.type == "cuda" and dist.get_backend(self.group) != "nccl"
-                if host_sync:
-                    self.torch.cuda.synchronize(self.device)
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-                if host_sync:
-                    self.torch.cuda.synchronize(self.device)
+            self._p2p_ranges(buf, [(bounds[r] * unit, bounds[r + 1] * unit) for r in range(self.world)])
             return
         if self._inplace_ok and len(set(sizes)) == 1 and sizes[0] > 0:
             own = buf[bounds[self.rank] * unit: bounds[self.rank + 1] * unit]
@@ -298,9 +337,37 @@ class ShardedFit:
                 src = dist.get_global_rank(self.group, r) if self.group is not None else r
                 dist.broadcast(buf[bounds[r] * unit: bounds[r + 1] * unit], src=src, group=self.group)
 
+    def _p2p_ranges(self, buf, ranges):
+        """Rank r owns buf[ranges[r][0]:ranges[r][1]]: send the own range to every peer and receive every peer's range in place, as ONE
+        group of point-to-point operations (grouped ncclSend / ncclRecv on RCCL)."""
+        dist = self.dist
+        g = lambda r: dist.get_global_rank(self.group, r) if self.group is not None else r
+        lo, hi = ranges[self.rank]
+        own = buf[lo:hi]
+        ops = []
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            if hi > lo:
+                ops.append(dist.P2POp(dist.isend, own, g(r), group=self.group))
+            if ranges[r][1] > ranges[r][0]:
+                ops.append(dist.P2POp(dist.irecv, buf[ranges[r][0]:ranges[r][1]], g(r), group=self.group))
+        if not ops:
+            return
+        # only ProcessGroupNCCL orders point-to-point transfers with the CUDA stream; gloo (the plumbing-check backend) reads and
+        # writes device tensors from the host, so the stream is drained on both sides of the exchange there
+        host_sync = self.device.type == "cuda" and dist.get_backend(self.group) != "nccl"
+        if host_sync:
+            self.torch.cuda.synchronize(self.device)
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+        if host_sync:
+            self.torch.cuda.synchronize(self.device)
+
     def _step_x_pipelined(self, params):
-        """Last inner X sweep in row chunks; chunk j is all-gathered (into a staging buffer, then copied to each
-        owner's place in the replicated X) while chunk j+1 is being swept."""
+        """Last inner X sweep in row chunks; the exchange of chunk j proceeds on a side stream while chunk j+1 is being swept.  With
+        the point-to-point exchange every chunk goes straight from its owner into its place on every peer; with the all-gather it
+        lands in a staging buffer (the ranks' chunks are not adjacent in X) and is copied into place."""
         torch, dist, api, h = self.torch, self.dist, self.api, self.h
         S, ld, rb = self.x_chunks, self.ld, self.row_bounds
         c = (rb[self.rank + 1] - rb[self.rank]) // S
@@ -313,17 +380,29 @@ class ShardedFit:
                 ev.record()
                 with torch.cuda.stream(self._comm_stream):
                     self._comm_stream.wait_event(ev)
-                    dist.all_gather_into_tensor(self._stage[j], own, group=self.group)
-                    for q in range(self.world):
-                        if q != self.rank:
-                            self.dX[(rb[q] + j * c) * ld: (rb[q] + (j + 1) * c) * ld].copy_(self._stage[j][q * c * ld: (q + 1) * c * ld], non_blocking=True)
+                    if self._p2p:
+                        self._p2p_ranges(self.dX, [((rb[q] + j * c) * ld, (rb[q] + (j + 1) * c) * ld) for q in range(self.world)])
+                    else:
+                        dist.all_gather_into_tensor(self._stage[j], own, group=self.group)
+                        for q in range(self.world):
+                            if q != self.rank:
+                                self.dX[(rb[q] + j * c) * ld: (rb[q] + (j + 1) * c) * ld].copy_(self._stage[j][q * c * ld: (q + 1) * c * ld], non_blocking=True)
+            elif self._p2p:
+                self._p2p_ranges(self.dX, [((rb[q] + j * c) * ld, (rb[q] + (j + 1) * c) * ld) for q in range(self.world)])
             else:
                 dist.all_gather_into_tensor(self._stage[j], own.clone(), group=self.group)
                 for q in range(self.world):
                     if q != self.rank:
                         self.dX[(rb[q] + j * c) * ld: (rb[q] + (j + 1) * c) * ld].copy_(self._stage[j][q * c * ld: (q + 1) * c * ld])
         if cuda:
-            torch.cuda.current_stream().wait_stream(self._comm_stream)
+            if self._profile:  # what the pipeline did NOT hide: the wait for the last chunks
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
+                b.record()
+                self._timed.append(("x", a, b))
+            else:
+                torch.cuda.current_stream().wait_stream(self._comm_stream)
 
     def initial_objective(self):
         api, h = self.api, self.h
@@ -349,11 +428,11 @@ class ShardedFit:
             self._step_x_pipelined(params)
         else:
             api.step_x(h, params.min_stepsize)
-            self._gather(self.dX, self.row_bounds, self.ld)  # inner X sweeps only touch own rows: gather once
+            self._timed_gather("x", self.dX, self.row_bounds, self.ld)  # inner X sweeps only touch own rows: gather once
         for _ in range(params.inner_iter_Y):
             api.step_y(h, params.min_stepsize)
-        self._gather(self.dY, self.y_bounds, self.ld)
-        self._gather(self.dObjCol, self.col_bounds, 1)
+        self._timed_gather("y", self.dY, self.y_bounds, self.ld)
+        self._timed_gather("objective", self.dObjCol, self.col_bounds, 1)
         return api.sum(h, self.dObjCol.data_ptr(), self.n)
 
 

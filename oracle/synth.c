@@ -67,6 +67,35 @@ int glrm_synth_cpu_cols(const glrm_synth_spec* s, int64_t col_begin, int64_t col
   return 0;
 }
 
+/* The column view of rows [0, m) x columns [col_begin, col_end) from the ROW view of the same block, by a stable counting sort on the
+ * column index: O(nnz) instead of the O(columns x m) hash scan above, and the same arrays (rows ascending inside a column because the
+ * row view is walked in row order; a value depends on (e, f) only) -- tests/test_synth.py compares the two.  Bench tooling: the CPU
+ * legs of bench.py build their samples with it.  colptr: col_end - col_begin + 1 entries. */
+int glrm_synth_cpu_cols_from_rows(int64_t m, int64_t col_begin, int64_t col_end, const int64_t* rowptr, const int32_t* colidx,
+                                  const double* rowvals, int64_t* colptr, int32_t* rowidx, double* colvals) {
+  const int64_t nc = col_end - col_begin;
+  if (m < 0 || nc < 0) return -1;
+  for (int64_t i = 0; i <= nc; ++i) colptr[i] = 0;
+  const int64_t nnz = rowptr[m];
+  for (int64_t t = 0; t < nnz; ++t) {
+    const int64_t f = colidx[t] - col_begin;
+    if (f < 0 || f >= nc) return -1;
+    ++colptr[f + 1];
+  }
+  for (int64_t i = 0; i < nc; ++i) colptr[i + 1] += colptr[i];
+  int64_t* pos = (int64_t*)malloc((size_t)(nc > 0 ? nc : 1) * sizeof(int64_t));
+  if (!pos) return -1;
+  for (int64_t i = 0; i < nc; ++i) pos[i] = colptr[i];
+  for (int64_t e = 0; e < m; ++e)
+    for (int64_t t = rowptr[e]; t < rowptr[e + 1]; ++t) {
+      const int64_t p = pos[colidx[t] - col_begin]++;
+      rowidx[p] = (int32_t)e;
+      colvals[p] = rowvals[t];
+    }
+  free(pos);
+  return 0;
+}
+
 static double box_muller(uint64_t seed, uint64_t stream, uint64_t i, uint64_t j) {
   double u1 = glrm_unif(glrm_hash4(seed, stream, i, j));
   double u2 = glrm_unif(glrm_hash4(seed, stream + 100, i, j));

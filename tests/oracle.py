@@ -175,8 +175,10 @@ class SynthSpec(C.Structure):
 
 
 def synth_cpu(m, n, k, q, seed=20260926, value_model=0, loss_mix=0, noise=0.1, init_seed=1,
-              rows=None, cols=None):
-    """Generate (rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0) with oracle/synth.c."""
+              rows=None, cols=None, transpose=False):
+    """Generate (rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0) with oracle/synth.c.
+    transpose=True (whole problems only): the column view is counting-sorted out of the row view (O(nnz)) instead of the generator's
+    O(n x m) hash scan -- the same arrays (tests/test_synth.py), what bench.py's CPU legs use."""
     lib = oracle_lib()
     s = SynthSpec(m, n, k, q, seed, value_model, loss_mix, noise)
     rb, re = (0, m) if rows is None else rows
@@ -187,6 +189,18 @@ def synth_cpu(m, n, k, q, seed=20260926, value_model=0, loss_mix=0, noise=0.1, i
     rowvals = np.zeros(nzr, np.float64)
     assert lib.glrm_synth_cpu_rows(C.byref(s), C.c_int64(rb), C.c_int64(re), C.c_void_p(rowptr.ctypes.data),
                                    C.c_void_p(colidx.ctypes.data), C.c_void_p(rowvals.ctypes.data)) == 0
+    if transpose:
+        assert (rb, re, cb, ce) == (0, m, 0, n), "transpose=True builds whole problems"
+        colptr = np.zeros(n + 1, np.int64)
+        rowidx = np.zeros(nzr, np.int32)
+        colvals = np.zeros(nzr, np.float64)
+        assert lib.glrm_synth_cpu_cols_from_rows(C.c_int64(m), C.c_int64(0), C.c_int64(n), C.c_void_p(rowptr.ctypes.data), C.c_void_p(colidx.ctypes.data),
+                                                 C.c_void_p(rowvals.ctypes.data), C.c_void_p(colptr.ctypes.data), C.c_void_p(rowidx.ctypes.data),
+                                                 C.c_void_p(colvals.ctypes.data)) == 0
+        X0 = np.zeros((k, m), order="F")
+        Y0 = np.zeros((k, n), order="F")
+        assert lib.glrm_synth_cpu_init(C.byref(s), C.c_uint64(init_seed), C.c_int(k), C.c_void_p(X0.ctypes.data), C.c_void_p(Y0.ctypes.data)) == 0
+        return rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0
     colptr = np.zeros(ce - cb + 1, np.int64)
     assert lib.glrm_synth_cpu_col_counts(C.byref(s), C.c_int64(cb), C.c_int64(ce), C.c_void_p(colptr.ctypes.data)) == 0
     nzc = int(colptr[-1])

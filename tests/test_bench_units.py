@@ -23,7 +23,7 @@ def test_algorithmic_bytes_match_the_survey():
     ("tiled", dict(nnz=5 * 10**8, nseg=10_000, nopp=1_000_000, k=32, ld=32, ms=9.7), "lds"),     # C2 Y half-step
     ("dense", dict(nnz=10**10, nseg=1_000_000, nopp=10_000, k=32, ld=32, ms=42.3, m=1_000_000, n=10_000), "mfma"),
     ("dense", dict(nnz=10**10, nseg=1_000_000, nopp=10_000, k=32, ld=32, ms=24.4, m=1_000_000, n=10_000, quad_gram=True), "mfma"),
-    ("cached", dict(nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=85.3), "l2"),      # C4 X half-step, one gather pass
+    ("cached", dict(nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=85.3), "infinity_cache"),  # C4 X half-step, one gather pass
     ("cached", dict(nnz=10**9, nseg=10_000_000, nopp=2_000_000, k=64, ld=64, ms=120.0), "hbm"),  # the same with Y = 1 GB: HBM gathers
 ])
 def test_roofline_fractions_are_fractions(family, kw, bound):
@@ -71,8 +71,13 @@ def test_cpu_legs_with_the_oracle_standing_in(monkeypatch):
     assert r["gpu_first_iteration_at_or_below_J_ref"] is not None and r["gpu_objective_there"] <= r["J_ref"] * (1 + 1e-5)
     assert r["gpu_first_iteration_at_or_below_J_ref"] <= r["cpu_iterations_to_own_stop"]
     monkeypatch.setattr(bench.time, "time", _fast_clock())
-    b = bench.cpu_baseline(Args, dict(cfg, q=20), 64, 20, 400)
-    assert b["kind"] == "port" and b["value"] > 0 and b["cores"] >= 1 and "first" in b["sample"]
+    Args.cpu_cols_sample, Args.cpu_target_obs = True, 40_000   # 2 000 rows x 20 per row, then 10 000 rows x 4 per row
+    b = bench.cpu_baseline(Args, dict(cfg, q=20), 64, 20, 400, 10_000)
+    assert b["kind"] == "port" and b["value"] > 0 and b["cores"] >= 1 and "first" in b["rows_sample"]["sample"]
+    # the second sample keeps the columns at their full length: all rows x the first strata of the generator
+    assert "first 2000 rows" in b["rows_sample"]["sample"] and "all 10000 rows x the first 80 columns" in b["columns_sample"]["sample"] and "columns sample" in b["sample"]
+    rx, ry = b["rows_sample"]["x_halfstep_updates_per_s"], b["columns_sample"]["y_halfstep_updates_per_s"]
+    assert b["value"] == pytest.approx(2 / (1 / rx + 1 / ry))
 
 
 def _fast_clock():
@@ -84,9 +89,20 @@ def _fast_clock():
 def test_cached_family_prices_one_gather_pass():
     two = bench.kernel_roofline("gather", nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=100.0)
     one = bench.kernel_roofline("cached", nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=100.0)
-    l2 = lambda r: next(c for c in r["candidates"] if c["bound"] == "l2")
-    assert l2(one)["per_launch"] * 2 == l2(two)["per_launch"] == 2 * 10**9 * 8 * 64
-    assert any(c["bound"] == "lds" for c in one["candidates"])  # the passes read the row out of LDS / registers
+    by = lambda r, b: next(c for c in r["candidates"] if c["bound"] == b)
+    assert by(one, "infinity_cache")["per_launch"] * 2 == by(two, "l2")["per_launch"] == 2 * 10**9 * 8 * 64
+    # priced against the MEASURED ceiling of such reads out of the Infinity Cache: 5.12e11 B in 85.5 ms = 0.73
+    r = bench.kernel_roofline("cached", nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=85.5)
+    assert r["best"]["bound"] == "infinity_cache" and r["best"]["frac"] == pytest.approx(0.73, abs=5e-3) and "MEASURED" in r["best"]["peak_is"]
+
+
+def test_step_model_reproduces_the_round_two_check():
+    """BENCH_r02: 228.9 ms per iteration at C4.  SURVEY 8(d) (P = 2 on both sides) gives 9.16 TB/s -- above the peak; with the cached row
+    sweep's single pass the step moves ~1.59e12 B = 6.9 TB/s = 0.87 of the peak."""
+    sm = bench.step_model("cached", "blocked", 10**9, 10**9, 10_000_000, 100_000, 64, 64, 228.9, 1)
+    assert sm["passes"] == {"x": 1, "y": 2} and sm["within_peak"]
+    assert sm["survey_8d_P2_GBps"] == pytest.approx(9157, abs=5) and sm["GBps"] == pytest.approx(6913, abs=10)
+    assert bench.step_model("gather", "gather", 10**9, 10**9, 10_000_000, 100_000, 64, 64, 290.0, 1)["passes"] == {"x": 2, "y": 2}
 
 
 def test_quad_gram_prices_the_flop_that_are_left():

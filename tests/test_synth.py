@@ -38,3 +38,12 @@ def test_shards_concatenate_to_the_whole():
     assert np.array_equal(np.concatenate([a[1], b[1]]), full[1]) and np.array_equal(np.concatenate([a[2], b[2]]), full[2])
     assert np.array_equal(np.concatenate([a[4], b[4]]), full[4]) and np.array_equal(np.concatenate([a[5], b[5]]), full[5])
     assert np.array_equal(np.concatenate([a[3], a[3][-1] + b[3][1:]]), full[3])
+
+
+def test_column_view_by_transposition_equals_the_generated_one():
+    """bench.py's CPU legs build the column view by a stable counting sort of the row view (O(nnz)); it is the generator's own."""
+    for mix in (0, 1):
+        a = O.synth_cpu(700, 90, 5, 9, seed=3, loss_mix=mix)
+        b = O.synth_cpu(700, 90, 5, 9, seed=3, loss_mix=mix, transpose=True)
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
