@@ -363,7 +363,7 @@ def pmc_traffic(args, kernel_re, per_halfstep=False, child_env=None):
         d = tempfile.mkdtemp(prefix="glrm_pmc_", dir="/tmp")
         cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--config", args.config, "--rows", str(args.rows), "--steps", "2", "--warmup", str(max(args.warmup, 1)), "--tiled", str(args.tiled), *(["--quad-gram"] if args.quad_gram else []),
-               "--no-cpu-baseline", "--no-convergence-run", "--no-jref", "--pmc", "off", "--seed", str(args.seed),
+               "--no-cpu-baseline", "--no-convergence-run", "--no-jref", "--pmc", "off", "--seed", str(args.seed), "--borrow", args.borrow,
                "--cols", str(args.cols), "--obs-per-row", str(args.obs_per_row), "--rank", str(args.k)]
         env = dict(os.environ, TMPDIR="/tmp", **(child_env or {}))
         try:
@@ -515,6 +515,7 @@ def main():
     ap.add_argument("--pmc", default="auto", choices=["auto", "on", "off"], help="HBM traffic of the dominant kernel from rocprofv3 PMC child passes")
     ap.add_argument("--pmc-timeout", type=int, default=240)
     ap.add_argument("--cpu-sample-rows", type=int, default=20_000)
+    ap.add_argument("--borrow", default="auto", choices=["auto", "on", "off"], help="hand the generated lists to the engine in place (no second copy in HBM)")
     ap.add_argument("--no-cpu-cols-sample", dest="cpu_cols_sample", action="store_false", help="cpu_baseline: skip the all-rows x few-columns sample")
     ap.add_argument("--emulate-rank", type=int, default=-1, help="with --of N: ONE GPU runs rank r's shard of the N-way sharded problem "
                     "(m/N rows, n/N columns, full replicas of X and Y, kernel families chosen from the whole problem) and times its half-steps")
@@ -571,11 +572,15 @@ def main():
                                  value_model=cfg["value_model"], loss_mix=cfg["loss_mix"], rx=reg, ry=reg, device=device)
     t_gen = time.time() - t_gen
     t_create = time.time()
-    sf = ShardedFit(api, w.problem(), rbs, cbs, device=device, stream=torch.cuda.current_stream().cuda_stream,
+    # Lists too large to hold twice in HBM (C5 at its stated size: 120 GB) are handed over in place (GLRM_PROBLEM_BORROW_DEVICE_ARRAYS):
+    # the engine reads the generator's arrays and only makes the private copies its kernels need (the row view regrouped by loss kind)
+    borrow = args.config != "C3" and (args.borrow == "on" or (args.borrow == "auto" and w.list_bytes() > 90e9))
+    sf = ShardedFit(api, w.problem(borrow=borrow) if args.config != "C3" else w.problem(), rbs, cbs, device=device, stream=torch.cuda.current_stream().cuda_stream,
                     opts=dict(profile=1, waves_row=args.waves_row, waves_col=args.waves_col, tiled=args.tiled, quad_gram=1 if args.quad_gram else 0),
                     x_chunks=args.x_chunks if args.config != "C3" else 1)
     nnz_r, nnz_c = w.nnz_rows, w.nnz_cols
-    w.free_sources()
+    if not borrow:
+        w.free_sources()
     t_create = time.time() - t_create
     def load_start():
         X0, Y0 = w.init_factors(sf.ld)
@@ -641,6 +646,8 @@ def main():
     flags = st["tiled"]
     sf.close()
     del sf
+    if borrow:
+        w.free_sources()  # the handle is gone: the borrowed lists may go too (the PMC child runs need the memory)
     torch.cuda.empty_cache()
 
     if rank == 0:
@@ -716,7 +723,7 @@ def main():
             "step_model": step_model(fam_r, fam_c, nnz_r, nnz_c, nseg_r, nseg_c, k, ld, 1e3 * elapsed / args.steps, world) if args.config != "C3" else None,
             "objective": {"initial": obj0, "after_warmup_and_steps": objs[-1] if objs else None},
             "to_reference_stop": conv,
-            "setup_s": {"generate": t_gen, "create": t_create},
+            "setup_s": {"generate": t_gen, "create": t_create, "lists_borrowed_in_place": bool(borrow)},
         }
         if world == 1 and not args.no_jref and args.config != "C3":
             try:

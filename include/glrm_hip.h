@@ -131,6 +131,11 @@ typedef struct glrm_domain {
 } glrm_domain; /* 24 bytes */
 
 #define GLRM_PROBLEM_DEVICE_ARRAYS 1 /* flags bit 0: rowptr..colvals are DEVICE pointers (copied, not adopted) */
+#define GLRM_PROBLEM_BORROW_DEVICE_ARRAYS 4 /* flags bit 2, with bit 0: the engine reads the caller's device arrays IN PLACE instead of
+                                        copying them; the caller keeps them alive and unchanged until glrm_hip_destroy.  The engine never
+                                        writes to them (a view it has to reorder -- tile sort, grouping by loss kind -- gets a private
+                                        copy).  For hosts whose Omega already lives in HBM and is too large to hold twice (BASELINE
+                                        configs[4]: 120 GB of lists).  Not available for dense_A, whose packed copies replace the original. */
 #define GLRM_PROBLEM_DEFER_SETUP 2   /* flags bit 1: this is one shard of a sharded fit -- glrm_hip_create only uploads it; the host
                                         combines the shards' glrm_signature and calls glrm_hip_finalize on every shard before the
                                         first step (see glrm_signature below) */

@@ -17,6 +17,7 @@ GLRM_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_COMM, ERR_OOM, ERR_NONFINITE = -1, -2, -3, -4, -5, -6
 PROBLEM_DEVICE_ARRAYS = 1
 PROBLEM_DEFER_SETUP = 2
+PROBLEM_BORROW_DEVICE_ARRAYS = 4
 
 
 class GLRMError(RuntimeError):

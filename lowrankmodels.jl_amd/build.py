@@ -57,5 +57,31 @@ def build_all(force=False, verbose=True):
     return built
 
 
+def build_variant(tag, defines, verbose=True):
+    """libglrm_hip_<tag>.so: the engine compiled with extra -D switches, next to the product library (same-box A/B of kernel variants with
+    tests/perf/ab_lib.py; e.g. tag "libm", defines GLRM_LOGISTIC_LIBM GLRM_ORDINAL_BRANCHY GLRM_POISSON_LIBM = round 2's loss formulas)."""
+    srcs, _ = TARGETS["libglrm_hip.so"]
+    out = os.path.join(PKG, f"libglrm_hip_{tag}.so")
+    objs, procs = [], []
+    for sname in srcs:
+        sp = os.path.join(CSRC, sname)
+        obj = os.path.join(PKG, "build", tag, sname + ".o")
+        os.makedirs(os.path.dirname(obj), exist_ok=True)
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-D" + d for d in defines] + ["-c", sp, "-o", obj]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+        objs.append(obj)
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", out], check=True)
+    return out
+
+
 if __name__ == "__main__":
-    build_all(force=True)
+    import sys
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":  # python -m lowrankmodels.jl_amd.build --variant libm GLRM_LOGISTIC_LIBM ...
+        build_variant(sys.argv[2], sys.argv[3:])
+    else:
+        build_all(force=True)

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "../../include/glrm_hip.h"
+#include "glrm_fastmath.hpp"
 
 namespace glrm {
 
@@ -140,13 +141,20 @@ __device__ __forceinline__ void loss_both(const LossDesc& l, double u, double a,
       break;
     }
     case GLRM_LOSS_POISSON: { // :237-241
+#if defined(GLRM_POISSON_LIBM)
       const double eu = exp(u);
+#else
+      const double eu = fm_exp(u);
+#endif
       L = s * (eu - a * u + (a == 0 ? 0.0 : a * (log(a) - 1)));
       if (NEED_GRAD) dL = s * (eu - a);
       break;
     }
-    case GLRM_LOSS_ORDINAL_HINGE: { // :258-292, branches transcribed literally
+    case GLRM_LOSS_ORDINAL_HINGE: { // :258-292.  The four branches of evaluate share one expression, n (n + 1) / 2 + (n + 1) f, and differ
+      // in n and f only: the operands are selected, the expression is evaluated once -- the same operations on the same values as the
+      // literal transcription (oracle/glrm_oracle.c), without four divergent code paths.
       const double mn = l.p0, mx = l.p1;
+#if defined(GLRM_ORDINAL_BRANCHY)
       double n, loss;
       if (u > mx - 1) {
         n = fmin(floor(u), mx - 1) - a;
@@ -166,12 +174,28 @@ __device__ __forceinline__ void loss_both(const LossDesc& l, double u, double a,
         const double g = u > a ? fmin(ceil(u), mx) - a : -(a - fmax(floor(u), mn));
         dL = s * g;
       }
+#else
+      const double fl = floor(u), ce = ceil(u);
+      const bool top = u > mx - 1, up = top || u > a, mid = u > mn + 1;
+      const double n_up = fmin(fl, top ? mx - 1 : mx) - a, f_up = top ? u - mx + 1 : u - fl;
+      const double n_dn = a - fmax(ce, mn + 1), f_dn = mid ? ce - u : mn + 1 - u;
+      const double n = up ? n_up : n_dn, f = up ? f_up : f_dn;
+      L = s * (n * (n + 1) / 2 + (n + 1) * f);
+      if (NEED_GRAD) {
+        const double g = u > a ? fmin(ce, mx) - a : -(a - fmax(fl, mn));
+        dL = s * g;
+      }
+#endif
       break;
     }
-    case GLRM_LOSS_LOGISTIC: { // :304,306 ; a is 1.0 (true) / 0.0 (false)
+    case GLRM_LOSS_LOGISTIC: { // :304,306 ; a is 1.0 (true) / 0.0 (false).  One exponential per observation: glrm_fastmath.hpp
+#if defined(GLRM_LOGISTIC_LIBM)
       const double aa = 2 * a - 1;
       L = s * log(1 + exp(-aa * u));
       if (NEED_GRAD) dL = -aa * s / (1 + exp(aa * u));
+#else
+      fm_logistic<NEED_GRAD>(s, 2 * a - 1, u, L, dL);
+#endif
       break;
     }
     case GLRM_LOSS_WEIGHTED_HINGE: { // :326-341

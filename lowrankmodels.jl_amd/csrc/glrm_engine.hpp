@@ -94,6 +94,8 @@ struct glrm_handle {
   int64_t *rowptr = nullptr, *colptr = nullptr;
   int32_t *colidx = nullptr, *rowidx = nullptr;
   double *rowvals = nullptr, *colvals = nullptr;
+  // GLRM_PROBLEM_BORROW_DEVICE_ARRAYS: false = the array above is the caller's (never freed, never written by the engine)
+  bool own_ptrs = true, own_rowview = true, own_colview = true;
   glrm_loss* losses = nullptr;
   int64_t n_losses = 0;
   bool loss_quad_uniform = false;
@@ -161,7 +163,7 @@ int glrm_setup_blocked(glrm_handle* h);
 int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only);
 
 // stable segmented sort of a view by tile index (glrm_tilesort.hip)
-int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals);
+int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals, bool free_old);
 
 // cached gather row sweep (glrm_cached.hip)
 int glrm_setup_cached(glrm_handle* h);                 // finalize: cached_want / cached_row from h->sig

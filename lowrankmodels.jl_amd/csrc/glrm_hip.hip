@@ -576,6 +576,9 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
   if (!h) return;
   DeviceGuard dg(h->device);
   (void)hipStreamSynchronize(h->stream);
+  if (!h->own_ptrs) h->rowptr = h->colptr = nullptr;        // borrowed arrays are the caller's
+  if (!h->own_rowview) { h->colidx = nullptr; h->rowvals = nullptr; }
+  if (!h->own_colview) { h->rowidx = nullptr; h->colvals = nullptr; }
   void* ptrs[] = {h->rowptr, h->colptr, h->colidx, h->rowidx, h->rowvals, h->colvals, h->losses, h->rx, h->ry,
                   h->alpharow, h->alphacol, h->oX, h->oY, h->oobjcol, h->oobjrow, h->partials, h->dscalar, h->dcount,
                   h->trials_r, h->accepts_r, h->trials_c, h->accepts_c, h->part, h->gsum, h->trialbuf, h->joldbuf,
@@ -694,7 +697,18 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   }
   hipStream_t st = h->stream;
   int rc;
-  if (!p->dense_A) {
+  const bool borrow = on_dev && (p->flags & GLRM_PROBLEM_BORROW_DEVICE_ARRAYS) != 0;
+  if (!p->dense_A && borrow) { // the caller's device arrays, read in place
+    h->own_ptrs = h->own_rowview = h->own_colview = false;
+    h->rowptr = const_cast<int64_t*>(p->rowptr); h->colptr = const_cast<int64_t*>(p->colptr);
+    h->colidx = const_cast<int32_t*>(p->colidx); h->rowvals = const_cast<double*>(p->rowvals);
+    h->rowidx = const_cast<int32_t*>(p->rowidx); h->colvals = const_cast<double*>(p->colvals);
+    HIPCK(hipMemcpyAsync(&h->nnz_r, p->rowptr + h->ml, 8, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(&h->nnz_c, p->colptr + h->nl, 8, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    if ((h->nnz_r > 0 && (!h->colidx || !h->rowvals)) || (h->nnz_c > 0 && (!h->rowidx || !h->colvals)))
+      return fail(GLRM_ERR_INVALID, "index / value arrays are NULL");
+  } else if (!p->dense_A) {
     if ((rc = dev_copy_in(&h->rowptr, p->rowptr, h->ml + 1, on_dev, st))) return rc;
     if ((rc = dev_copy_in(&h->colptr, p->colptr, h->nl + 1, on_dev, st))) return rc;
     if (on_dev) {
@@ -787,6 +801,8 @@ extern "C" int glrm_hip_create(glrm_handle** out, const glrm_problem* p, const g
     return fail(GLRM_ERR_INVALID, "shard ranges out of bounds");
   int rc = check_desc(p);
   if (rc) return rc;
+  if ((p->flags & GLRM_PROBLEM_BORROW_DEVICE_ARRAYS) && (!(p->flags & GLRM_PROBLEM_DEVICE_ARRAYS) || p->dense_A))
+    return fail(GLRM_ERR_INVALID, "GLRM_PROBLEM_BORROW_DEVICE_ARRAYS needs GLRM_PROBLEM_DEVICE_ARRAYS and observation lists (not dense_A)");
   if (p->dense_A) {
     // validated in glrm_setup_dense
   } else if (!(p->flags & GLRM_PROBLEM_DEVICE_ARRAYS)) {

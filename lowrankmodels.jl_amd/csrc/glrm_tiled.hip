@@ -132,15 +132,17 @@ int glrm_setup_tiled(glrm_handle* h) {
   const int64_t sort_limit = env_int("GLRM_HIP_TILE_SORT_BATCH", 0) > 0 ? env_int("GLRM_HIP_TILE_SORT_BATCH", 0) : 1500000000ll;
   if (want_row && !h->rows_sorted && may_sort && h->sig.max_row_len <= sort_limit) {
     if (h->sig_local.rows_unordered) {
-      const int rc = glrm_tile_sort_view(st, h->rowptr, h->ml, h->nnz_r, T0, h->n, &h->colidx, &h->rowvals);
+      const int rc = glrm_tile_sort_view(st, h->rowptr, h->ml, h->nnz_r, T0, h->n, &h->colidx, &h->rowvals, h->own_rowview);
       if (rc) return rc;
+      h->own_rowview = true;
     }
     h->rows_sorted = true;
   }
   if (want_col && !h->cols_sorted && may_sort && h->sig.max_col_len <= sort_limit) {
     if (h->sig_local.cols_unordered) {
-      const int rc = glrm_tile_sort_view(st, h->colptr, h->nl, h->nnz_c, T0, h->m, &h->rowidx, &h->colvals);
+      const int rc = glrm_tile_sort_view(st, h->colptr, h->nl, h->nnz_c, T0, h->m, &h->rowidx, &h->colvals, h->own_colview);
       if (rc) return rc;
+      h->own_colview = true;
     }
     h->cols_sorted = true;
   }
@@ -154,10 +156,13 @@ int glrm_setup_tiled(glrm_handle* h) {
     hipLaunchKernelGGL(group_rows_by_kind_kernel, dim3((unsigned)h->ml), dim3(64), 0, st, h->rowptr, h->colidx, h->rowvals, h->ml, T0, h->losses, oidx, ovals);
     HIPCK(hipGetLastError());
     HIPCK(hipStreamSynchronize(st));
-    (void)hipFree(h->colidx);
-    (void)hipFree(h->rowvals);
+    if (h->own_rowview) {
+      (void)hipFree(h->colidx);
+      (void)hipFree(h->rowvals);
+    }
     h->colidx = oidx;
     h->rowvals = ovals;
+    h->own_rowview = true;
   }
   if (h->tiled_row && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_UDESC", 1)) {
     // distinct loss descriptors of the model; with at most 256 of them every entry of the row view carries a one-byte id and the

@@ -37,7 +37,8 @@ struct MinusBase { // segment offsets relative to the batch's first entry
 // hipCUB counts items and segments in int, so a view is sorted in batches of whole segments with at most `limit` entries each
 // (1.5e9; GLRM_HIP_TILE_SORT_BATCH overrides, the tests use it to exercise the batching on small inputs); the scratch arrays are
 // sized for one batch.  A single segment longer than the limit cannot be sorted this way (GLRM_ERR_UNSUPPORTED: gather sweeps).
-int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals) {
+// free_old = false: the old arrays are the caller's (GLRM_PROBLEM_BORROW_DEVICE_ARRAYS) and stay untouched.
+int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals, bool free_old) {
   if (nnz <= 0 || nseg <= 0) return GLRM_OK;
   int64_t limit = env_int("GLRM_HIP_TILE_SORT_BATCH", 0);
   if (limit <= 0) limit = 1500000000ll;
@@ -91,8 +92,10 @@ int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_
     hipLaunchKernelGGL(apply_perm_kernel, dim3(4096), dim3(256), 0, st, p1, cnt, *idx + base, *vals + base, oidx + base, ovals + base);
   }
   if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "tile sort kernels failed"));
-  (void)hipFree(*idx);
-  (void)hipFree(*vals);
+  if (free_old) {
+    (void)hipFree(*idx);
+    (void)hipFree(*vals);
+  }
   *idx = oidx;
   *vals = ovals;
   return cleanup(GLRM_OK);

@@ -111,11 +111,18 @@ class DeviceWorkload:
         sig.max_row_len, sig.max_col_len = self.q, longest
         return sig
 
-    def problem(self) -> _capi.ProblemArrays:
+    def list_bytes(self) -> int:
+        """Bytes of the two Omega views (index + value per observation)."""
+        return (self.nnz_rows + self.nnz_cols) * 12
+
+    def problem(self, borrow=False) -> _capi.ProblemArrays:
+        """borrow=True: the engine reads these tensors in place (GLRM_PROBLEM_BORROW_DEVICE_ARRAYS) -- keep the workload alive and do
+        NOT call free_sources() while the handle exists.  For problems whose lists do not fit HBM twice (C5: 120 GB)."""
         p = lambda t: int(t.data_ptr())
+        flags = _capi.PROBLEM_DEVICE_ARRAYS | (_capi.PROBLEM_BORROW_DEVICE_ARRAYS if borrow else 0)
         return _capi.ProblemArrays(self.m, self.n, self.k, p(self.rowptr), p(self.colidx), p(self.rowvals), p(self.colptr),
                                    p(self.rowidx), p(self.colvals), self.losses, self.rx, self.ry, self.rows[0], self.rows[1],
-                                   self.cols[0], self.cols[1], flags=_capi.PROBLEM_DEVICE_ARRAYS)
+                                   self.cols[0], self.cols[1], flags=flags)
 
     def init_factors(self, ld, init_seed=1):
         """X0 (ld x m) and Y0 (ld x n) iid N(0,1) on the device, padding rows zero."""

@@ -235,3 +235,38 @@ def test_deferred_handle_refuses_to_step_before_finalize():
         api.step_x(h, 0.01)
     finally:
         api.destroy(h)
+
+
+# ------------------------------------------------------------------------------------------------ lists borrowed in place
+
+@pytest.mark.parametrize("tiled,mix", [(1, 0), (2, 0), (2, 1)])
+def test_borrowed_device_arrays_give_the_bits_of_copied_ones(tiled, mix):
+    """GLRM_PROBLEM_BORROW_DEVICE_ARRAYS: the engine reads the caller's device arrays in place (what lets BASELINE configs[4], 120 GB of
+    lists, run on one 288 GB device); views it has to reorder (mix = 1: the row view regrouped by loss kind) get a private copy.  Same
+    bits as the copying hand-over, and the caller's arrays are untouched."""
+    import torch
+    from lowrankmodels.jl_amd import synth
+    m, n, k, q = 4000, 1200, 32, 60
+    w = synth.DeviceWorkload(m, n, k, q, loss_mix=mix)
+    api = hip()
+    params = L.ProxGradParams(max_iter=5)
+    snap = [t.clone() for t in (w.rowptr, w.colidx, w.rowvals, w.colptr, w.rowidx, w.colvals)]
+    out = []
+    for borrow in (False, True):
+        h = api.create(w.problem(borrow=borrow), tiled=tiled)
+        ld = api.factor_ld(h)
+        dX, dY = w.init_factors(ld)
+        X = np.asfortranarray(0.3 * dX.cpu().numpy().reshape(m, ld)[:, :k].T)
+        Y = np.asfortranarray(0.3 * dY.cpu().numpy().reshape(n, ld)[:, :k].T)
+        obj, _ = api.fit(h, params, X, Y)
+        st = api.kernel_stats(h)
+        api.destroy(h)
+        out.append((obj, X, Y, st["tiled"]))
+        for a, b in zip(snap, (w.rowptr, w.colidx, w.rowvals, w.colptr, w.rowidx, w.colvals)):
+            assert torch.equal(a, b)
+    assert out[0][3] == out[1][3] == (3 if tiled == 2 else 0)
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    with pytest.raises(_capi.GLRMError):   # host arrays cannot be borrowed
+        pa, X0, Y0 = ragged_problem(np.random.default_rng(1), 30, 20, 4, 5)
+        pa.flags = _capi.PROBLEM_BORROW_DEVICE_ARRAYS
+        api.create(pa)
