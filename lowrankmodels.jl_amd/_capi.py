@@ -445,7 +445,8 @@ class ProblemArrays:
 
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_PKG_DIR, "libglrm_hip.so")
+# GLRM_HIP_LIB_PATH: another BUILD of the same engine (tests/perf/ab_lib.py, variant builds of build.py) -- never another engine
+HIP_LIB_PATH = os.environ.get("GLRM_HIP_LIB_PATH") or os.path.join(_PKG_DIR, "libglrm_hip.so")
 _hip_api = None
 
 

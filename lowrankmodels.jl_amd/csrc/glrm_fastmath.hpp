@@ -1,14 +1,9 @@
 // glrm_fastmath.hpp -- fp64 exp / log1p / reciprocal for the loss formulas of the sweep kernels, written out so that
-//   * LogisticLoss (src/losses.jl:298-311) costs ONE exponential per observation: with z = (2a-1) u and t = exp(-|z|) in (0, 1],
-//         evaluate = scale * log(1 + exp(-z))   = scale * (max(-z, 0) + log1p(t))
-//         grad     = -(2a-1) * scale / (1 + exp(z)) = -(2a-1) * scale * (z >= 0 ? t / (1 + t) : 1 / (1 + t))
-//     instead of exp + log + exp + an IEEE division (the ocml calls the compiler would inline: ~105 fp64 VALU instructions and ~20 live
-//     registers per lane; here ~60 and ~10);
+//   * LogisticLoss (src/losses.jl:298-311) costs ONE exponential per observation (fm_logistic below) instead of exp + log + exp + an
+//     IEEE division (the ocml calls the compiler would inline);
 //   * nothing is called: no table, no special-case branches -- straight-line FMA chains the scheduler can interleave with LDS reads.
-// Accuracy (tools/check_fastmath.cpp, run on the host against libm over 4e6 points per function): exp <= 1.2e-16 relative on
-// [-745, 709], log1p <= 2.3e-16 relative on (0, 1], the logistic loss and its derivative <= 4e-16 relative to the exact value.  The
-// reference's own `log(1 + exp(-z))` LOSES digits once exp(-z) < 1e-8 (1 + tiny rounds): there the two differ by up to 1.1e-16
-// ABSOLUTE per observation (relative to a loss value of that size), which is far inside the 1e-5 contract on objectives and factors.
+// Accuracy (tools/check_fastmath.cpp, run on the host against libm over 4e6 points per function): see the numbers it prints
+// (exp and log ~1e-16 relative; the logistic loss and derivative against the reference's literal double formula likewise).
 // The CPU oracle keeps libm and the reference's literal formula; parity tests compare against it.
 #pragma once
 
@@ -65,29 +60,43 @@ GLRM_FM double fm_exp(double x) {
   return ldexp(p, (int)n);
 }
 
-// log1p(t) for t in [0, 1]: log(1 + t) = 2 atanh(t / (2 + t)); above sqrt(2) - 1 the argument is halved first,
-// log(1 + t) = ln 2 + log1p((t - 1) / 2), so that |s| = |tt / (2 + tt)| <= 0.1716 and eleven terms of the atanh series suffice.
-GLRM_FM double fm_log1p_unit(double t) {
-  const bool hi = t > 0.41421356237309503;
-  const double tt = hi ? (t - 1.0) * 0.5 : t;
-  const double s = tt * fm_rcp(2.0 + tt);
+// log(w) for w in [1, Inf]: w = 2^e m with m in [sqrt(1/2), sqrt(2)), log(m) = 2 atanh((m - 1) / (m + 1)) with |(m - 1) / (m + 1)| <= 0.1716
+// (eleven terms of the series), log(w) = e ln2 + log(m) with ln2 split in two.  Near w = 1 the result keeps its relative accuracy
+// (e = 0 and m - 1 is exact).  log(Inf) = Inf, log(NaN) = NaN.
+GLRM_FM double fm_log_ge1(double w) {
+  int e;
+  double m = frexp(w, &e);                     // m in [0.5, 1)
+  const bool lo = m < 0.70710678118654752440;
+  m = lo ? m + m : m;                          // [sqrt(1/2), sqrt(2))
+  const double ed = (double)(lo ? e - 1 : e);
+  const double f = m - 1.0;
+  const double s = f * fm_rcp(2.0 + f);
   const double s2 = s * s;
   double p = fm_atanh_c[0];
 #pragma unroll
   for (int i = 1; i < 10; ++i) p = fma(p, s2, fm_atanh_c[i]);
   p = fma(p, s2 * s, s);                       // s + s^3 (1/3 + ...)
-  return fma(2.0, p, hi ? 0.693147180559945309417 : 0.0);
+  const double r = fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, p + p));
+  return w < __builtin_inf() ? r : w;          // Inf (frexp of Inf is unspecified) and NaN pass through
 }
 
-// LogisticLoss from one exponential (see the header).  aa = 2a - 1 in {-1, +1}.
+// LogisticLoss (src/losses.jl:298-311) from ONE exponential, in the reference's own structure so that its rounding is reproduced:
+// with z = (2a-1) u and E = exp(-z), w = 1 + E (rounded as in the reference),
+//     evaluate = scale * log(1 + exp(-z))        = scale * log(w)            -- exactly 0 once E < 2^-53, Inf once exp overflows
+//     grad     = -(2a-1) scale / (1 + exp(z))    = -(2a-1) scale * E / w     -- exp(z) = 1 / E; for E > 1 as 1 - 1 / w (no Inf * 0)
+// (the line search compares sums of these with a strict `<`: a loss that is "more accurate than the reference" -- log1p(E), or a
+// finite value where the reference overflows -- takes different decisions; found by tests/test_gpu_fuzz.py).
 template <bool NEED_GRAD>
 GLRM_FM void fm_logistic(double scale, double aa, double u, double& L, double& dL) {
   const double z = aa * u;
-  const double t = fm_exp(z < 0 ? z : -z);     // exp(-|z|) in (0, 1]; NaN stays NaN
-  L = scale * ((z < 0 ? -z : 0.0) + fm_log1p_unit(t));
+  const double E = fm_exp(-z);
+  const double w = 1.0 + E;
+  L = scale * fm_log_ge1(w);
   if (NEED_GRAD) {
-    const double r = fm_rcp(1.0 + t);
-    dL = -aa * scale * (z < 0 ? r : t * r);
+    const bool fin = w < __builtin_inf();
+    const double rw = fm_rcp(fin ? w : 1.0);   // the Newton steps of fm_rcp would turn 1 / Inf into NaN
+    const double frac = E > 1.0 ? 1.0 - (fin ? rw : 0.0) : E * rw; // E / (1 + E) = 1 / (1 + exp(z)); NaN stays NaN
+    dL = -aa * scale * frac;
   }
 }
 

@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdint>
+#include <initializer_list>
 #include "../lowrankmodels.jl_amd/csrc/glrm_fastmath.hpp"
 
 static uint64_t mix(uint64_t z) { z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
@@ -10,6 +11,7 @@ static double unif(uint64_t i) { return ((double)(mix(i) >> 11) + 0.5) / 9007199
 int main() {
   const int N = 4000000;
   double e_exp = 0, e_l1p = 0, e_L = 0, e_dL = 0, e_Lref = 0, a_Lref = 0;
+  long nonzero_where_ref_zero = 0;
   for (int i = 0; i < N; ++i) {
     const double x = -745.0 + 1454.0 * unif(i);
     const long double ex = expl((long double)x);
@@ -20,31 +22,36 @@ int main() {
     const double errs = (double)fabsl(((long double)glrm::fm_exp(xs) - es) / es);
     if (errs > e_exp) e_exp = errs;
     const double t = unif(i + 123456789);
-    const long double l1 = log1pl((long double)t);
-    const double err2 = (double)fabsl(((long double)glrm::fm_log1p_unit(t) - l1) / l1);
-    if (err2 > e_l1p) e_l1p = err2;
-    const double tiny = ldexp(t, -(int)(mix(i) % 60));
-    const long double l2 = log1pl((long double)tiny);
-    const double err3 = (double)fabsl(((long double)glrm::fm_log1p_unit(tiny) - l2) / l2);
-    if (err3 > e_l1p) e_l1p = err3;
+    const double w1 = 1.0 + t * (i & 1 ? 1.0 : ldexp(1.0, -(int)(mix(i) % 50)));            // [1, 2], dense near 1
+    const double w2 = ldexp(1.0 + t, (int)(mix(i + 5) % 1023));                              // the whole range above 1
+    for (double w : {w1, w2}) {
+      const long double l1 = logl((long double)w);
+      if (l1 > 0) { const double err2 = (double)fabsl(((long double)glrm::fm_log_ge1(w) - l1) / l1); if (err2 > e_l1p) e_l1p = err2; }
+    }
     // logistic: u in [-45, 45], both labels
     const double u = -45.0 + 90.0 * unif(i + 424242), aa = (i & 1) ? 1.0 : -1.0, sc = 0.7;
     double L, dL;
     glrm::fm_logistic<true>(sc, aa, u, L, dL);
     const long double zz = (long double)aa * u;
-    const long double Lx = sc * log1pl(expl(-zz)), dLx = -aa * sc / (1.0L + expl(zz));
-    const double r1 = (double)fabsl((L - Lx) / Lx), r2 = (double)fabsl((dL - dLx) / dLx);
-    if (r1 > e_L) e_L = r1;
+    const long double dLx = -aa * sc / (1.0L + expl(zz));
+    const double r2 = (double)fabsl((dL - dLx) / dLx);
     if (r2 > e_dL) e_dL = r2;
-    const double Lref = sc * log(1 + exp(-aa * u)); // the reference's literal formula in double
+    const double Lref = sc * log(1 + exp(-aa * u)), dLref = -aa * sc / (1 + exp(aa * u)); // the reference's literal formulas in double
     const double ad = fabs(L - Lref);
     if (ad > a_Lref) a_Lref = ad;
-    if (Lref > 1e-6) { const double rr = ad / Lref; if (rr > e_Lref) e_Lref = rr; }
+    if (Lref > 0) { const double rr = ad / Lref; if (rr > e_Lref) e_Lref = rr; } else if (L != 0) ++nonzero_where_ref_zero;
+    const double r1 = dLref != 0 ? fabs((dL - dLref) / dLref) : 0; if (r1 > e_L) e_L = r1;
   }
   double L, dL;
   glrm::fm_logistic<true>(1.0, 1.0, NAN, L, dL);
-  printf("max rel err: exp %.3g  log1p %.3g  logistic L %.3g  dL %.3g\n", e_exp, e_l1p, e_L, e_dL);
-  printf("vs the reference's double formula: max abs %.3g, max rel (L > 1e-6) %.3g; NaN in -> %g %g\n", a_Lref, e_Lref, L, dL);
+  printf("max rel err vs long double: exp %.3g  log (w >= 1) %.3g  logistic derivative %.3g\n", e_exp, e_l1p, e_dL);
+  printf("logistic vs the reference's literal double formulas: loss max abs %.3g, max rel %.3g (nonzero where the reference is exactly 0: %ld); derivative max rel %.3g; NaN in -> %g %g\n", a_Lref, e_Lref, nonzero_where_ref_zero, e_L, L, dL);
+  glrm::fm_logistic<true>(1.0, 1.0, -800.0, L, dL);
+  printf("z = -800 (exp overflows in the reference): L %g (reference Inf) dL %g (reference -1)\n", L, dL);
+  glrm::fm_logistic<true>(1.0, 1.0, 800.0, L, dL);
+  printf("z = +800: L %g (reference 0) dL %g (reference -0)\n", L, dL);
+  glrm::fm_logistic<true>(1.0, 1.0, 40.0, L, dL);
+  printf("z = +40: L %g (reference %g)\n", L, log(1 + exp(-40.0)));
   printf("exp(800) %g exp(-800) %g exp(0) %.17g exp(1) %.17g\n", glrm::fm_exp(800), glrm::fm_exp(-800), glrm::fm_exp(0.0), glrm::fm_exp(1.0));
   glrm::fm_logistic<true>(1.0, 1.0, 1.0, L, dL);
   printf("logistic(1, true) %.17g (reference KAT 0.31326168751822286)  grad %.17g\n", L, dL);
