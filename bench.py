@@ -169,23 +169,38 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
     return dict(best=best, candidates=cands, algorithmic_GBps=alg / t / 1e9)
 
 
-def step_model(fam_r, fam_c, nnz_r, nnz_c, nseg_r, nseg_c, k, ld, ms_per_step, world):
+def family_step_bytes(family, nnz, nseg, nopp, k, ld):
+    """Bytes one half-step of the family has to bring in from beyond the CU: the (index, value) stream once per pass, the own factor
+    read and written, and the opposing k-vectors -- once per update and pass for the families that gather them (gather, phase-aligned
+    passes, general sweeps), once per update for the cached row sweep, once per half-step for the LDS-tiled sweeps (the tiles are
+    shared by the 256 segments of a workgroup and re-read from L2 by the others)."""
+    P = passes_priced(family)
+    own = 2 * nseg * ld * 8
+    if family == "tiled":
+        return P * 12 * nnz + own + nopp * ld * 8
+    return P * (12 + 8 * k) * nnz + own
+
+
+def step_model(fam_r, fam_c, nnz_r, nnz_c, nseg_r, nseg_c, k, ld, ms_per_step, world, m=0, n=0):
     """The bytes ONE outer iteration of one rank has to move under the kernel families that ran it, and the self-check that the step's
     wall-clock does not beat the HBM peak with them.  SURVEY.md 8(d) prices every half-step at P = 2 passes x (12 + 8k) B per update;
-    the cached row sweep makes ONE pass (the row's list and vectors stay in registers for every trial), so with it the 8(d) figure is
-    no longer a lower bound for the X half-step -- published here so that the check can be redone from the JSON alone."""
-    px, py = passes_priced(fam_r), passes_priced(fam_c)
-    bx = nnz_r * px * (12 + 8 * k) + 2 * nseg_r * ld * 8
-    by = nnz_c * py * (12 + 8 * k) + 2 * nseg_c * ld * 8
+    the cached row sweep makes ONE pass (the row's list and vectors stay in registers for every trial) and the LDS-tiled sweeps fetch
+    a k-vector once per workgroup instead of once per update, so with them the 8(d) figure is no lower bound -- the model the step
+    actually obeys is published here so that the check can be redone from the JSON alone."""
+    bx = family_step_bytes(fam_r, nnz_r, nseg_r, n, k, ld)
+    by = family_step_bytes(fam_c, nnz_c, nseg_c, m, k, ld)
     t = ms_per_step * 1e-3
     gbps = (bx + by) / t / 1e9
     survey = (nnz_r + nnz_c) * 2 * (12 + 8 * k) / t / 1e9
-    return {"passes": {"x": px, "y": py}, "bytes_per_step_per_rank": {"x": bx, "y": by, "total": bx + by},
-            "bytes_are": "passes x (12 + 8k) B per update + own factor read and write, per rank (rank 0's shard)",
+    return {"passes": {"x": passes_priced(fam_r), "y": passes_priced(fam_c)}, "families": {"x": fam_r, "y": fam_c},
+            "bytes_per_step_per_rank": {"x": bx, "y": by, "total": bx + by},
+            "bytes_are": "per family (bench.py: family_step_bytes): stream + own factor r/w + opposing vectors per update and pass (gather / "
+                         "phase-aligned / general), per update (cached rows) or per half-step (LDS-tiled); rank 0's shard",
             "GBps": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBS, "within_peak": bool(gbps <= HBM_PEAK_GBS),
             "survey_8d_P2_GBps": survey,
-            "note": ("includes host round trips, the objective sum and (N > 1) the exchange in ms_per_step; survey_8d_P2_GBps may exceed the "
-                     "peak when a family makes fewer than two passes -- it is kept for comparison with earlier rounds only")}
+            "note": ("ms_per_step includes host round trips, the objective sum and (N > 1) the exchange; survey_8d_P2_GBps (every update "
+                     "priced at 2 x (12 + 8k) B) exceeds the peak whenever a family re-uses the opposing vectors on chip -- kept for "
+                     "comparison with earlier rounds only")}
 
 
 # ----------------------------------------------------------------------------- CPU legs (rank 0, N = 1 only)
@@ -720,7 +735,7 @@ def main():
                         "col_sweep": None if not rl_c else {kk: rl_c["best"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac")},
                         "mean_trials_per_row": st["trials_x"] / max(args.steps * nseg_r, 1),
                         "mean_trials_per_col": st["trials_y"] / max(args.steps * nseg_c, 1)},
-            "step_model": step_model(fam_r, fam_c, nnz_r, nnz_c, nseg_r, nseg_c, k, ld, 1e3 * elapsed / args.steps, world) if args.config != "C3" else None,
+            "step_model": step_model(fam_r, fam_c, nnz_r, nnz_c, nseg_r, nseg_c, k, ld, 1e3 * elapsed / args.steps, world, m=m, n=n) if args.config != "C3" else None,
             "objective": {"initial": obj0, "after_warmup_and_steps": objs[-1] if objs else None},
             "to_reference_stop": conv,
             "setup_s": {"generate": t_gen, "create": t_create, "lists_borrowed_in_place": bool(borrow)},

@@ -103,6 +103,9 @@ def test_step_model_reproduces_the_round_two_check():
     assert sm["passes"] == {"x": 1, "y": 2} and sm["within_peak"]
     assert sm["survey_8d_P2_GBps"] == pytest.approx(9157, abs=5) and sm["GBps"] == pytest.approx(6913, abs=10)
     assert bench.step_model("gather", "gather", 10**9, 10**9, 10_000_000, 100_000, 64, 64, 290.0, 1)["passes"] == {"x": 2, "y": 2}
+    # LDS-tiled sweeps (C5 at its stated size, 582.8 ms): the k-vectors are fetched per workgroup, not per update -- no 9.2 TB/s artefact
+    t = bench.step_model("tiled", "tiled", 5 * 10**9, 5 * 10**9, 5_000_000, 50_000, 32, 32, 582.8, 1, m=5_000_000, n=50_000)
+    assert t["within_peak"] and t["survey_8d_P2_GBps"] > 8000 and t["GBps"] == pytest.approx(420, abs=10)
 
 
 def test_quad_gram_prices_the_flop_that_are_left():
