@@ -149,7 +149,12 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
   if (a.nseg <= 0) return GLRM_OK;
   if (rows) {
     const size_t lds = multi_lds_doubles(true, 1, h->kp, h->dmax, a.lgP) * 8;
-    if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, true>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+    // every embedding dimension <= 8: the opposing block of an observation is held in registers (glrm_multi.hpp: multi_pass, RD)
+    const bool regs = h->dmax <= 8 && env_int("GLRM_HIP_MULTI_REGS", 1);
+    if (regs) {
+      if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, true, 8>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+      else hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false, 8>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+    } else if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, true>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
     else hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
   } else {
     const int rc = setup_split(h); // decides once per handle whether the columns are long enough to split
@@ -157,8 +162,8 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
     if (h->col_nsplit > 1) return run_split_cols(h, a);
     const size_t lds = multi_lds_doubles(false, 8, h->kp, h->dmax, a.lgP) * 8;
     if (h->dmax <= 8) {
-      if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, true>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
-      else hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, false>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+      if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, true, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+      else hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, false, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
     } else {
       if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, GLRM_MAX_EMBEDDING_DIM, true>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
       else hipLaunchKernelGGL((multi_sweep_kernel<false, 8, GLRM_MAX_EMBEDDING_DIM, false>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);

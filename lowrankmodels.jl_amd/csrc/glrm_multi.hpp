@@ -335,8 +335,8 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
   // stage 2: per-lane term, slot sum
   double term = 0.0, dLb = 0.0;
   if (in && vec) {
-    if (kind == GLRM_LOSS_MULTINOMIAL) term = exp(u - mx);
-    else if (kind == GLRM_LOSS_ORDISTIC) term = exp(-(u * u) - mx);
+    if (kind == GLRM_LOSS_MULTINOMIAL) term = fm_exp(u - mx);          // arguments <= 0 (glrm_fastmath.hpp)
+    else if (kind == GLRM_LOSS_ORDISTIC) term = fm_exp(-(u * u) - mx);
     else if (kind == GLRM_LOSS_OVA || kind == GLRM_LOSS_BVS) {
       const bool truth = kind == GLRM_LOSS_OVA ? a == sub : a > sub;
       loss_both<GRAD, false>(bin_loss_of(l), u, truth ? 1.0 : 0.0, term, dLb);
@@ -354,7 +354,7 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
     double w = -TOL;
     if (ord && in) for (int i = 0; i <= sub; ++i) { const double wi = us[i] + i * TOL; w = wi < w ? wi : w; }
     const double up = w - sub * TOL;
-    const double ea = ord ? exp(up) : 0.0;
+    const double ea = ord ? fm_exp(up) : 0.0;
     int hi = a > 0 ? a - 1 : 0, lo = a < dd ? a : dd - 1; // lanes of u'_{a-1}, u'_a
     hi = hi < 0 ? 0 : (hi > P - 1 ? P - 1 : hi);
     lo = lo < 0 ? 0 : (lo > P - 1 ? P - 1 : lo);
@@ -370,9 +370,9 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
     loss_both<GRAD, TRIG>(l, u0, av, L, cg);
   } else if (vec) {
     switch (kind) {
-      case GLRM_LOSS_MULTINOMIAL:
-        L = s * (log(se) + (mx - ua));
-        if (GRAD && in) cg = s * ((sub == a ? -1.0 : 0.0) + term / se);
+      case GLRM_LOSS_MULTINOMIAL: // se in [1, d]: the slot's largest term is exp(0)
+        L = s * (fm_log_ge1(se) + (mx - ua));
+        if (GRAD && in) cg = s * ((sub == a ? -1.0 : 0.0) + term * fm_rcp(se));
         break;
       case GLRM_LOSS_OVA:
       case GLRM_LOSS_BVS:
@@ -380,8 +380,8 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
         if (GRAD && in) cg = s * dLb;
         break;
       case GLRM_LOSS_ORDISTIC:
-        L = s * ((ua * ua + mx) + log(se));
-        if (GRAD && in) cg = s * ((sub == a ? 2 * u : 0.0) - 2 * u * term / se);
+        L = s * ((ua * ua + mx) + fm_log_ge1(se));
+        if (GRAD && in) cg = s * ((sub == a ? 2 * u : 0.0) - 2 * u * term * fm_rcp(se));
         break;
       default: { // GLRM_LOSS_MULTINOMIAL_ORDINAL
         double g = 0.0;
@@ -412,7 +412,13 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
 // up in lane j), the loss and its d-vector gradient are evaluated lane-parallel (vloss_lanes), and lane `sub` accumulates
 // component `sub` of the gradient.  Index / value loads run two wave-iterations ahead and (columns) the opposing row
 // one iteration ahead.  Slot partials are combined in slot order, wave partials in wave order.
-template <bool ROWS, int NW, bool GRAD, int GDC, bool TRIG>
+//
+// RD > 0 (every embedding dimension of the model <= RD = 8): the d vectors an observation meets live in REGISTERS -- lane `sub` holds
+// component `sub` of each -- instead of LDS.  Rows: the opposing block is read from memory straight into registers (no staging pass,
+// no LDS round trip between the load and the dot products); columns: the own block is read out of LDS once per pass.  The components
+// of the d-vector gradient come back by lane shuffles instead of through LDS.  Per observation that removes d LDS writes, 2 d LDS reads
+// and three wave barriers; every product and every sum is formed in the same order as on the LDS path (same bits).
+template <bool ROWS, int NW, bool GRAD, int GDC, bool TRIG, int RD = 0>
 __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, const double* own, double* wbase, double* Gt, double* red,
                                     const LossDesc& lseg, int dseg) {
   constexpr int NT = NW * 64, GD = ROWS ? 1 : GDC; // GDC >= the largest embedding dimension of the problem
@@ -426,6 +432,11 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
   double* cgs = us + 32;
   const bool comp = sub < k;
   const double xown = (ROWS && comp) ? own[sub] : 0.0;
+  double yreg[RD > 0 ? RD : 1]; // RD > 0: component `sub` of the block's vectors
+  if constexpr (RD > 0 && !ROWS) {
+#pragma unroll
+    for (int j = 0; j < RD; ++j) yreg[j] = (j < DO && comp) ? own[j * S + sub] : 0.0;
+  }
   double lsum = 0.0;
   double G[GD];
 #pragma unroll
@@ -464,25 +475,54 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
       const int64_t li = a.loss_single ? 0 : id;
       l = load_loss(a.losses, li);
       d = a.losses[li].dim > 1 ? a.losses[li].dim : 1;
-      if (valid) {
-        const double* Yb = a.other + a.ystart[id] * kp; // the d vectors of column id are contiguous
-        for (int i = sub; i < d * kp; i += P) { const int j = i / kp, c = i - j * kp; oth[j * S + c] = Yb[i]; }
+      const double* Yb = a.other + a.ystart[id] * kp; // the d vectors of column id are contiguous (id: clamped into the list, always valid)
+      if constexpr (RD > 0) {
+#pragma unroll
+        for (int j = 0; j < RD; ++j) yreg[j] = (j < d && comp) ? Yb[j * kp + sub] : 0.0;
+      } else {
+        if (valid) {
+          for (int i = sub; i < d * kp; i += P) { const int j = i / kp, c = i - j * kp; oth[j * S + c] = Yb[i]; }
+        }
+        wave_sync();
       }
-      wave_sync();
     }
     const double* blk = ROWS ? oth : own; // the d vectors this observation meets
     const int dd = valid ? d : 0;
     // u_j = <x, y_j>: one slot reduction per j, uniform trip count (the largest d among the wave's slots)
     double u = 0.0, u0 = 0.0;
-    for (int j = 0; __any(j < dd); ++j) {
-      const double r = slot_reduce((comp && j < dd) ? xc * blk[j * S + sub] : 0.0, lg, OpSum());
-      u = (sub == j && j < dd) ? r : u;
-      u0 = j == 0 ? r : u0;
+    if constexpr (RD > 0) {
+#pragma unroll
+      for (int j = 0; j < RD; ++j) {
+        if (!__any(j < dd)) break;
+        const double r = slot_reduce((comp && j < dd) ? xc * yreg[j] : 0.0, lg, OpSum());
+        u = (sub == j && j < dd) ? r : u;
+        u0 = j == 0 ? r : u0;
+      }
+    } else {
+      for (int j = 0; __any(j < dd); ++j) {
+        const double r = slot_reduce((comp && j < dd) ? xc * blk[j * S + sub] : 0.0, lg, OpSum());
+        u = (sub == j && j < dd) ? r : u;
+        u0 = j == 0 ? r : u0;
+      }
     }
     double cg = 0.0;
     const double L = obs_loss<GRAD, TRIG>(l, u, u0, av, dd, sub, lg, lane - sub, us, cg);
     lsum += L;
-    if constexpr (GRAD) {
+    if constexpr (GRAD && RD > 0) {
+      // component j of the observation's gradient sits in lane j of the slot: fetch it by a shuffle (executed by the whole wave,
+      // uniform trip count) and accumulate in the order j = 0, 1, ... of the LDS path.  A scalar loss has cg uniform over its slot.
+      double g0 = G[0];
+#pragma unroll
+      for (int j = 0; j < RD; ++j) {
+        if (!__any(j < dd)) break;
+        const double cj = __shfl(cg, (lane - sub) + j, 64);
+        if (valid && comp && j < d) {
+          if constexpr (ROWS) g0 = fma(cj, yreg[j], g0); // g += Y_f * curgrad
+          else G[j < GD ? j : 0] = fma(cj, xc, G[j < GD ? j : 0]); // G += x * curgrad'
+        }
+      }
+      if constexpr (ROWS) G[0] = g0;
+    } else if constexpr (GRAD) {
       const bool vec = valid && d > 1;
       if (__any(vec)) {
         if (vec && sub < d) cgs[sub] = cg;
@@ -503,7 +543,7 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
         }
       }
       wave_sync();
-    } else if constexpr (ROWS) {
+    } else if constexpr (ROWS && RD == 0) {
       wave_sync(); // oth is overwritten by the next staging
     }
     t += stride;
@@ -549,7 +589,7 @@ __host__ __device__ inline size_t multi_lds_doubles(bool rows, int nw, int kp, i
 }
 
 // TRIG = false: the scalar-loss columns of the model hold no PeriodicLoss (LOSS_*_NOTRIG in glrm_engine.hpp)
-template <bool ROWS, int NW, int GDC, bool TRIG>
+template <bool ROWS, int NW, int GDC, bool TRIG, int RD = 0>
 __global__ void __launch_bounds__(NW * 64, NW == 1 ? 4 : 2) multi_sweep_kernel(const MultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NT = NW * 64;
@@ -581,11 +621,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 4 : 2) multi_sweep_kernel(c
   const glrm_reg rg = a.regs[a.reg_single ? 0 : s];
 
   if (a.mode == 1) { // losses only
-    const double tot = multi_pass<ROWS, NW, false, GDC, TRIG>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
+    const double tot = multi_pass<ROWS, NW, false, GDC, TRIG, RD>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
     if (tid == 0 && a.obj) a.obj[gseg] = tot;
     return;
   }
-  const double loss_old = multi_pass<ROWS, NW, true, GDC, TRIG>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
+  const double loss_old = multi_pass<ROWS, NW, true, GDC, TRIG, RD>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
   const double l1 = (double)(e - b) + 1;
   if (a.mode == 2) { // sparse_proxgrad.jl:72-78 / :94-99: scale the gradient, add, prox -- no line search
     const double st = a.fixed_alpha / l1;
@@ -609,7 +649,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 4 : 2) multi_sweep_kernel(c
     }
     __syncthreads();
     block_prox<NW>(ownB, S, k, DO, rg, stepsize, tmp);
-    const double nloss = multi_pass<ROWS, NW, false, GDC, TRIG>(a, b, e, ownB, wbase, Gt, red, lseg, dseg);
+    const double nloss = multi_pass<ROWS, NW, false, GDC, TRIG, RD>(a, b, e, ownB, wbase, Gt, red, lseg, dseg);
     const double nobj = nloss + block_reg_eval<NW>(ownB, S, k, DO, rg, red);
     ++ntr;
     if (nobj < obj) {
@@ -679,7 +719,7 @@ __global__ void __launch_bounds__(512, (GRAD && GDC > 8) ? 2 : 4) multi_colpass_
   int64_t b = b0 + (int64_t)y * sa.chunk, e = b + sa.chunk;
   b = b < e0 ? b : e0;
   e = e < e0 ? e : e0;
-  const double tot = multi_pass<false, NW, GRAD, GDC, TRIG>(a, b, e, own, wbase, Gt, red, lseg, dseg);
+  const double tot = multi_pass<false, NW, GRAD, GDC, TRIG, (GDC <= 8 ? 8 : 0)>(a, b, e, own, wbase, Gt, red, lseg, dseg);
   if (tid == 0) sa.part_loss[s * sa.nsplit + y] = tot;
   if constexpr (GRAD) {
     double* pg = sa.part_G + ((size_t)s * sa.nsplit + y) * a.dmax * kp;
