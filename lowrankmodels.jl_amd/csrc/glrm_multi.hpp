@@ -18,6 +18,10 @@
 
 #include "glrm_device.hpp"
 
+#ifndef GLRM_MULTI_PF
+#define GLRM_MULTI_PF 0 // software-pipeline depth of the row sweep with register-resident blocks (multi_pass); measured: 0 is fastest (the extra registers spill)
+#endif
+
 namespace glrm {
 
 struct MultiArgs {
@@ -456,6 +460,32 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
       xr_n = a.other[(int64_t)id_nn * kp + (comp ? sub : 0)];
     }
   }
+  // Rows with register-resident blocks: the chain index -> (loss descriptor, first vector of the column) -> the column's vectors is
+  // software-pipelined as well.  PF = 1: descriptor and ystart of the NEXT observation are requested while this one is worked on, so
+  // the block loads at the top of an iteration wait for one memory round trip instead of two; PF = 2: they run two ahead and the block
+  // itself one ahead (RD more doubles per lane).
+  constexpr int PF = (ROWS && RD > 0) ? GLRM_MULTI_PF : 0;
+  LossDesc l_n = lseg, l_nn = lseg;
+  int d_n = 1, d_nn = 1;
+  int64_t ys_n = 0, ys_nn = 0;
+  double ynx[(PF >= 2) ? RD : 1];
+  auto fetch_desc = [&](int32_t idc, LossDesc& lo, int& dc, int64_t& ysc) {
+    const int64_t li = a.loss_single ? 0 : idc;
+    lo = load_loss(a.losses, li);
+    dc = a.losses[li].dim > 1 ? a.losses[li].dim : 1;
+    ysc = a.ystart[idc];
+  };
+  if constexpr (PF >= 1) {
+    if (e > b) {
+      fetch_desc(id_n, l_n, d_n, ys_n);
+      if constexpr (PF >= 2) {
+        fetch_desc(id_nn, l_nn, d_nn, ys_nn);
+        const double* Yb = a.other + ys_n * kp;
+#pragma unroll
+        for (int j = 0; j < RD; ++j) ynx[j] = (j < d_n && comp) ? Yb[j * kp + sub] : 0.0;
+      }
+    }
+  }
   for (int64_t t0 = b + (int64_t)wave * SL; t0 < e; t0 += stride) { // wave-uniform trip count
     const bool valid = t < e;
     const int32_t id = id_n;
@@ -471,7 +501,23 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
     if constexpr (!ROWS) xr_n = a.other[(int64_t)id_nn * kp + (comp ? sub : 0)]; // the row two observations ahead
     LossDesc l = lseg;
     int d = dseg;
-    if constexpr (ROWS) {
+    if constexpr (PF >= 1) { // (id_n is the NEXT observation from here on)
+      l = l_n; d = d_n;
+      if constexpr (PF >= 2) {
+#pragma unroll
+        for (int j = 0; j < RD; ++j) yreg[j] = ynx[j];
+        l_n = l_nn; d_n = d_nn; ys_n = ys_nn;
+        fetch_desc(id_nn, l_nn, d_nn, ys_nn);
+        const double* Yn = a.other + ys_n * kp;
+#pragma unroll
+        for (int j = 0; j < RD; ++j) ynx[j] = (j < d_n && comp) ? Yn[j * kp + sub] : 0.0;
+      } else {
+        const double* Yb = a.other + ys_n * kp;
+#pragma unroll
+        for (int j = 0; j < RD; ++j) yreg[j] = (j < d && comp) ? Yb[j * kp + sub] : 0.0;
+        fetch_desc(id_n, l_n, d_n, ys_n);
+      }
+    } else if constexpr (ROWS) {
       const int64_t li = a.loss_single ? 0 : id;
       l = load_loss(a.losses, li);
       d = a.losses[li].dim > 1 ? a.losses[li].dim : 1;
