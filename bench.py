@@ -615,6 +615,8 @@ def main():
     for _ in range(args.warmup):
         objs.append(sf.iteration(P))
     api.kernel_stats(sf.h, reset=True)
+    if world > 1:
+        sf.exchange_times()  # drop the warm-up's exchange time
 
     def fence():
         if world > 1:
@@ -637,6 +639,9 @@ def main():
     else:
         tot_r, tot_c = nnz_r, nnz_c
     st = api.kernel_stats(sf.h)
+    # what the exchanges added to the iterations of the timed region (events on the rank's stream around every exchange; with row
+    # chunks: the wait for the chunks the pipeline did not hide), and the set-up probe that picked the exchange (N > 2 on RCCL)
+    exch = sf.exchange_times() if world > 1 else None
 
     # The reference's own run at full size -- default ProxGradParams(), stop rule of src/algorithms/proxgrad.jl:210-213, from the same
     # X0, Y0 -- timed end to end on the GPU (the CPU-derived J_ref leg is `to_ref_objective`).
@@ -659,6 +664,7 @@ def main():
 
     nseg_r, nseg_c = rbs[1] - rbs[0], cbs[1] - cbs[0]
     flags = st["tiled"]
+    sf_p2p, sf_chunks, sf_probe = sf._p2p, sf.x_chunks, sf.exchange_probe_ms
     sf.close()
     del sf
     if borrow:
@@ -735,6 +741,12 @@ def main():
                         "col_sweep": None if not rl_c else {kk: rl_c["best"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac")},
                         "mean_trials_per_row": st["trials_x"] / max(args.steps * nseg_r, 1),
                         "mean_trials_per_col": st["trials_y"] / max(args.steps * nseg_c, 1)},
+            "exchange": None if exch is None else {
+                "ms_per_step_on_rank0_stream": {kk: v / max(args.steps, 1) for kk, v in exch.items()},
+                "mode": "p2p" if sf_p2p else "all-gather / broadcast", "x_chunks": sf_chunks, "probe_ms": sf_probe,
+                "model_ms": {"X_block": exchange_model_ms((m // world) * st["ld"] * 8, world), "Y_block": exchange_model_ms((n // world) * st["ld"] * 8, world)},
+                "note": "measured on rank 0's stream (HIP events around the exchanges; warm-up iterations are included in the sum only if "
+                        "they ran after the last read-out); model: direct = one block per xGMI link at 153 GB/s, ring = N - 1 hops"},
             "step_model": step_model(fam_r, fam_c, nnz_r, nnz_c, nseg_r, nseg_c, k, ld, 1e3 * elapsed / args.steps, world, m=m, n=n) if args.config != "C3" else None,
             "objective": {"initial": obj0, "after_warmup_and_steps": objs[-1] if objs else None},
             "to_reference_stop": conv,

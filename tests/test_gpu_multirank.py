@@ -58,6 +58,11 @@ def test_c4_recipe_strong_scaling_equals_one_rank(nranks):
     assert many["config"]["observed"] == one["config"]["observed"] == 48000 * 100
     assert many["objective"] == one["objective"]
     assert 0 < one["roofline"]["frac"] <= 1.0 and one["roofline"]["bound"] in ("hbm", "l2", "lds", "mfma")
+    # the multi-rank line says what the exchanges cost on rank 0's stream and what the xGMI model expects; the single-rank line has none
+    ex = many["exchange"]
+    assert one["exchange"] is None and set(ex["ms_per_step_on_rank0_stream"]) == {"x", "y", "objective"}
+    assert all(v >= 0 for v in ex["ms_per_step_on_rank0_stream"].values()) and ex["model_ms"]["X_block"]["direct"] > 0
+    assert one["step_model"]["within_peak"] and many["step_model"]["passes"] == one["step_model"]["passes"]
 
 
 def test_eight_ranks_on_one_gpu_equal_one_rank():
