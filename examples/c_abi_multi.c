@@ -67,6 +67,9 @@ int main(int argc, char** argv) {
   minfo_fn minfo = (minfo_fn)sym(lib, prefix, "multi_info");
   mdestroy_fn mdestroy = (mdestroy_fn)sym(lib, prefix, "multi_destroy");
   last_error_fn last_error = (last_error_fn)sym(lib, prefix, "last_error");
+  /* the structs below are laid out as THIS header declares them: refuse a library built from another revision */
+  int (*version)(void) = (int (*)(void))sym(lib, prefix, "version");
+  if (version() != GLRM_HIP_ABI_VERSION) { fprintf(stderr, "%s speaks ABI %d, this caller was compiled against ABI %d\n", path, version(), GLRM_HIP_ABI_VERSION); return 2; }
 
   static double A[M][N], Xs[M][K], Ys[N][K];
   static unsigned char obs[M][N];
