@@ -353,3 +353,71 @@ def test_c3_full_size_dense_path_and_oracle_spot_check(quad_gram):
     loss = api.sum(h, dC.data_ptr(), n)
     assert loss == pytest.approx(o1[-1], rel=1e-9 if not quad_gram else 1e-7)
     api.destroy(h)
+
+
+def test_c5_full_size_heterogeneous_columns_and_oracle_spot_check():
+    """BASELINE configs[4] at its STATED size: 5M x 50k, rank 32, 5e9 observations, QuadLoss / LogisticLoss / OrdinalHingeLoss(1, 5) by
+    column (f mod 3), QuadReg(1.0).  The 120 GB of lists are handed over in place (GLRM_PROBLEM_BORROW_DEVICE_ARRAYS); both half-steps
+    run on the LDS-tiled sweeps (row view regrouped by loss kind inside the tile windows, descriptor ids with the entries, in-kernel fp64
+    exp / log).  One X half-step and one Y half-step are compared with the oracle on sampled rows (1 000 observations each, all three
+    loss kinds) and columns (100 000 observations each, one of every kind); the recorded objective is re-evaluated; offsets beyond 2^32."""
+    import gc
+    import torch
+    gc.collect(); torch.cuda.empty_cache()
+    m, n, k, q = 5_000_000, 50_000, 32, 1000
+    api = _capi.hip_api()
+    w = synth.DeviceWorkload(m, n, k, q, loss_mix=1)
+    assert w.nnz_rows == w.nnz_cols == m * q > 2 ** 32
+    h = api.create(w.problem(borrow=True), stream=torch.cuda.current_stream().cuda_stream)
+    ld = api.factor_ld(h)
+    st = api.kernel_stats(h)
+    assert ld == 32 and st["tiled"] == 3 and st["nnz_rows"] == m * q
+    dX, dY = w.init_factors(ld)
+    dC, dR = torch.zeros(n, dtype=torch.float64, device=dX.device), torch.zeros(m, dtype=torch.float64, device=dX.device)
+    api.bind_buffers(h, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())
+    p = L.ProxGradParams()
+    losses = w.losses                                            # one descriptor per column
+    reg = np.array([(1, 0, 1.0)], dtype=_capi.REG_DTYPE)
+    oapi = O.oracle_api()
+    X2 = lambda t: t.view(m, ld)
+    rows = np.array([0, 7, 1_234_567, 4_294_968, m - 1])        # 4_294_968 * 1000 > 2^32: past the 32-bit offsets
+    rows_t = torch.as_tensor(rows, device=dX.device)
+    Yh = dY.cpu().numpy().reshape(n, ld)[:, :k].T.copy()
+    Xh_rows = X2(dX)[rows_t].cpu().numpy()[:, :k]
+    api.reset_stepsizes(h, p.stepsize)
+    api.step_x(h, p.min_stepsize)
+    X_after_rows = X2(dX)[rows_t].cpu().numpy()[:, :k]
+    for i, e in enumerate(rows):
+        b = int(e) * q
+        ci, va = w.colidx[b:b + q].cpu().numpy(), w.rowvals[b:b + q].cpu().numpy()
+        assert np.all(np.diff(ci) > 0) and len({int(c) % 3 for c in ci}) == 3
+        xo = _oracle_row_step(oapi, n, k, ci, va, Xh_rows[i], Yh, losses, reg, p)
+        np.testing.assert_allclose(X_after_rows[i], xo, rtol=1e-9, atol=1e-12)
+        assert np.any(X_after_rows[i] != Xh_rows[i])
+    cols = np.array([0, 1, 2, 25_000, n - 1])                    # Quad, Logistic, OrdinalHinge, ...
+    cp = w.colptr[torch.as_tensor(np.concatenate([cols, cols + 1]), device=dX.device)].cpu().numpy()
+    col_data = []
+    for i, f in enumerate(cols):
+        b, e1 = int(cp[i]), int(cp[len(cols) + i])
+        ri = w.rowidx[b:e1]
+        col_data.append((X2(dX)[ri.long()].cpu().numpy()[:, :k], w.colvals[b:e1].cpu().numpy()))
+    api.step_y(h, p.min_stepsize)
+    Y_after = dY.cpu().numpy().reshape(n, ld)
+    objc = dC.cpu().numpy()
+    for i, f in enumerate(cols):
+        one = np.ascontiguousarray(losses[f:f + 1])
+        yo, oc = _oracle_col_step(oapi, k, col_data[i][0], col_data[i][1], Yh[:, f], one, reg, p)
+        np.testing.assert_allclose(Y_after[f, :k], yo, rtol=1e-9, atol=1e-12)
+        assert objc[f] == pytest.approx(oc, rel=1e-9)
+    o = []
+    for _ in range(2):
+        api.step_x(h, p.min_stepsize); api.step_y(h, p.min_stepsize)
+        o.append(api.sum(h, dC.data_ptr(), n))
+    assert o[1] < o[0]
+    api.col_losses(h)
+    loss = api.sum(h, dC.data_ptr(), n)
+    api.col_penalties(h)
+    pen = api.sum(h, dC.data_ptr(), n)
+    assert loss + pen == pytest.approx(o[-1], rel=1e-10)
+    api.destroy(h)
+    w.free_sources()
