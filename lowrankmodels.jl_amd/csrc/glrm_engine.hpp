@@ -68,6 +68,7 @@ struct glrm_handle {
   bool multi = false;
   int64_t d = 0;                      // vectors of Y = sum of embedding dimensions (= n for scalar losses)
   int dmax = 1;
+  int multi_kmask = 0;                // loss kinds of the model: bit `kind` per multi-dimensional kind, bit 0 = some scalar loss (glrm_multi.hpp: MULTI_KM_*)
   int64_t* ystart = nullptr;          // device, n+1
   int64_t ys_cb = 0;                  // ystart[cb]: first vector of the shard's column block
   int col_nsplit = 1;                 // > 1: the Y half-step runs as split passes + decide rounds

@@ -12,10 +12,12 @@ int glrm_setup_multi(glrm_handle* h, const glrm_problem* p) {
   std::vector<int64_t> ys((size_t)p->n + 1);
   ys[0] = 0;
   h->dmax = 1;
+  h->multi_kmask = 0;
   bool multi = false;
   for (int64_t f = 0; f < p->n; ++f) {
     const glrm_loss& l = p->n_losses == 1 ? p->losses[0] : p->losses[f];
     const int d = l.dim > 1 ? l.dim : 1;
+    h->multi_kmask |= l.kind >= GLRM_LOSS_MULTINOMIAL ? (1 << l.kind) : MULTI_KM_SCALAR; // the kinds of the WHOLE model (never the shard's)
     if (d > 1) multi = true;
     if (d > h->dmax) h->dmax = d;
     ys[f + 1] = ys[f] + d;
@@ -59,11 +61,19 @@ static int setup_split(glrm_handle* h) {
 }
 
 // GDC = 8 when no embedding is wider (gradient registers per lane: 8 instead of 32); TRIG: see LOSS_*_NOTRIG in glrm_engine.hpp
+// kind-specialised instantiations (glrm_multi.hpp: MULTI_KM_*) exist for the small-dimension, no-PeriodicLoss variants
+static int kind_class(const glrm_handle* h) { // 0 = all kinds, 1 = MultinomialLoss only, 2 = MultinomialLoss + scalar losses
+  if (!env_int("GLRM_HIP_MULTI_KINDS", 1)) return 0;
+  return h->multi_kmask == MULTI_KM_MNL ? 1 : ((h->multi_kmask & ~(MULTI_KM_MNL | MULTI_KM_SCALAR)) == 0 && (h->multi_kmask & MULTI_KM_MNL) ? 2 : 0);
+}
+
 template <bool GRAD>
-static void launch_colpass(bool small, bool trig, dim3 grid, size_t lds, hipStream_t st, const SplitArgs& sa) {
+static void launch_colpass(bool small, bool trig, int kc, dim3 grid, size_t lds, hipStream_t st, const SplitArgs& sa) {
   constexpr int D = GLRM_MAX_EMBEDDING_DIM;
   if (small) {
     if (trig) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, true>), grid, dim3(512), lds, st, sa);
+    else if (kc == 1) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, false, MULTI_KM_MNL>), grid, dim3(512), lds, st, sa);
+    else if (kc == 2) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, false, MULTI_KM_MNL | MULTI_KM_SCALAR>), grid, dim3(512), lds, st, sa);
     else hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, false>), grid, dim3(512), lds, st, sa);
   } else {
     if (trig) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, D, true>), grid, dim3(512), lds, st, sa);
@@ -88,14 +98,14 @@ static int run_split_cols(glrm_handle* h, const MultiArgs& a) {
   sa.point = a.own;
   if (a.mode == 1) { // losses only
     sa.round = -1;
-    launch_colpass<false>(small, h->has_trig, grid, lds_pass, st, sa);
+    launch_colpass<false>(small, h->has_trig, kind_class(h), grid, lds_pass, st, sa);
     hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
     HIPCK(hipGetLastError());
     return GLRM_OK;
   }
   sa.round = 0;
   HIPCK(hipMemsetAsync(h->mnactive, 0, 4, st));
-  launch_colpass<true>(small, h->has_trig, grid, lds_pass, st, sa);
+  launch_colpass<true>(small, h->has_trig, kind_class(h), grid, lds_pass, st, sa);
   hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
   HIPCK(hipGetLastError());
   if (a.mode == 2) return GLRM_OK;
@@ -107,7 +117,7 @@ static int run_split_cols(glrm_handle* h, const MultiArgs& a) {
     if (nact == 0) break;
     sa.round = round;
     HIPCK(hipMemsetAsync(h->mnactive, 0, 4, st));
-    launch_colpass<false>(small, h->has_trig, grid, lds_pass, st, sa);
+    launch_colpass<false>(small, h->has_trig, kind_class(h), grid, lds_pass, st, sa);
     hipLaunchKernelGGL(multi_coldecide_kernel, dim3((unsigned)a.nseg), dim3(512), lds_dec, st, sa);
     HIPCK(hipGetLastError());
   }
@@ -151,8 +161,11 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
     const size_t lds = multi_lds_doubles(true, 1, h->kp, h->dmax, a.lgP) * 8;
     // every embedding dimension <= 8: the opposing block of an observation is held in registers (glrm_multi.hpp: multi_pass, RD)
     const bool regs = h->dmax <= 8 && env_int("GLRM_HIP_MULTI_REGS", 1);
+    const int kc = kind_class(h);
     if (regs) {
       if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, true, 8>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+      else if (kc == 1) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false, 8, MULTI_KM_MNL>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+      else if (kc == 2) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false, 8, MULTI_KM_MNL | MULTI_KM_SCALAR>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
       else hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false, 8>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
     } else if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, true>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
     else hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
@@ -162,7 +175,10 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
     if (h->col_nsplit > 1) return run_split_cols(h, a);
     const size_t lds = multi_lds_doubles(false, 8, h->kp, h->dmax, a.lgP) * 8;
     if (h->dmax <= 8) {
+      const int kc = kind_class(h);
       if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, true, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+      else if (kc == 1) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, false, 8, MULTI_KM_MNL>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+      else if (kc == 2) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, false, 8, MULTI_KM_MNL | MULTI_KM_SCALAR>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
       else hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, false, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
     } else {
       if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, GLRM_MAX_EMBEDDING_DIM, true>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);

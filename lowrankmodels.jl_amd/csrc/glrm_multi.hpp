@@ -323,7 +323,16 @@ __device__ __forceinline__ double slot_reduce(double v, int lg, Op op) {
 //   Multinomial: sumexp_j of the reference is sum_j' exp(u_j' - max u) for every j, and exp(-M_j) = exp(u_j - max u);
 //   Ordistic:    the same with v_j = -u_j^2;
 //   MultinomialOrdinal: enforce_MNLOrdRules (:572-578) in closed form, u'_j = min(u_0, u_1 + TOL, ..., u_j + j TOL, -TOL) - j TOL.
-template <bool GRAD, bool TRIG>
+//
+// KM: the loss kinds the MODEL holds, as a bit mask (bit `kind` for the five multi-dimensional kinds, bit 0 = some scalar loss): the code
+// of kinds the model does not have is compiled out.  The all-kinds row kernel is 11 000 instructions with every formula inlined three
+// times (gradient pass, trial pass, fixed-step pass) and spills at the 128-VGPR cap that four waves per SIMD need; for an all-Multinomial
+// model (KM = MULTI_KM_MNL) it is 6 100 instructions, 119 VGPRs, no scratch.  Instantiated: everything, MultinomialLoss only,
+// MultinomialLoss + scalar losses (the categorical + real / boolean columns of a typical data frame).
+constexpr int MULTI_KM_ALL = 0xFFFF, MULTI_KM_SCALAR = 1, MULTI_KM_MNL = 1 << GLRM_LOSS_MULTINOMIAL;
+template <int KM>
+constexpr bool mk_has(int kind) { return ((KM >> kind) & 1) != 0; }
+template <bool GRAD, bool TRIG, int KM = MULTI_KM_ALL>
 __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double av, int dd, int sub, int lg, int slot_lane0, double* us,
                                   double& cg) {
   const double s = l.scale;
@@ -333,15 +342,15 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
   const int ash = a < 0 ? 0 : (a > P - 1 ? P - 1 : a); // in-range lane for the shuffles (idle / scalar slots too)
   // stage 1: slot maximum
   double mv = -__builtin_inf();
-  if (in && vec && kind == GLRM_LOSS_MULTINOMIAL) mv = u;
-  if (in && vec && kind == GLRM_LOSS_ORDISTIC) mv = -(u * u);
+  if (mk_has<KM>(GLRM_LOSS_MULTINOMIAL) && in && vec && kind == GLRM_LOSS_MULTINOMIAL) mv = u;
+  if (mk_has<KM>(GLRM_LOSS_ORDISTIC) && in && vec && kind == GLRM_LOSS_ORDISTIC) mv = -(u * u);
   const double mx = slot_reduce(mv, lg, OpMax());
   // stage 2: per-lane term, slot sum
   double term = 0.0, dLb = 0.0;
   if (in && vec) {
-    if (kind == GLRM_LOSS_MULTINOMIAL) term = fm_exp(u - mx);          // arguments <= 0 (glrm_fastmath.hpp)
-    else if (kind == GLRM_LOSS_ORDISTIC) term = fm_exp(-(u * u) - mx);
-    else if (kind == GLRM_LOSS_OVA || kind == GLRM_LOSS_BVS) {
+    if (mk_has<KM>(GLRM_LOSS_MULTINOMIAL) && kind == GLRM_LOSS_MULTINOMIAL) term = fm_exp(u - mx);          // arguments <= 0 (glrm_fastmath.hpp)
+    else if (mk_has<KM>(GLRM_LOSS_ORDISTIC) && kind == GLRM_LOSS_ORDISTIC) term = fm_exp(-(u * u) - mx);
+    else if ((mk_has<KM>(GLRM_LOSS_OVA) || mk_has<KM>(GLRM_LOSS_BVS)) && (kind == GLRM_LOSS_OVA || kind == GLRM_LOSS_BVS)) {
       const bool truth = kind == GLRM_LOSS_OVA ? a == sub : a > sub;
       loss_both<GRAD, false>(bin_loss_of(l), u, truth ? 1.0 : 0.0, term, dLb);
     }
@@ -349,7 +358,7 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
   const double se = slot_reduce(term, lg, OpSum());
   const double ua = __shfl(u, slot_lane0 + ash, 64);
   // MultinomialOrdinal: thresholds through LDS
-  const bool ord = vec && kind == GLRM_LOSS_MULTINOMIAL_ORDINAL;
+  const bool ord = mk_has<KM>(GLRM_LOSS_MULTINOMIAL_ORDINAL) && vec && kind == GLRM_LOSS_MULTINOMIAL_ORDINAL;
   double e_hi = 0.0, e_lo = 0.0, u_hi = 0.0;
   if (__any(ord)) {
     const double TOL = 1e-3;
@@ -370,24 +379,28 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
   // stage 3: per-kind closing formulas (lane-local)
   cg = 0.0;
   double L = 0.0;
-  if (dd == 1) {
+  if (mk_has<KM>(0) && dd == 1) {
     loss_both<GRAD, TRIG>(l, u0, av, L, cg);
   } else if (vec) {
     switch (kind) {
       case GLRM_LOSS_MULTINOMIAL: // se in [1, d]: the slot's largest term is exp(0)
+        if (!mk_has<KM>(GLRM_LOSS_MULTINOMIAL)) break;
         L = s * (fm_log_ge1(se) + (mx - ua));
         if (GRAD && in) cg = s * ((sub == a ? -1.0 : 0.0) + term * fm_rcp(se));
         break;
       case GLRM_LOSS_OVA:
       case GLRM_LOSS_BVS:
+        if (!(mk_has<KM>(GLRM_LOSS_OVA) || mk_has<KM>(GLRM_LOSS_BVS))) break;
         L = s * se;
         if (GRAD && in) cg = s * dLb;
         break;
       case GLRM_LOSS_ORDISTIC:
+        if (!mk_has<KM>(GLRM_LOSS_ORDISTIC)) break;
         L = s * ((ua * ua + mx) + fm_log_ge1(se));
         if (GRAD && in) cg = s * ((sub == a ? 2 * u : 0.0) - 2 * u * term * fm_rcp(se));
         break;
       default: { // GLRM_LOSS_MULTINOMIAL_ORDINAL
+        if (!mk_has<KM>(GLRM_LOSS_MULTINOMIAL_ORDINAL)) break;
         double g = 0.0;
         if (a == 0) {
           L = -s * log(1.0 - e_lo);
@@ -422,7 +435,7 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
 // no LDS round trip between the load and the dot products); columns: the own block is read out of LDS once per pass.  The components
 // of the d-vector gradient come back by lane shuffles instead of through LDS.  Per observation that removes d LDS writes, 2 d LDS reads
 // and three wave barriers; every product and every sum is formed in the same order as on the LDS path (same bits).
-template <bool ROWS, int NW, bool GRAD, int GDC, bool TRIG, int RD = 0>
+template <bool ROWS, int NW, bool GRAD, int GDC, bool TRIG, int RD = 0, int KM = MULTI_KM_ALL>
 __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, const double* own, double* wbase, double* Gt, double* red,
                                     const LossDesc& lseg, int dseg) {
   constexpr int NT = NW * 64, GD = ROWS ? 1 : GDC; // GDC >= the largest embedding dimension of the problem
@@ -552,7 +565,7 @@ __device__ inline double multi_pass(const MultiArgs& a, int64_t b, int64_t e, co
       }
     }
     double cg = 0.0;
-    const double L = obs_loss<GRAD, TRIG>(l, u, u0, av, dd, sub, lg, lane - sub, us, cg);
+    const double L = obs_loss<GRAD, TRIG, KM>(l, u, u0, av, dd, sub, lg, lane - sub, us, cg);
     lsum += L;
     if constexpr (GRAD && RD > 0) {
       // component j of the observation's gradient sits in lane j of the slot: fetch it by a shuffle (executed by the whole wave,
@@ -635,7 +648,7 @@ __host__ __device__ inline size_t multi_lds_doubles(bool rows, int nw, int kp, i
 }
 
 // TRIG = false: the scalar-loss columns of the model hold no PeriodicLoss (LOSS_*_NOTRIG in glrm_engine.hpp)
-template <bool ROWS, int NW, int GDC, bool TRIG, int RD = 0>
+template <bool ROWS, int NW, int GDC, bool TRIG, int RD = 0, int KM = MULTI_KM_ALL>
 __global__ void __launch_bounds__(NW * 64, NW == 1 ? 4 : 2) multi_sweep_kernel(const MultiArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NT = NW * 64;
@@ -667,11 +680,11 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 4 : 2) multi_sweep_kernel(c
   const glrm_reg rg = a.regs[a.reg_single ? 0 : s];
 
   if (a.mode == 1) { // losses only
-    const double tot = multi_pass<ROWS, NW, false, GDC, TRIG, RD>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
+    const double tot = multi_pass<ROWS, NW, false, GDC, TRIG, RD, KM>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
     if (tid == 0 && a.obj) a.obj[gseg] = tot;
     return;
   }
-  const double loss_old = multi_pass<ROWS, NW, true, GDC, TRIG, RD>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
+  const double loss_old = multi_pass<ROWS, NW, true, GDC, TRIG, RD, KM>(a, b, e, ownA, wbase, Gt, red, lseg, dseg);
   const double l1 = (double)(e - b) + 1;
   if (a.mode == 2) { // sparse_proxgrad.jl:72-78 / :94-99: scale the gradient, add, prox -- no line search
     const double st = a.fixed_alpha / l1;
@@ -695,7 +708,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 1 ? 4 : 2) multi_sweep_kernel(c
     }
     __syncthreads();
     block_prox<NW>(ownB, S, k, DO, rg, stepsize, tmp);
-    const double nloss = multi_pass<ROWS, NW, false, GDC, TRIG, RD>(a, b, e, ownB, wbase, Gt, red, lseg, dseg);
+    const double nloss = multi_pass<ROWS, NW, false, GDC, TRIG, RD, KM>(a, b, e, ownB, wbase, Gt, red, lseg, dseg);
     const double nobj = nloss + block_reg_eval<NW>(ownB, S, k, DO, rg, red);
     ++ntr;
     if (nobj < obj) {
@@ -740,7 +753,7 @@ struct SplitArgs {
   unsigned int* nactive;
 };
 
-template <bool GRAD, int GDC, bool TRIG>
+template <bool GRAD, int GDC, bool TRIG, int KM = MULTI_KM_ALL>
 __global__ void __launch_bounds__(512, (GRAD && GDC > 8) ? 2 : 4) multi_colpass_kernel(const SplitArgs sa) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   constexpr int NW = 8, NT = NW * 64;
@@ -765,7 +778,7 @@ __global__ void __launch_bounds__(512, (GRAD && GDC > 8) ? 2 : 4) multi_colpass_
   int64_t b = b0 + (int64_t)y * sa.chunk, e = b + sa.chunk;
   b = b < e0 ? b : e0;
   e = e < e0 ? e : e0;
-  const double tot = multi_pass<false, NW, GRAD, GDC, TRIG, (GDC <= 8 ? 8 : 0)>(a, b, e, own, wbase, Gt, red, lseg, dseg);
+  const double tot = multi_pass<false, NW, GRAD, GDC, TRIG, (GDC <= 8 ? 8 : 0), KM>(a, b, e, own, wbase, Gt, red, lseg, dseg);
   if (tid == 0) sa.part_loss[s * sa.nsplit + y] = tot;
   if constexpr (GRAD) {
     double* pg = sa.part_G + ((size_t)s * sa.nsplit + y) * a.dmax * kp;

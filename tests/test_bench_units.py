@@ -99,10 +99,12 @@ def test_cached_family_prices_one_gather_pass():
 def test_step_model_reproduces_the_round_two_check():
     """BENCH_r02: 228.9 ms per iteration at C4.  SURVEY 8(d) (P = 2 on both sides) gives 9.16 TB/s -- above the peak; with the cached row
     sweep's single pass the step moves ~1.59e12 B = 6.9 TB/s = 0.87 of the peak."""
-    sm = bench.step_model("cached", "blocked", 10**9, 10**9, 10_000_000, 100_000, 64, 64, 228.9, 1)
+    sm = bench.step_model("cached", "blocked", 10**9, 10**9, 10_000_000, 100_000, 64, 64, 228.9, 1, m=10_000_000, n=100_000)
     assert sm["passes"] == {"x": 1, "y": 2} and sm["within_peak"]
+    # HBM itself: Y (51 MB) lives in the Infinity Cache, so the X half-step's floor is its streams; X (5 GB) does not
+    assert sm["hbm_floor"]["opposing_factor_cache_resident"] == {"x": True, "y": False} and sm["hbm_floor"]["GBps"] == pytest.approx(4677, abs=10)
     assert sm["survey_8d_P2_GBps"] == pytest.approx(9157, abs=5) and sm["GBps"] == pytest.approx(6913, abs=10)
-    assert bench.step_model("gather", "gather", 10**9, 10**9, 10_000_000, 100_000, 64, 64, 290.0, 1)["passes"] == {"x": 2, "y": 2}
+    assert bench.step_model("gather", "gather", 10**9, 10**9, 10_000_000, 100_000, 64, 64, 290.0, 1, m=10_000_000, n=100_000)["passes"] == {"x": 2, "y": 2}
     # LDS-tiled sweeps (C5 at its stated size, 582.8 ms): the k-vectors are fetched per workgroup, not per update -- no 9.2 TB/s artefact
     t = bench.step_model("tiled", "tiled", 5 * 10**9, 5 * 10**9, 5_000_000, 50_000, 32, 32, 582.8, 1, m=5_000_000, n=50_000)
     assert t["within_peak"] and t["survey_8d_P2_GBps"] > 8000 and t["GBps"] == pytest.approx(420, abs=10)

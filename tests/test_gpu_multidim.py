@@ -274,3 +274,44 @@ def test_python_fit_with_offset_and_categoricals():
     X2, Y2, ch2 = L.fit_b(g, L.HipProxGradParams(max_iter=5), verbose=False)
     assert ch2.objective[0] == pytest.approx(start, rel=1e-12)
     assert ch2.objective[-1] <= ch2.objective[0]
+
+
+@pytest.mark.parametrize("model", ["mnl_only", "mnl_and_scalars"])
+@pytest.mark.parametrize("tall", [False, True])
+def test_kind_specialised_kernels_give_the_bits_of_the_general_ones(model, tall, monkeypatch):
+    """Models whose columns are all MultinomialLoss, or MultinomialLoss + scalar losses (the categorical / real / boolean columns of a data
+    frame), run kernels compiled without the other kinds' code (glrm_multi.hpp: MULTI_KM_*; 6 100 instead of 11 000 instructions, no
+    scratch).  Same formulas in the same order: bit-identical to the all-kinds kernels (GLRM_HIP_MULTI_KINDS=0), and within 1e-5 of the
+    oracle.  tall: columns long enough for the split column passes (multi_colpass_kernel)."""
+    rng = np.random.default_rng(77 if tall else 78)
+    m, n, k = (30000, 6, 6) if tall else (400, 24, 7)
+    losses = []
+    for f in range(n):
+        if model == "mnl_only" or f % 3 == 0:
+            losses.append(L.MultinomialLoss(int(rng.integers(2, 7))))
+        else:
+            losses.append([L.QuadLoss(), L.LogisticLoss(), L.HuberLoss(), L.OrdinalHingeLoss(1, 5)][f % 4])
+    Z = rng.standard_normal((m, 3))
+    A = np.zeros((m, n))
+    for f, lo in enumerate(losses):
+        z = Z @ rng.standard_normal(3)
+        if hasattr(lo, "max") and not isinstance(lo, L.OrdinalHingeLoss):
+            A[:, f] = np.clip(np.round((1 + lo.max) / 2 + z), 1, lo.max)
+        elif isinstance(lo, L.OrdinalHingeLoss):
+            A[:, f] = np.clip(np.round(3 + z), 1, 5)
+        else:
+            A[:, f] = (z > 0) if lo.classification else z
+    I, J = np.nonzero(rng.random((m, n)) < 0.8)
+    D = L.embedding_dim(losses)
+    X0, Y0 = 0.5 * rng.standard_normal((k, m)), 0.5 * rng.standard_normal((k, D))
+    g = L.GLRM(A, losses, L.QuadReg(0.1), L.QuadReg(0.1), k, obs=(I, J), X=X0, Y=Y0)
+    pa = g.problem_arrays()
+    p = L.ProxGradParams(max_iter=5)
+    X0, Y0 = np.asfortranarray(X0), np.asfortranarray(Y0)
+    a = cases.run_engine(hip(), pa, X0, Y0, p)
+    monkeypatch.setenv("GLRM_HIP_MULTI_KINDS", "0")
+    b = cases.run_engine(hip(), pa, X0, Y0, p)
+    assert a[3]["tiled"] == b[3]["tiled"] == 8
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    monkeypatch.delenv("GLRM_HIP_MULTI_KINDS")
+    compare(pa, X0, Y0, p)
