@@ -18,6 +18,9 @@ from .convergence import ConvergenceHistory, update_ch
 from .params import AbstractParams, HipProxGradParams, ProxGradParams, SparseProxGradParams
 
 
+LAST_EXCHANGE_PROBE = None  # the last set-up probe of a ShardedFit in this process (diagnostics; tests)
+
+
 def _engine_opts(params):
     g = lambda k, d: getattr(params, k, d)
     return dict(device_id=g("device_id", -1), profile=1 if g("profile", False) else 0,
@@ -260,7 +263,9 @@ class ShardedFit:
         self._timed = []                                            # (kind, start event, end event) awaiting a synchronisation
         self._profile = bool(o.get("profile")) and self.device.type == "cuda"
         self.exchange_probe_ms = None
-        if self.world > 2 and mode == "auto" and self.device.type == "cuda" and dist.get_backend(group) == "nccl":
+        # (GLRM_GATHER_PROBE=1 runs the probe on any backend: how the gloo tests cover this code before the first multi-GPU node does)
+        on_rccl = self.device.type == "cuda" and self.world > 1 and dist.get_backend(group) == "nccl"
+        if self.world > 2 and mode == "auto" and (on_rccl or os.environ.get("GLRM_GATHER_PROBE") == "1"):
             self._probe_exchange()
 
     def _probe_exchange(self):
@@ -271,12 +276,13 @@ class ShardedFit:
         for name in ("allgather", "p2p"):
             self._p2p = name == "p2p"
             try:
+                sync = (lambda: torch.cuda.synchronize(self.device)) if self.device.type == "cuda" else (lambda: None)
                 for rep in range(2):  # first repetition: connection set-up
-                    torch.cuda.synchronize(self.device)
+                    sync()
                     dist.barrier(group=self.group)
                     t0 = time.perf_counter()
                     self._gather(self.dX, self.row_bounds, self.ld)
-                    torch.cuda.synchronize(self.device)
+                    sync()
                     dt = (time.perf_counter() - t0) * 1e3
                 t = torch.tensor([dt], dtype=torch.float64, device=self.device)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
@@ -289,6 +295,8 @@ class ShardedFit:
         self._p2p = bool(flag.item() > 0.5)
         res["chosen"] = "p2p" if self._p2p else "allgather"
         self.exchange_probe_ms = res
+        global LAST_EXCHANGE_PROBE
+        LAST_EXCHANGE_PROBE = res
 
     def close(self):
         if self.h is not None:

@@ -113,3 +113,23 @@ def test_two_ranks_multidimensional_losses(tmp_path):
         for z in ranks:
             assert np.array_equal(z[name + "_X"], X) and np.array_equal(z[name + "_Y"], Y), name
             assert np.array_equal(z[name + "_obj"][1:], np.array(ch.objective[1:])), name
+
+
+@pytest.mark.parametrize("nproc,chunks", [(4, "1"), (4, "2"), (3, "1")])
+def test_exchange_probe_picks_one_mode_on_every_rank(tmp_path, nproc, chunks):
+    """More than two ranks on RCCL: ShardedFit times an all-gather and a grouped send / recv exchange of the X blocks at set-up and keeps
+    the faster one on every rank (fit.py: _probe_exchange).  GLRM_GATHER_PROBE=1 runs that code on gloo: whichever mode wins, the fit
+    equals the single-process bits -- equal blocks (4 ranks, also with pipelined row chunks) and ragged ones (3 ranks: the all-gather leg
+    of the probe runs as one broadcast per owner)."""
+    names = ["c4"] if nproc == 4 else ["nnmf"]
+    ranks = run_world(tmp_path, names, nproc, {"GLRM_GATHER_PROBE": "1", "GLRM_X_CHUNKS": chunks})
+    assert all("probe_ms" in z.files and np.all(np.isfinite(z["probe_ms"])) and np.all(z["probe_ms"] > 0) for z in ranks)  # both legs ran
+    assert len({bool(z["probe_chose_p2p"]) for z in ranks}) == 1                                                            # one choice
+    O.set_threads(1)
+    for name in names:
+        kwargs, params = cases.build_golden_case(name)
+        g = L.GLRM(**kwargs)
+        X, Y, ch = L.fit_b(g, params, verbose=False, engine=O.oracle_api())
+        for z in ranks:
+            assert np.array_equal(z[name + "_X"], X) and np.array_equal(z[name + "_Y"], Y), name
+            assert np.array_equal(z[name + "_obj"][1:], np.array(ch.objective[1:])), name
