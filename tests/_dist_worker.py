@@ -27,7 +27,7 @@ if __name__ == "__main__":
         res[name + "_obj"] = np.array(ch.objective)
         res[name + "_X"] = X
         res[name + "_Y"] = Y
-    from lowrankmodels.jl_amd import fit as _fit
+    _fit = sys.modules["lowrankmodels.jl_amd.fit"]  # (the package exports the function `fit` under the module's name)
     if _fit.LAST_EXCHANGE_PROBE is not None:  # GLRM_GATHER_PROBE=1: which exchange the set-up probe kept (must agree on every rank)
         res["probe_chose_p2p"] = np.array(_fit.LAST_EXCHANGE_PROBE["chosen"] == "p2p")
         res["probe_ms"] = np.array([_fit.LAST_EXCHANGE_PROBE["allgather"], _fit.LAST_EXCHANGE_PROBE["p2p"]])
