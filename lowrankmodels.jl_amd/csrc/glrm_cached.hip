@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "glrm_device.hpp"
@@ -442,6 +443,166 @@ __global__ void __launch_bounds__(WAVES * 64) regcached_sweep_kernel(const Cache
   }
 }
 
+// ---- persistent form: a workgroup walks rows slot, slot + gridDim.x, ... and hands the NEXT row's (index, value) list over while it
+// works on the current one.  In the one-row-per-workgroup kernel above a row's life is three dependent memory round trips -- row pointer
+// -> list -> opposing vectors -- before the first FMA, with two waves per SIMD to hide them (244 VGPRs).  Here the pointers of the next
+// row are scalar loads issued one row ahead, its list is requested right behind the current row's gathers (3 * PF dwords per lane, the
+// only extra registers) and reaches the lanes through LDS after the current row's passes: the chain per row is ONE round trip, the
+// gathers.  Which lane group adds which observation, and in which order, is unchanged: same bits as the kernel above.
+template <int G, int R, int LOSS, int MAXT>
+__global__ void __launch_bounds__(128, 2) regcached_persist_kernel(const CachedArgs a) {
+  constexpr int WAVES = 2, KP = G * R, NG = (64 / G) * WAVES, MAXLEN = MAXT * NG, PF = (MAXLEN + 127) / 128;
+  // ONE shared array (a second __shared__ object makes hipcc drain the load queue before every LDS read, cdna_hip_programming.md):
+  // [combine buffer: WAVES * (KP + 2) doubles][values: PF * 128 doubles][indices: PF * 128 ints]
+  constexpr int RED = WAVES * (KP + 2);
+  __shared__ __attribute__((aligned(16))) double sh[RED + PF * 128 + PF * 64];
+  double* red = sh;
+  double* lvals = sh + RED;
+  int* lidx = reinterpret_cast<int*>(sh + RED + PF * 128);
+  int* lvals_dw = reinterpret_cast<int*>(lvals);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane % G, gi = wave * (64 / G) + lane / G;
+  const RegDesc rd0 = load_reg(a.regs, 0);
+  LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
+  if constexpr (loss_mode(LOSS) != LOSS_PER_OBS) segloss = load_loss(a.losses, 0);
+  const double2* __restrict__ other2 = reinterpret_cast<const double2*>(a.other);
+
+  // segment of a slot (-1: none / filtered out), its list
+  auto seg_of = [&](int64_t slot) -> int64_t { return cached_segment(a, slot); };
+  auto fetch_list = [&](int64_t beg, int len, int (&pi)[PF], int (&pv)[2 * PF]) { // this lane's share of the row's list, clamped
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      int e = q * 128 + tid;
+      e = e < len ? e : (len > 0 ? len - 1 : 0);
+      pi[q] = len > 0 ? a.idx[beg + e] : 0;
+      const int2 v = len > 0 ? *reinterpret_cast<const int2*>(a.vals + beg + e) : make_int2(0, 0);
+      pv[2 * q] = v.x; pv[2 * q + 1] = v.y;
+    }
+  };
+  auto store_list = [&](const int (&pi)[PF], const int (&pv)[2 * PF]) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      lidx[q * 128 + tid] = pi[q];
+      lvals_dw[2 * (q * 128 + tid)] = pv[2 * q];
+      lvals_dw[2 * (q * 128 + tid) + 1] = pv[2 * q + 1];
+    }
+  };
+
+  int64_t slot = blockIdx.x;
+  int64_t seg = seg_of(slot), seg_n = seg_of(slot + gridDim.x);
+  int64_t beg = seg >= 0 ? a.ptr[seg] : 0, beg_n = seg_n >= 0 ? a.ptr[seg_n] : 0;
+  int len = seg >= 0 ? (int)(a.ptr[seg + 1] - beg) : 0, len_n = seg_n >= 0 ? (int)(a.ptr[seg_n + 1] - beg_n) : 0;
+  {
+    int pi[PF], pv[2 * PF];
+    fetch_list(beg, len, pi, pv);
+    store_list(pi, pv);
+  }
+  __syncthreads();
+  for (; slot < a.nseg; slot += gridDim.x) { // block-uniform
+    // the row after the next one: pointers only (scalar loads, consumed an iteration from now)
+    const int64_t seg_nn = seg_of(slot + 2 * (int64_t)gridDim.x);
+    const int64_t beg_nn = seg_nn >= 0 ? a.ptr[seg_nn] : 0;
+    const int len_nn = seg_nn >= 0 ? (int)(a.ptr[seg_nn + 1] - beg_nn) : 0;
+    int cc[MAXT];
+    double av[MAXT];
+    double2 y[MAXT][R / 2];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) { // the group's entries out of LDS (clamped: lanes past the end re-read the last entry and are masked)
+      int tt = t * NG + gi;
+      tt = tt < len ? tt : (len > 0 ? len - 1 : 0);
+      cc[t] = lidx[tt];
+      av[t] = lvals[tt];
+    }
+    const int64_t gseg = a.own_offset + (seg >= 0 ? seg : 0);
+    double2* ownp = reinterpret_cast<double2*>(a.own + gseg * KP);
+    Vec<G, R> x, g;
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) x.v[i] = ownp[i * G + j];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+      if (t * NG + wave * (64 / G) < len) { // wave-uniform
+        const double2* yp = other2 + (int64_t)cc[t] * (KP / 2) + j;
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) y[t][i] = yp[i * G];
+      } else {
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) y[t][i] = make_double2(0.0, 0.0);
+      }
+    }
+    // the next row's list rides behind the gathers
+    int pi[PF], pv[2 * PF];
+    fetch_list(beg_n, len_n, pi, pv);
+    const RegDesc rd = a.reg_single ? rd0 : load_reg(a.regs, seg >= 0 ? seg : 0);
+
+    if (seg >= 0) {
+      double Jold = reg_pass<G, R, LOSS, MAXT, true, WAVES>(a, y, av, cc, x, g, len, gi, segloss);
+      Jold = row_combine<G, R, WAVES, true>(Jold, g, red, wave, lane);
+      if (a.fixed_alpha > 0.0) {
+        const double s = a.fixed_alpha / ((double)len + 1.0);
+        Vec<G, R> xn;
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+          xn.v[i].x = x.v[i].x + g.v[i].x * (-s);
+          xn.v[i].y = x.v[i].y + g.v[i].y * (-s);
+        }
+        reg_prox<G, R>(rd, xn, s, j, a.k);
+        if (gi == 0) {
+#pragma unroll
+          for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = xn.v[i];
+        }
+      } else {
+        Jold += reg_eval<G, R>(rd, x, j, a.k);
+        double alpha = a.alpha[seg];
+        const double l = (double)len + 1.0;
+        int ntrials = 0;
+        bool accepted = false;
+        while (alpha > a.min_stepsize) {
+          const double s = alpha / l;
+          Vec<G, R> xn, dummy;
+#pragma unroll
+          for (int i = 0; i < R / 2; ++i) {
+            xn.v[i].x = fma(-s, g.v[i].x, x.v[i].x);
+            xn.v[i].y = fma(-s, g.v[i].y, x.v[i].y);
+          }
+          reg_prox<G, R>(rd, xn, s, j, a.k);
+          double Jn = reg_pass<G, R, LOSS, MAXT, false, WAVES>(a, y, av, cc, xn, dummy, len, gi, segloss);
+          Jn = row_combine<G, R, WAVES, false>(Jn, dummy, red, wave, lane);
+          Jn += reg_eval<G, R>(rd, xn, j, a.k);
+          ++ntrials;
+          if (Jn < Jold) {
+            x = xn;
+            alpha *= 1.05;
+            Jold = Jn;
+            accepted = true;
+            break;
+          }
+          alpha *= .7;
+          if (alpha < a.min_stepsize) {
+            alpha = a.min_stepsize * 1.1;
+            break;
+          }
+        }
+        if (accepted && gi == 0) {
+#pragma unroll
+          for (int i = 0; i < R / 2; ++i) ownp[i * G + j] = x.v[i];
+        }
+        if (tid == 0) {
+          a.alpha[seg] = alpha;
+          if (a.trials) {
+            a.trials[seg] += ntrials;
+            a.accepts[seg] += accepted ? 1 : 0;
+          }
+        }
+      }
+    }
+    __syncthreads();      // everybody has read this row's list out of LDS (and is done with the combine buffer)
+    store_list(pi, pv);   // hand the next row's list over
+    __syncthreads();
+    seg = seg_n; beg = beg_n; len = len_n;
+    seg_n = seg_nn; beg_n = beg_nn; len_n = len_nn;
+  }
+}
+
 template <int G, int R, int LOSS>
 int launch_reg_inst(const CachedArgs& a, hipStream_t st) { // a.cap = trips of one wave the longest row needs (64 / G observations each)
   // Two waves per row (each holds every other trip's vectors: half the registers, two waves per SIMD, so one wave's loads overlap the
@@ -449,6 +610,26 @@ int launch_reg_inst(const CachedArgs& a, hipStream_t st) { // a.cap = trips of o
   // ALWAYS two, also for rows one wave could hold: the wave count fixes the order of the sums, and it must not depend on the
   // longest row of the launch (MAXT only adds empty trips).  GLRM_HIP_CACHED_WAVES = 1 | 4 are the experiment switches.
   const int waves = env_int("GLRM_HIP_CACHED_WAVES", 2);
+  if (waves == 2 && env_int("GLRM_HIP_CACHED_PERSIST", 1)) { // the persistent form of the two-wave kernel (same bits)
+    static std::atomic<int> blocks7{0}, blocks4{0};
+    const bool small = (a.cap + 1) / 2 <= 4;
+    std::atomic<int>& cache = small ? blocks4 : blocks7;
+    int nb = cache.load(std::memory_order_relaxed);
+    if (nb == 0) {
+      int per_cu = 0, dev = 0;
+      hipDeviceProp_t prop;
+      const void* k = small ? (const void*)regcached_persist_kernel<G, R, LOSS, 4> : (const void*)regcached_persist_kernel<G, R, LOSS, 7>;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 128, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+      int cus = 256;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+      nb = per_cu * cus * env_int("GLRM_HIP_CACHED_PERSIST_FILL", 1);
+      cache.store(nb, std::memory_order_relaxed);
+    }
+    const unsigned grid = (unsigned)std::min<int64_t>(a.nseg, nb);
+    if (small) hipLaunchKernelGGL((regcached_persist_kernel<G, R, LOSS, 4>), dim3(grid), dim3(128), 0, st, a);
+    else hipLaunchKernelGGL((regcached_persist_kernel<G, R, LOSS, 7>), dim3(grid), dim3(128), 0, st, a);
+    return GLRM_OK;
+  }
   if (waves == 4 && (a.cap + 3) / 4 <= 4) {
     hipLaunchKernelGGL((regcached_sweep_kernel<G, R, LOSS, 4, 4>), dim3((unsigned)a.nseg), dim3(256), 0, st, a);
   } else if (waves == 1) {
