@@ -99,7 +99,10 @@ static int64_t slice_capacity(K kernel, int device, int spb) {
   int cus = 256;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
   const int64_t cap = (int64_t)nb * cus * spb;
-  const int pct = env_int("GLRM_HIP_BLOCKED_FILL", 100); // percent of the residency to use per launch
+  // percent of the residency one launch covers.  Half: the next launch's workgroups fill the CUs the current one's stragglers have left
+  // (launches of one stream overlap at their tails), which a slice of exactly the residency cannot do -- C4 Y half-step 143.2 -> 138.4 ms
+  // (25 / 33 / 66 / 100 / 200 %: 149.0 / 148.1 / 141.6 / 143.2 / 144.1, profiles/r03_c4_blocked_knobs.txt).  Changes no sum.
+  const int pct = env_int("GLRM_HIP_BLOCKED_FILL", 50);
   return std::max<int64_t>(spb, cap * pct / 100 / spb * spb);
 }
 
