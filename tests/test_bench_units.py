@@ -116,3 +116,16 @@ def test_quad_gram_prices_the_flop_that_are_left():
     mf = lambda r: next(c for c in r["candidates"] if c["bound"] == "mfma")
     assert mf(a)["per_launch"] == 6.0 * 10**6 * 10**4 * 32 and mf(b)["per_launch"] == 4.0 * 10**6 * 10**4 * 32
     assert mf(a)["measured_ceiling"]["v_mfma_f64_16x16x4_f64"] == 50.3
+
+
+def test_exchange_model_and_signature_combine():
+    """xGMI model printed beside the shard measurements: direct = one block per link, ring = N - 1 hops; the whole problem's signature is
+    the sum of the shards' observation counts and the max of everything else."""
+    from lowrankmodels.jl_amd import _capi
+    ex = bench.exchange_model_ms(640e6, 8)
+    assert ex["direct"] == pytest.approx(640e6 / 153e9 * 1e3) and ex["ring"] == pytest.approx(7 * ex["direct"])
+    assert bench.exchange_model_ms(1e9, 1) == {"direct": 0.0, "ring": 0.0}
+    a, b = _capi.CSignature(10, 12, 3, 5, 0, 1), _capi.CSignature(7, 1, 9, 2, 1, 0)
+    w = _capi.CSignature.combine([a, b.astuple()])
+    assert w.astuple() == (17, 13, 9, 5, 1, 1)
+    assert bench.passes_priced("cached") == 1 and bench.passes_priced("blocked") == 2
