@@ -27,7 +27,13 @@
 
 using namespace glrm;
 
-constexpr int BNW = 4;                                                     // waves per workgroup
+// Waves per workgroup.  ONE: the finest grain the dispatcher can spread over the CUs and retire -- C4 Y half-step, same box, with the
+// half-residency launch slices below: 138.5 (4 waves) / 134.9 (2) / 129.6 ms (1); at full-residency slices 150.7 / 146.3 / 144.4
+// (profiles/r03_c4_blocked_knobs.txt).  Changes no sum (a lane group owns a segment whatever workgroup it sits in).
+#ifndef GLRM_BLOCKED_NW
+#define GLRM_BLOCKED_NW 1
+#endif
+constexpr int BNW = GLRM_BLOCKED_NW;                                       // waves per workgroup
 constexpr int tile_rows_b(int kp) { return ((150 * 1024) / (kp * 8 + 16)) / 16 * 16; } // the LDS tile unit the super-tiles are counted in
 
 int glrm_setup_blocked(glrm_handle* h) {
@@ -101,7 +107,9 @@ static int64_t slice_capacity(K kernel, int device, int spb) {
   const int64_t cap = (int64_t)nb * cus * spb;
   // percent of the residency one launch covers.  Half: the next launch's workgroups fill the CUs the current one's stragglers have left
   // (launches of one stream overlap at their tails), which a slice of exactly the residency cannot do -- C4 Y half-step 143.2 -> 138.4 ms
-  // (25 / 33 / 66 / 100 / 200 %: 149.0 / 148.1 / 141.6 / 143.2 / 144.1, profiles/r03_c4_blocked_knobs.txt).  Changes no sum.
+  // with four-wave workgroups (25 / 33 / 66 / 100 / 200 %: 149.0 / 148.1 / 141.6 / 143.2 / 144.1), and with one-wave workgroups
+  // 25 / 33 / 40 / 50 / 60 / 75 / 100 %: 139.7 / 137.0 / 135.6 / 131.0 / 133.0 / 136.9 / 144.4 (profiles/r03_c4_blocked_knobs.txt).
+  // Changes no sum.
   const int pct = env_int("GLRM_HIP_BLOCKED_FILL", 50);
   return std::max<int64_t>(spb, cap * pct / 100 / spb * spb);
 }
@@ -114,11 +122,15 @@ static int launch_blocked_inst(glrm_handle* h, TiledArgs a) {
   int64_t cap = cap_cache.load(std::memory_order_relaxed);
   if (cap == 0) { cap = slice_capacity(kernel, h->device, SPB); cap_cache.store(cap, std::memory_order_relaxed); }
   const int64_t nseg = a.nseg;
+  // equal slices: ceil(nseg / cap) launches per super-tile, all of the same size (a last slice of a few percent of the others is a launch
+  // that cannot fill the chip)
+  const int64_t nslices = (nseg + cap - 1) / cap;
+  const int64_t per = nslices > 0 ? ((nseg + nslices - 1) / nslices + SPB - 1) / SPB * SPB : cap;
   for (int sup = 0; sup < a.nsup; ++sup) {
-    for (int64_t s0 = 0; s0 < nseg; s0 += cap) {
+    for (int64_t s0 = 0; s0 < nseg; s0 += per) {
       a.sup_fixed = sup;
       a.seg_begin = s0;
-      a.nseg_slice = std::min(cap, nseg - s0);
+      a.nseg_slice = std::min(per, nseg - s0);
       hipLaunchKernelGGL(kernel, dim3((unsigned)((a.nseg_slice + SPB - 1) / SPB)), dim3(BNW * 64), 0, h->stream, a);
     }
   }

@@ -622,7 +622,8 @@ int launch_reg_inst(const CachedArgs& a, hipStream_t st) { // a.cap = trips of o
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 128, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
       int cus = 256;
       if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-      nb = per_cu * cus * env_int("GLRM_HIP_CACHED_PERSIST_FILL", 1);
+      nb = (int)((int64_t)per_cu * cus * env_int("GLRM_HIP_CACHED_PERSIST_FILL", 100) / 100); // percent of the resident grid
+      if (nb < 1) nb = 1;
       cache.store(nb, std::memory_order_relaxed);
     }
     const unsigned grid = (unsigned)std::min<int64_t>(a.nseg, nb);
