@@ -392,7 +392,8 @@ typedef struct glrm_kernel_stats {
   int32_t tiled;               /* bit0: LDS-tiled row sweep in use, bit1: LDS-tiled column sweep in use,
                                   bit2: dense MFMA path in use, bit3: general sweeps (multi-dimensional losses),
                                   bit4 / bit5: phase-aligned gather passes (L2-blocked) for the row / column sweep,
-                                  bit6: row sweep with the row's opposing vectors cached in LDS */
+                                  bit6: cached gather row sweep (the short rows' opposing vectors fetched once per half-step
+                                  and kept in registers / LDS for every pass) */
 } glrm_kernel_stats;
 
 int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int reset);
