@@ -80,6 +80,13 @@ GLRM_FM double fm_log_ge1(double w) {
   return w < __builtin_inf() ? r : w;          // Inf (frexp of Inf is unspecified) and NaN pass through
 }
 
+// log(x) for any x: the same reduction serves 0 < x < 1 (frexp handles denormals; the worst cancellation, e ln2 + log(m) at e = -1, costs
+// under half a digit).  log(0) = -Inf, log(x < 0) = NaN, log(Inf) = Inf, log(NaN) = NaN, as IEEE / libm.
+GLRM_FM double fm_log(double x) {
+  const double r = fm_log_ge1(x);
+  return x > 0.0 ? r : (x == 0.0 ? -__builtin_inf() : __builtin_nan(""));
+}
+
 // LogisticLoss (src/losses.jl:298-311) from ONE exponential, in the reference's own structure so that its rounding is reproduced:
 // with z = (2a-1) u and E = exp(-z), w = 1 + E (rounded as in the reference),
 //     evaluate = scale * log(1 + exp(-z))        = scale * log(w)            -- exactly 0 once E < 2^-53, Inf once exp overflows

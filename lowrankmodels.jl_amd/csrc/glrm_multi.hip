@@ -62,9 +62,11 @@ static int setup_split(glrm_handle* h) {
 
 // GDC = 8 when no embedding is wider (gradient registers per lane: 8 instead of 32); TRIG: see LOSS_*_NOTRIG in glrm_engine.hpp
 // kind-specialised instantiations (glrm_multi.hpp: MULTI_KM_*) exist for the small-dimension, no-PeriodicLoss variants
-static int kind_class(const glrm_handle* h) { // 0 = all kinds, 1 = MultinomialLoss only, 2 = MultinomialLoss + scalar losses
-  if (!env_int("GLRM_HIP_MULTI_KINDS", 1)) return 0;
-  return h->multi_kmask == MULTI_KM_MNL ? 1 : ((h->multi_kmask & ~(MULTI_KM_MNL | MULTI_KM_SCALAR)) == 0 && (h->multi_kmask & MULTI_KM_MNL) ? 2 : 0);
+static int kind_class(const glrm_handle* h) { // 0 = all kinds, 1 = MultinomialLoss only, 2 = MultinomialLoss + scalar losses, 3 = ordinal
+  if (!env_int("GLRM_HIP_MULTI_KINDS", 1)) return 0; // (BvSLoss / MultinomialOrdinalLoss: the columns of an ordinal data frame)
+  if (h->multi_kmask == MULTI_KM_MNL) return 1;
+  if ((h->multi_kmask & ~(MULTI_KM_MNL | MULTI_KM_SCALAR)) == 0 && (h->multi_kmask & MULTI_KM_MNL)) return 2;
+  return h->multi_kmask != 0 && (h->multi_kmask & ~MULTI_KM_ORD) == 0 ? 3 : 0;
 }
 
 template <bool GRAD>
@@ -74,6 +76,7 @@ static void launch_colpass(bool small, bool trig, int kc, dim3 grid, size_t lds,
     if (trig) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, true>), grid, dim3(512), lds, st, sa);
     else if (kc == 1) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, false, MULTI_KM_MNL>), grid, dim3(512), lds, st, sa);
     else if (kc == 2) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, false, MULTI_KM_MNL | MULTI_KM_SCALAR>), grid, dim3(512), lds, st, sa);
+    else if (kc == 3) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, false, MULTI_KM_ORD>), grid, dim3(512), lds, st, sa);
     else hipLaunchKernelGGL((multi_colpass_kernel<GRAD, 8, false>), grid, dim3(512), lds, st, sa);
   } else {
     if (trig) hipLaunchKernelGGL((multi_colpass_kernel<GRAD, D, true>), grid, dim3(512), lds, st, sa);
@@ -166,6 +169,7 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
       if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, true, 8>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
       else if (kc == 1) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false, 8, MULTI_KM_MNL>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
       else if (kc == 2) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false, 8, MULTI_KM_MNL | MULTI_KM_SCALAR>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
+      else if (kc == 3) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false, 8, MULTI_KM_ORD>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
       else hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false, 8>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
     } else if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, true>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
     else hipLaunchKernelGGL((multi_sweep_kernel<true, 1, GLRM_MAX_EMBEDDING_DIM, false>), dim3((unsigned)a.nseg), dim3(64), lds, h->stream, a);
@@ -179,6 +183,7 @@ int glrm_run_multi(glrm_handle* h, bool rows, double min_stepsize, int eval_only
       if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, true, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
       else if (kc == 1) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, false, 8, MULTI_KM_MNL>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
       else if (kc == 2) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, false, 8, MULTI_KM_MNL | MULTI_KM_SCALAR>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
+      else if (kc == 3) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, false, 8, MULTI_KM_ORD>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
       else hipLaunchKernelGGL((multi_sweep_kernel<false, 8, 8, false, 8>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);
     } else {
       if (h->has_trig) hipLaunchKernelGGL((multi_sweep_kernel<false, 8, GLRM_MAX_EMBEDDING_DIM, true>), dim3((unsigned)a.nseg), dim3(512), lds, h->stream, a);

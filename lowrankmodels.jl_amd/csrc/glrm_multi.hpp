@@ -315,6 +315,24 @@ __device__ __forceinline__ double slot_reduce(double v, int lg, Op op) {
   return v;
 }
 
+// Inclusive prefix over the lanes 0 .. sub of a slot.  Slots of <= 16 lanes lie inside one DPP row (row_shr); wider slots span rows, which
+// row_shr does not cross: they shuffle.  The lanes a shift would read from outside the slot keep their own value.
+constexpr int DPP_SHR1 = 0x111, DPP_SHR2 = 0x112, DPP_SHR4 = 0x114, DPP_SHR8 = 0x118; // row_shr:1 / 2 / 4 / 8
+template <class Op>
+__device__ __forceinline__ double slot_prefix(double v, int sub, int lg, Op op) {
+  double t;
+  if (lg <= 4) {
+    t = dpp_f64<DPP_SHR1>(v); v = sub >= 1 ? op(v, t) : v;
+    t = dpp_f64<DPP_SHR2>(v); v = sub >= 2 ? op(v, t) : v;
+    if (lg >= 3) { t = dpp_f64<DPP_SHR4>(v); v = sub >= 4 ? op(v, t) : v; }
+    if (lg >= 4) { t = dpp_f64<DPP_SHR8>(v); v = sub >= 8 ? op(v, t) : v; }
+  } else {
+    for (int o = 1; o < (1 << lg); o <<= 1) { t = __shfl_up(v, o, 64); v = sub >= o ? op(v, t) : v; }
+  }
+  return v;
+}
+struct OpMin { __device__ __forceinline__ double operator()(double a, double b) const { return b < a ? b : a; } };
+
 // Lane-parallel evaluate / grad of one observation per slot.  Called by ALL lanes of the wave in uniform control flow (every
 // cross-lane operation below executes with the full wave; slots differ only in data): dd = embedding dimension of the slot's
 // observation (0 = idle slot), lane `sub` holds u_sub (sub < dd), u0 = u_0 in every lane (scalar losses).  Returns the loss
@@ -328,8 +346,10 @@ __device__ __forceinline__ double slot_reduce(double v, int lg, Op op) {
 // of kinds the model does not have is compiled out.  The all-kinds row kernel is 11 000 instructions with every formula inlined three
 // times (gradient pass, trial pass, fixed-step pass) and spills at the 128-VGPR cap that four waves per SIMD need; for an all-Multinomial
 // model (KM = MULTI_KM_MNL) it is 6 100 instructions, 119 VGPRs, no scratch.  Instantiated: everything, MultinomialLoss only,
-// MultinomialLoss + scalar losses (the categorical + real / boolean columns of a typical data frame).
+// MultinomialLoss + scalar losses (the categorical + real / boolean columns of a typical data frame), BvSLoss + MultinomialOrdinalLoss
+// (an ordinal data frame).
 constexpr int MULTI_KM_ALL = 0xFFFF, MULTI_KM_SCALAR = 1, MULTI_KM_MNL = 1 << GLRM_LOSS_MULTINOMIAL;
+constexpr int MULTI_KM_ORD = (1 << GLRM_LOSS_BVS) | (1 << GLRM_LOSS_MULTINOMIAL_ORDINAL); // the ordinal columns: no exponential of a block at all
 template <int KM>
 constexpr bool mk_has(int kind) { return ((KM >> kind) & 1) != 0; }
 template <bool GRAD, bool TRIG, int KM = MULTI_KM_ALL>
@@ -357,15 +377,23 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
   }
   const double se = slot_reduce(term, lg, OpSum());
   const double ua = __shfl(u, slot_lane0 + ash, 64);
-  // MultinomialOrdinal: thresholds through LDS
+  // MultinomialOrdinal: the thresholds u'_j = min(-TOL, min_{i <= j} (u_i + i TOL)) - j TOL as a prefix minimum over the slot's lanes (the
+  // reference's running `wi < w ? wi : w` skips a NaN u_i: it enters as +Inf)
   const bool ord = mk_has<KM>(GLRM_LOSS_MULTINOMIAL_ORDINAL) && vec && kind == GLRM_LOSS_MULTINOMIAL_ORDINAL;
   double e_hi = 0.0, e_lo = 0.0, u_hi = 0.0;
   if (__any(ord)) {
     const double TOL = 1e-3;
+#if defined(GLRM_MNLORD_LIBM) // A/B build: the thresholds through LDS, one read per lower threshold
     if (ord && in) us[sub] = u;
     wave_sync();
     double w = -TOL;
     if (ord && in) for (int i = 0; i <= sub; ++i) { const double wi = us[i] + i * TOL; w = wi < w ? wi : w; }
+#else
+    (void)us;
+    const double wi = u + sub * TOL;
+    const double pm = slot_prefix((ord && in && wi == wi) ? wi : __builtin_inf(), sub, lg, OpMin());
+    const double w = (ord && in && pm < -TOL) ? pm : -TOL;
+#endif
     const double up = w - sub * TOL;
     const double ea = ord ? fm_exp(up) : 0.0;
     int hi = a > 0 ? a - 1 : 0, lo = a < dd ? a : dd - 1; // lanes of u'_{a-1}, u'_a
@@ -374,7 +402,9 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
     e_hi = __shfl(ea, slot_lane0 + hi, 64); // exp(u'_{a-1})
     e_lo = __shfl(ea, slot_lane0 + lo, 64); // exp(u'_a)
     u_hi = __shfl(up, slot_lane0 + hi, 64);
+#if defined(GLRM_MNLORD_LIBM)
     wave_sync();
+#endif
   }
   // stage 3: per-kind closing formulas (lane-local)
   cg = 0.0;
@@ -401,6 +431,7 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
         break;
       default: { // GLRM_LOSS_MULTINOMIAL_ORDINAL
         if (!mk_has<KM>(GLRM_LOSS_MULTINOMIAL_ORDINAL)) break;
+#if defined(GLRM_MNLORD_LIBM) // A/B build: ocml log and a division per branch (the form before round 3)
         double g = 0.0;
         if (a == 0) {
           L = -s * log(1.0 - e_lo);
@@ -414,6 +445,19 @@ __device__ inline double obs_loss(const LossDesc& l, double u, double u0, double
           if (sub == a) g = -e_lo / den;
           else if (sub == a - 1) g = e_hi / den;
         }
+#else
+        // src/losses.jl:581-609 with the operands selected per level and ONE logarithm, ONE division: level 1: -log(1 - e_1), the top
+        // level: -u'_{d}, between: -log(e_{a-1} - e_a); the two lanes of the thresholds next to the level hold the only nonzero gradients
+        const bool bot = a == 0, top = a == dd;
+        const double den = bot ? 1.0 - e_lo : e_hi - e_lo;
+        const bool at_lo = !top && sub == a, at_hi = !bot && sub == a - 1;
+        L = top ? -s * u_hi : -s * fm_log(den);
+        double g = 0.0;
+        if (GRAD) {
+          const double q = (at_lo ? -e_lo : e_hi) / den;
+          g = top ? (at_hi ? 1.0 : 0.0) : (at_lo || at_hi ? q : 0.0);
+        }
+#endif
         if (GRAD && in) cg = -s * g;
       }
     }

@@ -276,18 +276,22 @@ def test_python_fit_with_offset_and_categoricals():
     assert ch2.objective[-1] <= ch2.objective[0]
 
 
-@pytest.mark.parametrize("model", ["mnl_only", "mnl_and_scalars"])
+@pytest.mark.parametrize("model", ["mnl_only", "mnl_and_scalars", "ordinal"])
 @pytest.mark.parametrize("tall", [False, True])
 def test_kind_specialised_kernels_give_the_bits_of_the_general_ones(model, tall, monkeypatch):
     """Models whose columns are all MultinomialLoss, or MultinomialLoss + scalar losses (the categorical / real / boolean columns of a data
     frame), run kernels compiled without the other kinds' code (glrm_multi.hpp: MULTI_KM_*; 6 100 instead of 11 000 instructions, no
     scratch).  Same formulas in the same order: bit-identical to the all-kinds kernels (GLRM_HIP_MULTI_KINDS=0), and within 1e-5 of the
-    oracle.  tall: columns long enough for the split column passes (multi_colpass_kernel)."""
+    oracle.  ordinal: BvSLoss + MultinomialOrdinalLoss columns under OrdinalReg / MNLOrdinalReg with lastentry1 on X (the reference's ordinal
+    data frame, test/prob_tests/BvSLoss.jl, MultinomialOrdinalLoss.jl).  tall: columns long enough for the split column passes
+    (multi_colpass_kernel)."""
     rng = np.random.default_rng(77 if tall else 78)
     m, n, k = (30000, 6, 6) if tall else (400, 24, 7)
     losses = []
     for f in range(n):
-        if model == "mnl_only" or f % 3 == 0:
+        if model == "ordinal":
+            losses.append(L.MultinomialOrdinalLoss(int(rng.integers(3, 8))) if f % 2 else L.BvSLoss(int(rng.integers(3, 8))))
+        elif model == "mnl_only" or f % 3 == 0:
             losses.append(L.MultinomialLoss(int(rng.integers(2, 7))))
         else:
             losses.append([L.QuadLoss(), L.LogisticLoss(), L.HuberLoss(), L.OrdinalHingeLoss(1, 5)][f % 4])
@@ -304,7 +308,11 @@ def test_kind_specialised_kernels_give_the_bits_of_the_general_ones(model, tall,
     I, J = np.nonzero(rng.random((m, n)) < 0.8)
     D = L.embedding_dim(losses)
     X0, Y0 = 0.5 * rng.standard_normal((k, m)), 0.5 * rng.standard_normal((k, D))
-    g = L.GLRM(A, losses, L.QuadReg(0.1), L.QuadReg(0.1), k, obs=(I, J), X=X0, Y=Y0)
+    rx, ry = L.QuadReg(0.1), L.QuadReg(0.1)
+    if model == "ordinal":
+        rx = L.lastentry1(L.QuadReg(0.1))
+        ry = [L.MNLOrdinalReg(L.QuadReg(0.1)) if f % 2 else L.OrdinalReg(L.QuadReg(0.1)) for f in range(n)]
+    g = L.GLRM(A, losses, rx, ry, k, obs=(I, J), X=X0, Y=Y0)
     pa = g.problem_arrays()
     p = L.ProxGradParams(max_iter=5)
     X0, Y0 = np.asfortranarray(X0), np.asfortranarray(Y0)

@@ -42,6 +42,23 @@ int main() {
     if (Lref > 0) { const double rr = ad / Lref; if (rr > e_Lref) e_Lref = rr; } else if (L != 0) ++nonzero_where_ref_zero;
     const double r1 = dLref != 0 ? fabs((dL - dLref) / dLref) : 0; if (r1 > e_L) e_L = r1;
   }
+  // fm_log on (0, Inf): the arguments of MultinomialOrdinalLoss are 1 - e and e_hi - e_lo in (0, 1); the whole exponent range incl. denormals
+  double e_log = 0, a_log1 = 0;
+  for (int i = 0; i < N; ++i) {
+    const double t = unif(i + 31337);
+    const double x1 = t;                                                        // (0, 1) uniform
+    const double x2 = ldexp(0.5 + 0.5 * t, -(int)(mix(i + 9) % 1074));          // down to the denormals
+    const double x3 = 1.0 - ldexp(t, -(int)(mix(i + 3) % 40));                  // just below 1
+    for (double x : {x1, x2, x3}) {
+      if (!(x > 0)) continue;
+      const long double l = logl((long double)x);
+      const double v = glrm::fm_log(x);
+      if (l != 0) { const double r = (double)fabsl(((long double)v - l) / l); if (r > e_log) e_log = r; }
+      const double ad = (double)fabsl((long double)v - l); if (x > 0.25 && ad > a_log1) a_log1 = ad;
+    }
+  }
+  printf("fm_log on (0, 1] incl. denormals: max rel err %.3g; max abs err on (0.25, 1): %.3g; log(0) %g log(-1) %g log(Inf) %g log(NaN) %g log(1) %g log(4.9e-324) %.17g (libm %.17g)\n",
+         e_log, a_log1, glrm::fm_log(0.0), glrm::fm_log(-1.0), glrm::fm_log(INFINITY), glrm::fm_log(NAN), glrm::fm_log(1.0), glrm::fm_log(4.9e-324), log(4.9e-324));
   double L, dL;
   glrm::fm_logistic<true>(1.0, 1.0, NAN, L, dL);
   printf("max rel err vs long double: exp %.3g  log (w >= 1) %.3g  logistic derivative %.3g\n", e_exp, e_l1p, e_dL);
