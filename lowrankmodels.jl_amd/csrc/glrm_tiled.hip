@@ -69,11 +69,12 @@ int glrm_prepare_tiled(glrm_handle* h) {
   hipStream_t st = h->stream;
   h->tile_cfg = env_int("GLRM_HIP_TILE_CFG", 1);
   h->tile_cfg12 = h->tile_cfg == 2; // experiment: 12-wave heterogeneous row sweep
-  // Loader waves of the double-buffered tiled sweeps (0 = single tile, everybody stages; glrm_tiled.hpp).  Default: two loader waves on
-  // the ROW sweep of uniform QuadLoss models -- measured on one box (tools/gpu_r3c.sh, profiles/r02_lw_default.txt): C2 row sweep 8.31 ->
-  // 7.41 ms, 1M x 50k 26.3 -> 23.0, 1M x 2k 1.65 -> 1.48, 300k x 3k 0.75 -> 0.73, same objective bits; the column passes and the
-  // heterogeneous row sweep lose with them and keep the single tile.  GLRM_HIP_TILE_LW = 0 | 1 | 2 overrides.
-  h->tile_lw = env_int("GLRM_HIP_TILE_LW", h->loss_quad_uniform ? 2 : 0);
+  // Loader waves of the double-buffered tiled sweeps (0 = single tile staged by every wave; glrm_tiled.hpp).  Round 2 ran the ROW sweep of
+  // uniform QuadLoss models on two loader waves (C2 row sweep 8.31 -> 7.41 ms against load / ds_write staging).  Since round 3 the single
+  // tile is staged by LDS-DMA from all waves (dma_tile_all) and wins on the four shapes that default was chosen on (tools/gpu_r3_30.sh,
+  // profiles/r03_tile_dma_all_ab.txt: C2 row sweep 7.50 -> 7.12 ms, 1M x 50k 23.0 -> 20.4, 1M x 2k 1.51 -> 1.48, 300k x 3k 0.73 -> 0.69, same
+  // objective bits): the default is 0 everywhere; GLRM_HIP_TILE_LW = 1 | 2 still selects the loader waves.
+  h->tile_lw = env_int("GLRM_HIP_TILE_LW", 0);
   if (h->tile_lw < 0 || h->tile_lw > 2 || !((h->G == 4 || h->G == 8) && h->R == 8) || !h->tile_cfg) h->tile_lw = 0;
   h->tile_lw_sides = env_int("GLRM_HIP_TILE_LW_SIDES", 1); // bit0: row sweep, bit1: column passes
   h->tile_cfg = h->tile_cfg ? 1 : 0;

@@ -188,6 +188,39 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ other, int64
   }
 }
 
+// Single-buffer staging by LDS-DMA from ALL waves (round 3; GLRM_TILE_DMA_ALL=0 builds the load / ds_write staging of stage_tile for A/B):
+// every 16-byte piece of the tile image is one lane of a global_load_lds_dwordx4 -- all pieces of the tile in flight at once (nine
+// instructions per wave for the 149 KB tile of k = 32), no VGPRs, no ds_write pass -- where stage_tile keeps four loads per thread in
+// flight and needs three rounds of load -> wait -> write.  Lanes past the end of the image are masked off (an inactive lane writes
+// nothing), so the buffer needs no KiB rounding.  Padded rows: piece c = row c / 17, piece c % 17 of it (the pad piece re-reads the
+// 16th); ROT rows are unpadded and the image is a plain copy.  Measured on one box (profiles/r03_tile_dma_all_ab.txt): C5-family row sweep
+// 63.2 -> 54.0 ms, C2 column passes 9.92 -> 9.00 ms, identical objectives.
+#ifndef GLRM_TILE_DMA_ALL
+#define GLRM_TILE_DMA_ALL 1
+#endif
+template <int G, int R, int NW, bool ROT>
+__device__ __forceinline__ void dma_tile_all(const double* __restrict__ other, int64_t lo, int64_t hi, char* buf, int wave, int lane) {
+  constexpr int KPB = G * R * 8, ROWB = tile_row_stride<G, R, ROT>(), CPR = ROWB / 16;
+  const int rows = (int)(hi - lo), total = rows * CPR;
+  const char* src0 = reinterpret_cast<const char*>(other) + lo * KPB;
+  for (int base = wave * 64; base < total; base += NW * 64) {
+    const int c = base + lane;
+    if (c < total) {
+      const char* src;
+      if constexpr (ROT) {
+        src = src0 + c * 16;
+      } else {
+        const int row = c / CPR;
+        int cc = c - row * CPR;
+        cc = cc < CPR - 1 ? cc : CPR - 2; // the pad piece
+        src = src0 + row * KPB + cc * 16;
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(buf + base * 16), 16, 0, 0);
+    }
+  }
+}
+
 // chunk held by register i of a lane whose first chunk sits at byte `ro` of the tile (ro carries the lane's 16-byte slot and, with
 // ROT, its rotation in the chunk field, which register index i then flips: chunk i ^ rot)
 template <bool ROT, int CB>
@@ -276,6 +309,9 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
       __syncthreads(); // everybody is done with the previous tile
 #if defined(GLRM_EXP_NOSTAGE) // timing experiment: stage only the first tile of the pass (results are wrong, the control flow stays finite)
       if (t == tile_begin) stage_tile<G, R, NT, ROT>(a.other, lo, hi, lds);
+#elif GLRM_TILE_DMA_ALL
+      dma_tile_all<G, R, NW, ROT>(a.other, lo, hi, lds, (int)(threadIdx.x >> 6), lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
       stage_tile<G, R, NT, ROT>(a.other, lo, hi, lds);
 #endif
