@@ -34,6 +34,7 @@ using namespace glrm;
 #define GLRM_BLOCKED_NW 1
 #endif
 constexpr int BNW = GLRM_BLOCKED_NW;                                       // waves per workgroup
+constexpr int LOCK_CTR_WORDS = 8 * 32 + 32;                                // lockstep windows: one 128-byte line per XCD + one for the give-up count
 constexpr int tile_rows_b(int kp) { return ((150 * 1024) / (kp * 8 + 16)) / 16 * 16; } // the LDS tile unit the super-tiles are counted in
 
 int glrm_setup_blocked(glrm_handle* h) {
@@ -63,15 +64,17 @@ int glrm_setup_blocked(glrm_handle* h) {
     return reuse >= 2.0;
   };
   const bool br = decide(true), bc = decide(false);
-  auto sups = [&](int64_t nopp, int& tps, int& nsup) {
+  h->lockstep = bc && (h->G * 100 + h->R == 808 || h->G * 100 + h->R == 408) && env_int("GLRM_HIP_LOCKSTEP", 0) ? 1 : 0; // column view in lockstep windows (below); an environment switch, never the shard
+  auto sups = [&](int64_t nopp, int& tps, int& nsup, bool lock) {
     const int64_t ntiles = (nopp + T - 1) / T;
     int64_t t = ((int64_t)128 * 1024 * 1024) / ((int64_t)T * h->kp * 8); // ~128 MB of the opposing factor per super-tile
     t = env_int("GLRM_HIP_BLOCKED_TPS", (int)(t < 1 ? 1 : t));
+    if (lock) t = ntiles > 0 ? ntiles : 1; // one pass over the whole factor, no partial sums per super-tile
     tps = (int)t;
     nsup = (int)((ntiles + t - 1) / t);
   };
   if (br) {
-    sups(h->n, h->tiles_per_sup_r, h->nsup_r);
+    sups(h->n, h->tiles_per_sup_r, h->nsup_r, false);
     const int64_t ml1 = h->ml > 0 ? h->ml : 1;
     HIPCK(hipMalloc((void**)&h->part_r, (size_t)ml1 * h->nsup_r * (h->kp + 2) * 8));
     HIPCK(hipMalloc((void**)&h->gsum_r, (size_t)ml1 * h->kp * 8));
@@ -82,7 +85,7 @@ int glrm_setup_blocked(glrm_handle* h) {
     h->blocked_row = 1;
   }
   if (bc) {
-    sups(h->m, h->tiles_per_sup, h->nsup);
+    sups(h->m, h->tiles_per_sup, h->nsup, h->lockstep != 0);
     const int64_t nl1 = h->nl > 0 ? h->nl : 1;
     HIPCK(hipMalloc((void**)&h->part, (size_t)nl1 * h->nsup * (h->kp + 2) * 8));
     HIPCK(hipMalloc((void**)&h->gsum, (size_t)nl1 * h->kp * 8));
@@ -93,6 +96,7 @@ int glrm_setup_blocked(glrm_handle* h) {
     h->blocked_col = 1;
   }
   if ((br || bc) && !h->nactive) HIPCK(hipMalloc((void**)&h->nactive, 4));
+  if (h->lockstep && !h->lock_ctr) HIPCK(hipMalloc((void**)&h->lock_ctr, LOCK_CTR_WORDS * 4));
   return GLRM_OK;
 }
 
@@ -136,6 +140,143 @@ static int launch_blocked_inst(glrm_handle* h, TiledArgs a) {
   }
   HIPCK(hipGetLastError());
   return GLRM_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ lockstep windows (round 3)
+// The launches above bound the DRIFT of the groups by a launch boundary every 128 MB of the opposing factor; inside a super-tile the groups
+// of an XCD spread over far more than its 4 MB of L2 (TCC hit rate of the C4 column passes: 19 %, profiles/r03_c4_tcc_hit_rate.txt), and
+// the passes run at what a miss stream reaches (8 TB/s).  Here the whole pass is ONE persistent kernel: a lane group keeps its column's
+// gradient in registers from the first to the last row (no partial sums per super-tile at all: nsup = 1), walks the factor in windows of
+// ~2 MB, and after every window the workgroups that share an XCD (block b runs on XCD b % 8) meet at a counter, so that the ~3 000 columns
+// an XCD holds read each window out of ITS L2 while it is there (every row of a window is met ~3 times per XCD and residency round at C4).
+// The meeting is a performance device only -- no data passes between workgroups, a late or lost arrival costs cache hits, never a result:
+// thread 0 adds 1 to its XCD's counter and polls it at most la.spin times; a workgroup whose poll runs out stops meeting (and, not
+// arriving any more, lets every other workgroup of its XCD run out once, in parallel): the kernel cannot hang.  Sums: a column's gradient
+// terms are added in list order from its first row to its last, its losses in list order inside a window and the windows in order -- a
+// function of (m, kp, window size) only.
+struct LockArgs {
+  unsigned int* ctr;
+  int wt;      // LDS-tile units (tile_rows_b rows) per window
+  int nwin;    // windows per pass
+  int nrounds; // residency rounds: workgroup b takes segments ((r * gridDim.x + b) * SPB ...) in round r
+  int spin;    // polls before a workgroup gives up meeting; 0: no meeting at all (sparse trial rounds)
+};
+
+template <int G, int R, int NW, int LOSS, bool GRAD>
+__global__ void __launch_bounds__(NW * 64, 16 / NW) lockstep_col_pass_kernel(const TiledArgs a, const LockArgs la) {
+  constexpr int KP = G * R, NGW = 64 / G, SPB = NW * NGW, PSTRIDE = KP + 2, T = tile_rows_b(KP);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane % G, gi = lane / G;
+  const unsigned xcd = blockIdx.x & 7u;
+  const unsigned members = (gridDim.x - xcd + 7u) / 8u; // workgroups of this launch on the same XCD
+  unsigned int* ctr = la.ctr + xcd * 32;
+  bool meeting = la.spin > 0; // thread 0's
+  unsigned step = 0;
+  for (int r = 0; r < la.nrounds; ++r) {
+    const int64_t slot = ((int64_t)r * gridDim.x + blockIdx.x) * SPB + wave * NGW + gi;
+    bool have = slot < a.nseg;
+    const int64_t seg = slot;
+    if (!GRAD && have) have = a.active[seg] != 0;
+    if (la.spin == 0 && !__syncthreads_or(have ? 1 : 0)) continue; // sparse round: nothing to evaluate in this column group
+    const int64_t beg = have ? a.ptr[seg] : 0, end = have ? a.ptr[seg + 1] : 0;
+    const int64_t gseg = a.own_offset + (have ? seg : 0);
+    const double2* xp = reinterpret_cast<const double2*>(GRAD ? a.own + gseg * KP : a.trial + (have ? seg : 0) * (int64_t)KP);
+    Vec<G, R> x, gacc; // the gradient is carried through the windows (tiled_pass<..., ACC = true>): list order from the first row to the last
+#pragma unroll
+    for (int i = 0; i < R / 2; ++i) {
+      x.v[i] = have ? xp[i * G + j] : make_double2(0.0, 0.0);
+      gacc.v[i] = make_double2(0.0, 0.0);
+    }
+    LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
+    if constexpr (loss_mode(LOSS) != 2) segloss = load_loss(a.losses, (a.loss_by_segment && have) ? gseg : 0);
+    int64_t pos = beg;
+    double Jacc = 0.0;
+    for (int w = 0; w < la.nwin; ++w) {
+      double J;
+      tiled_pass<G, R, NW, T, LOSS, GRAD, true, 0, false, true>(a, nullptr, x, gacc, J, have, pos, end, w * la.wt, (w + 1) * la.wt, segloss, lane, j);
+      Jacc += J;
+      if (la.spin > 0) { // meet the other workgroups of the XCD at the end of the window
+        ++step;
+        if (NW > 1) __syncthreads();
+        if (threadIdx.x == 0 && meeting) {
+          __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned target = step * members;
+          int polls = 0;
+          while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            if (++polls > la.spin) {
+              meeting = false;
+              __hip_atomic_fetch_add(la.ctr + 8 * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // reported by the host
+              break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+          }
+        }
+        if (NW > 1) __syncthreads();
+      }
+    }
+    if (have) {
+      double* p = a.part + (int64_t)seg * a.nsup * PSTRIDE; // nsup = 1
+      if (GRAD) {
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) *reinterpret_cast<double2*>(p + i * 2 * G + 2 * j) = gacc.v[i];
+      }
+      if (j == 0) p[KP] = Jacc;
+    }
+  }
+}
+
+template <int G, int R, int LOSS, bool GRAD>
+static int launch_lockstep_inst(glrm_handle* h, const TiledArgs& a, bool meet) {
+  constexpr int KP = G * R, T = tile_rows_b(KP), NW = 4, SPB = NW * (64 / G);
+  auto kernel = lockstep_col_pass_kernel<G, R, NW, LOSS, GRAD>;
+  static std::atomic<int64_t> grid_cache{0};
+  int64_t gridmax = grid_cache.load(std::memory_order_relaxed);
+  if (gridmax == 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NW * 64, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+    hipDeviceProp_t prop;
+    int cus = 256;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    gridmax = std::max<int64_t>(8, (int64_t)nb * cus / 8 * 8); // every workgroup of the launch resident at once
+    grid_cache.store(gridmax, std::memory_order_relaxed);
+  }
+  const int64_t need = (a.nseg + SPB - 1) / SPB;
+  if (need <= 0) return GLRM_OK;
+  LockArgs la{};
+  la.nrounds = (int)((need + gridmax - 1) / gridmax);
+  const int64_t grid = std::min<int64_t>(gridmax, ((need + la.nrounds - 1) / la.nrounds + 7) / 8 * 8); // equal rounds
+  const int64_t ntiles = (a.n_other + T - 1) / T;
+  const int wt_default = (int)std::max<int64_t>(1, ((int64_t)2 * 1024 * 1024) / ((int64_t)T * KP * 8)); // ~2 MB of the factor per window
+  la.wt = std::max(1, env_int("GLRM_HIP_LOCKSTEP_WT", wt_default));
+  la.nwin = (int)((ntiles + la.wt - 1) / la.wt);
+  la.spin = meet ? std::max(1, env_int("GLRM_HIP_LOCKSTEP_SPIN", 4000)) : 0;
+  la.ctr = h->lock_ctr;
+  if (meet) HIPCK(hipMemsetAsync(h->lock_ctr, 0, LOCK_CTR_WORDS * 4, h->stream));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(NW * 64), 0, h->stream, a, la);
+  HIPCK(hipGetLastError());
+  return GLRM_OK;
+}
+
+template <int G, int R>
+static int launch_lockstep_layout(glrm_handle* h, int loss, bool grad, const TiledArgs& a, bool meet) {
+#define GLRM_LS(LOSSV) (grad ? launch_lockstep_inst<G, R, LOSSV, true>(h, a, meet) : launch_lockstep_inst<G, R, LOSSV, false>(h, a, meet))
+  switch (loss) {
+    case LOSS_QUAD_UNIFORM: return GLRM_LS(0);
+    case LOSS_SEGMENT: return GLRM_LS(1);
+    case LOSS_SEGMENT_NOTRIG: return GLRM_LS(3);
+    case LOSS_PER_OBS_NOTRIG: return GLRM_LS(4);
+    default: return GLRM_LS(2);
+  }
+#undef GLRM_LS
+}
+
+static int launch_lockstep(glrm_handle* h, int loss, bool grad, const TiledArgs& a, bool meet) {
+  switch (h->G * 100 + h->R) {
+    case 408: return launch_lockstep_layout<4, 8>(h, loss, grad, a, meet);
+    case 808: return launch_lockstep_layout<8, 8>(h, loss, grad, a, meet);
+    default: return fail(GLRM_ERR_UNSUPPORTED, "no lockstep pass kernel for lane layout G=%d R=%d", h->G, h->R);
+  }
 }
 
 template <int G, int R>
@@ -205,7 +346,9 @@ int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, d
   }
   int rc;
   HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
-  if ((rc = launch_blocked(h, loss, true, a))) return rc;        // gradient + loss partials, super-tile by super-tile
+  const bool lock = !rows && h->lockstep; // the same kernel in every pass (one summation order); it meets at the windows while most columns take part
+  if (lock) { if ((rc = launch_lockstep(h, loss, true, a, true))) return rc; }
+  else if ((rc = launch_blocked(h, loss, true, a))) return rc;   // gradient + loss partials, super-tile by super-tile
   glrm_launch_col_small(h->kp, 0, a, h->stream);                 // reduce in super-tile order, J_old, first trial point
   HIPCK(hipGetLastError());
   if (eval_only || a.fixed_alpha > 0.0) return GLRM_OK;
@@ -215,7 +358,8 @@ int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, d
     HIPCK(hipStreamSynchronize(h->stream));
     if (nact == 0) break;
     HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
-    if ((rc = launch_blocked(h, loss, false, a))) return rc;     // loss partials at the trial points of the searching segments
+    if (lock) { if ((rc = launch_lockstep(h, loss, false, a, (int64_t)nact * 4 >= a.nseg))) return rc; }
+    else if ((rc = launch_blocked(h, loss, false, a))) return rc; // loss partials at the trial points of the searching segments
     glrm_launch_col_small(h->kp, 1, a, h->stream);               // accept / shrink / give up, next trial point
     HIPCK(hipGetLastError());
   }

@@ -59,6 +59,9 @@ struct glrm_handle {
   double *part = nullptr, *gsum = nullptr, *trialbuf = nullptr, *joldbuf = nullptr;
   int32_t *activebuf = nullptr, *ntrialbuf = nullptr;
   unsigned int* nactive = nullptr;
+  // lockstep form of the phase-aligned column passes (glrm_blocked.hip: lockstep_col_pass_kernel): 0 off, 1 on; per-XCD window counters
+  int lockstep = 0;
+  unsigned int* lock_ctr = nullptr;
   int* dflag = nullptr;
   uint8_t* rowdescid = nullptr;       // heterogeneous tiled row sweep: id of the loss descriptor of every entry of the row view
   glrm_loss* udesc = nullptr;         // the model's distinct loss descriptors (<= 256), device

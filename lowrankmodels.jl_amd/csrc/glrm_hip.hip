@@ -585,7 +585,7 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
                   h->activebuf, h->ntrialbuf, h->nactive, h->dflag, h->Arow, h->Acol, h->part_r, h->gsum_r, h->trial_r,
                   h->jold_r, h->active_r, h->ntrial_r, h->ystart, h->mtrial, h->mpart_loss, h->mpart_G, h->mgtot,
                   h->mobjold, h->mactive, h->mnactive, h->colperm, h->rowperm, h->seglist_r, h->seglist_c, h->rowdescid, h->udesc,
-                  h->gramH, h->gram_part, h->jloss_r, h->jloss_c};
+                  h->gramH, h->gram_part, h->jloss_r, h->jloss_c, h->lock_ctr};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->iter_exec) (void)hipGraphExecDestroy(h->iter_exec);

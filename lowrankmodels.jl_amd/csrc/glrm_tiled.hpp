@@ -239,7 +239,7 @@ __device__ __forceinline__ double2 tile_chunk(const char* tile, int ro, int i) {
 // barrier.  It is what the phase-aligned pass kernels below run: when every group in flight walks its sorted list through the same
 // super-tile at the same time, those reads hit the 4 MB L2 of the XCD (~30 TB/s) instead of the Infinity Cache / HBM (6.5-8 TB/s,
 // profiles/r02_ubench_gather.txt).
-template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false, int LW = 0, bool ROTK = false>
+template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false, int LW = 0, bool ROTK = false, bool ACC = false>
 __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const Vec<G, R>& xv, Vec<G, R>& g, double& J,
                                            bool active, int64_t& pos, int64_t end, int tile_begin, int tile_end,
                                            const LossDesc& segloss, int lane, int j, int rot = 0) {
@@ -255,7 +255,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
   constexpr bool FOUR = (G == 4 || G == 8) && LOSS != 0; // the whole batch of G observations per step (below)
   const double two_scale = 2 * segloss.scale;
   J = 0.0;
-  if (GRAD) {
+  if (GRAD && !ACC) { // ACC: the caller's gradient is carried on (lockstep windows, glrm_blocked.hip)
 #pragma unroll
     for (int i = 0; i < R / 2; ++i) g.v[i] = make_double2(0.0, 0.0);
   }

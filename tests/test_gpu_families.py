@@ -131,6 +131,51 @@ def test_phase_aligned_passes_row_chunks_and_sparse_solver(monkeypatch):
     assert cases.fro_err(outs[1][1], outs[0][1]) < TOL and cases.fro_err(outs[1][2], outs[0][2]) < TOL
 
 
+# ------------------------------------------------------------------------------------------------ lockstep windows (column view)
+
+def force_lockstep(monkeypatch, wt="1", spin="4000"):
+    """Column passes as one persistent kernel that walks the opposing factor in windows of `wt` LDS-tile units (288 rows at k = 64) and
+    meets the other workgroups of its XCD after every window (csrc/glrm_blocked.hip: lockstep_col_pass_kernel); rows on the phase-aligned
+    launches.  spin = polls before a workgroup gives the meeting up (1: practically at once -- results must not depend on it)."""
+    force_blocked(monkeypatch)
+    monkeypatch.setenv("GLRM_HIP_LOCKSTEP", "1")
+    monkeypatch.setenv("GLRM_HIP_LOCKSTEP_WT", wt)
+    monkeypatch.setenv("GLRM_HIP_LOCKSTEP_SPIN", spin)
+
+
+@pytest.mark.parametrize("spin", ["4000", "1"])
+def test_lockstep_windows_c4_recipe(monkeypatch, spin):
+    """The C4 recipe at 20 000 x 2 000 with 70 one-tile windows; meeting the XCD's other workgroups or giving up on them changes no bit."""
+    force_lockstep(monkeypatch, spin=spin)
+    pa, Xn, Yn, _, _ = c4_problem(20000, 2000, 100)
+    against_oracle(pa, Xn, Yn, L.ProxGradParams(max_iter=12), BLOCKED_ROWS | BLOCKED_COLS, tiled=1)
+    a = cases.run_engine(hip(), pa, Xn, Yn, L.ProxGradParams(max_iter=6), tiled=1)
+    monkeypatch.setenv("GLRM_HIP_LOCKSTEP_SPIN", "4000" if spin == "1" else "1")
+    monkeypatch.setenv("GLRM_HIP_LOCKSTEP_WT", "3")   # another window size: another grouping of the loss sums only
+    b = cases.run_engine(hip(), pa, Xn, Yn, L.ProxGradParams(max_iter=6), tiled=1)
+    assert cases.rel_err(b[0], a[0]) < 1e-12 and cases.fro_err(b[1], a[1]) < 1e-9 and cases.fro_err(b[2], a[2]) < 1e-9
+
+
+def test_lockstep_windows_two_residency_rounds_shards_and_mixed_losses(monkeypatch):
+    """40 000 columns: more column groups than the chip holds at once (two rounds per pass); ragged column shards reproduce the single handle
+    bit for bit; k = 32 with Quad / Logistic / OrdinalHinge columns on the per-observation-descriptor variant."""
+    force_lockstep(monkeypatch, wt="2")
+    pa, Xn, Yn, _, _ = c4_problem(3000, 40000, 100)
+    params = L.ProxGradParams(max_iter=5)
+    against_oracle(pa, Xn, Yn, params, BLOCKED_ROWS | BLOCKED_COLS, tiled=1)
+    api = hip()
+    o1, X1, Y1, _ = cases.run_engine(api, pa, Xn, Yn, params, tiled=1)
+    o2, X2, Y2, _ = cases.run_shards_on_one_device(api, pa, Xn, Yn, params, [0, 1000, 3000], [0, 33001, 40000], tiled=1)
+    assert np.array_equal(o2, o1[1:]) and np.array_equal(X2, X1) and np.array_equal(Y2, Y1)
+    m, n, k, q = 2500, 2000, 32, 100
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, q, value_model=0, loss_mix=1)
+    kinds = [L.QuadLoss().descriptor(), L.LogisticLoss().descriptor(), L.OrdinalHingeLoss(1, 5).descriptor()]
+    losses = np.array([kinds[f % 3] for f in range(n)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 1.0)], dtype=_capi.REG_DTYPE)
+    pa3 = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, losses, reg, reg)
+    against_oracle(pa3, 0.3 * X0, 0.3 * Y0, L.ProxGradParams(max_iter=10), BLOCKED_ROWS | BLOCKED_COLS, tiled=1)
+
+
 # ------------------------------------------------------------------------------------------------ register-cached row sweep, MAXT = 7
 
 def test_regcached_two_waves_seven_trips_at_full_c4_density(monkeypatch):
