@@ -110,7 +110,9 @@ def one(seed):
         detail = (stable, e, st_g["tiled"])
         if ok and seed % 3 == 0 and g.m >= 6 and g.n >= 6 and p.inner_iter_X == 1:  # three ragged shards on one device == the single handle, bit for bit
             rb, cb = [0, g.m // 5, g.m // 2 + 1, g.m], [0, g.n // 4 + 1, g.n // 2, g.n]
-            o_s, X_s, Y_s, _ = cases.run_shards_on_one_device(_capi.hip_api(), pa, X0, Y0, p, rb, cb, **kw)
+            # the step-level harness has no stop rule: as many iterations as the whole-fit call recorded (it stops when the objective rises)
+            ps = L.ProxGradParams(p.stepsize, max_iter=len(o_g) - 1, inner_iter=1, abs_tol=0.0, rel_tol=-1.0)
+            o_s, X_s, Y_s, _ = cases.run_shards_on_one_device(_capi.hip_api(), pa, X0, Y0, ps, rb, cb, **kw)
             same = np.array_equal(o_s, o_g[1:]) and np.array_equal(X_s, X_g) and np.array_equal(Y_s, Y_g)
             if not same:
                 return "SHARD-MISMATCH", fam, (stable, cases.rel_err(o_s, o_g[1:]), cases.fro_err(X_s, X_g), cases.fro_err(Y_s, Y_g))

@@ -1,5 +1,7 @@
 """-m gpu: randomized models across the whole descriptor table (14 losses, 5 regularizers, 4 wrappers, duplicates, unsorted lists,
 inner iterations, both solvers) -- HIP engine vs CPU oracle through the C ABI, north-star tolerance 1e-5."""
+import os
+
 import numpy as np
 import pytest
 
@@ -147,3 +149,18 @@ def test_random_models_sparse_solver(seed):
             api.destroy(h)
     assert len(res[0][0]) == len(res[1][0])
     assert cases.rel_err(res[1][0], res[0][0]) < TOL and cases.fro_err(res[1][1], res[0][1]) < TOL and cases.fro_err(res[1][2], res[0][2]) < TOL
+
+
+@pytest.mark.parametrize("seed", range(5000, 5036))
+def test_random_models_with_the_sweep_family_rotated(seed):
+    """tests/perf/soak_fuzz.py on 36 seeds of its own: the model of the seed on the family the seed selects (auto / gather only / LDS-tiled /
+    phase-aligned passes with small super-tiles / cached row sweep, persistent or not) against the oracle, and on every third seed three
+    ragged shards on one device against the single handle, bit for bit.  A deviation only passes as "ill-conditioned" if the oracle does not
+    reproduce itself from reversed observation lists or 1e-13-perturbed starts (profiles/r03_soak_fuzz.txt: 7 of 2 000 seeds)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("soak_fuzz", os.path.join(os.path.dirname(os.path.abspath(__file__)), "perf", "soak_fuzz.py"))
+    soak = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(soak)
+    O.set_threads(4)
+    res, fam, detail = soak.one(seed)
+    assert res in ("ok", "skip", "ill-conditioned"), (seed, fam, res, detail)
