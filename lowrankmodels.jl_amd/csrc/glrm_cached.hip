@@ -474,8 +474,14 @@ __global__ void __launch_bounds__(128, 2) regcached_persist_kernel(const CachedA
     for (int q = 0; q < PF; ++q) {
       int e = q * 128 + tid;
       e = e < len ? e : (len > 0 ? len - 1 : 0);
+#if defined(GLRM_CACHED_NT) // experiment: the streamed lists bypass the caches' retention (the opposing factor is what should stay in them)
+      pi[q] = len > 0 ? __builtin_nontemporal_load(a.idx + beg + e) : 0;
+      const double vd = len > 0 ? __builtin_nontemporal_load(a.vals + beg + e) : 0.0;
+      const int2 v = make_int2(__double2loint(vd), __double2hiint(vd));
+#else
       pi[q] = len > 0 ? a.idx[beg + e] : 0;
       const int2 v = len > 0 ? *reinterpret_cast<const int2*>(a.vals + beg + e) : make_int2(0, 0);
+#endif
       pv[2 * q] = v.x; pv[2 * q + 1] = v.y;
     }
   };
