@@ -48,3 +48,41 @@ def test_dma_staged_tile_equals_the_staged_rows(G, R, rows, rot):
         assert np.array_equal(got, src[r]), (r,)
     assert written[:rows * stride].max() == 1 and written[:rows * stride].min() == 1   # every byte of the image exactly once
     assert written[rows * stride:].sum() == 0 and np.all(lds[rows * stride:] == 0xEE)  # nothing behind the image
+
+
+# ------------------------------------------------------------------------------------------------ slot_prefix (csrc/glrm_multi.hpp)
+def slot_prefix_min(v, lg):
+    """The inclusive prefix minimum over the lanes of a slot as the general sweeps form it for MultinomialOrdinalLoss's thresholds: slots of
+    <= 16 lanes by row_shr:1/2/4/8 DPP steps (a DPP row is 16 lanes; a lane whose source falls outside its row keeps an undefined value, which
+    the `sub >= o` select discards), wider slots by __shfl_up over the wave."""
+    v = np.array(v, dtype=float)
+    P = 1 << lg
+    sub = np.arange(64) & (P - 1)
+    offsets = [o for o in (1, 2, 4, 8) if o < P] if lg <= 4 else [1 << i for i in range(lg)]
+    if lg <= 4 and P >= 2 and 2 not in offsets:
+        offsets = [1, 2]            # the device code always runs the first two steps (lgP >= 2 in the engine)
+    for o in offsets:
+        t = np.full(64, np.nan)     # NaN = "undefined": must never be selected
+        for lane in range(64):
+            srcl = lane - o
+            if lg <= 4:
+                if srcl >= 0 and srcl // 16 == lane // 16:
+                    t[lane] = v[srcl]
+            else:
+                t[lane] = v[srcl] if srcl >= 0 else v[lane]
+        take = sub >= o
+        assert not np.any(np.isnan(t[take])), "a selected lane read outside its DPP row"
+        v = np.where(take & (t < v), t, v)
+    return v
+
+
+@pytest.mark.parametrize("lg", [2, 3, 4, 5, 6])
+def test_slot_prefix_minimum_equals_the_running_minimum(lg):
+    rng = np.random.default_rng(lg)
+    P = 1 << lg
+    for _ in range(50):
+        v = rng.standard_normal(64)
+        v[rng.random(64) < 0.2] = np.inf     # lanes outside the embedding / NaN thresholds enter as +Inf
+        got = slot_prefix_min(v, lg)
+        want = np.concatenate([np.minimum.accumulate(v[s:s + P]) for s in range(0, 64, P)])
+        assert np.array_equal(got, want)
