@@ -398,6 +398,55 @@ typedef struct glrm_kernel_stats {
 
 int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int reset);
 
+/*
+ * The ORDER in which a handle adds the terms of a segment's sums -- the k-term dot product <x_e, y_f>, the loss sum of
+ * row_objective / col_objective (src/evaluate_fit.jl:24-55) and the gradient axpys (src/algorithms/proxgrad.jl:122-132,165-175).
+ * The reference adds them in list order; the engine's sweep families add the same fp64 terms in orders fixed by their lane
+ * layouts.  The accept test of the line search is a strict `<` between two such sums (proxgrad.jl:143,187), so a trajectory can
+ * fork on the last bit: this query is what lets a checker attribute a deviation to summation order (SURVEY.md section 7.3 item 1;
+ * section 8(b)'s `line_search_sum_order`).  The CPU oracle adopts a reported order (glrm_cpu_set_sum_order) and then reproduces
+ * the engine's factors BIT FOR BIT (tests/test_gpu_sum_order.py), while oracle(reference order) vs oracle(engine order) shows
+ * what the order alone does to a trajectory.  Additive in ABI 2 (a host that never calls it is unaffected).
+ *
+ * Common to every family: lane j of the `lanes` lanes that share an observation holds the components {2 lanes i + 2 j, + 1},
+ * i = 0 .. comps/2 - 1, of the zero-padded kp = lanes x comps vector; its partial dot product is one fma chain over them in that
+ * order (with `rotate`: over the chunks i ^ ((global segment id & 7) >> 1)); the lanes' partials are added by an xor butterfly
+ * (pairs at distance 1, then 2, 4, 8).  The regularizer's sum of squares / absolute values is formed the same way.
+ */
+#define GLRM_ORDER_REFERENCE 0 /* list order, one accumulator per sum (the oracle's default; no engine family reports it) */
+#define GLRM_ORDER_STRIDED 1   /* gather sweeps / cached row sweep: a segment is shared by W waves of 64 / lanes lane groups; group q
+                                  of the T = W x 64 / lanes groups takes the observations q, q + T, q + 2T, ... in ascending order into
+                                  its own loss and gradient accumulators; the groups of a wave are added by an xor butterfly (distance
+                                  1, 2, 4, ... in group index), the waves in ascending order starting from 0.  batch = 4: the group's
+                                  loss accumulator is four partials (observation u of each trip of 4, u = 0..3) added as a butterfly */
+#define GLRM_ORDER_WINDOWED 2  /* LDS-tiled sweeps / phase-aligned passes: ONE lane group per segment walks the list in list order;
+                                  gradient terms are added in list order; the loss terms go to `batch` partial sums by the entry's
+                                  position inside its window modulo batch (a window = the entries whose opposing index lies in
+                                  [w window, (w + 1) window)), added as a butterfly at the end of a super-tile; with
+                                  windows_per_sup > 0 both sums start from 0 in every super-tile of that many windows and the
+                                  super-tiles' partial sums are added in ascending order starting from 0 */
+#define GLRM_ORDER_OTHER 3     /* dense MFMA path, general sweeps: not restated by the oracle */
+
+typedef struct glrm_sum_order {
+  int32_t family;          /* GLRM_ORDER_* */
+  int32_t lanes, comps;    /* G, R: kp = lanes x comps */
+  int32_t waves;           /* STRIDED: waves per segment; 0 = from the segment's own length: 1 below waves4_from, 4 below waves8_from, else 8 */
+  int64_t waves4_from, waves8_from;
+  int64_t cached_maxlen;   /* STRIDED, rows: segments of at most this many observations are shared by cached_waves waves instead (-1: none) */
+  int32_t cached_waves;
+  int32_t batch;           /* loss partial sums per lane group: STRIDED 1 or 4 (4 applies to one-wave segments only when batch_one_wave_only), WINDOWED 2 or lanes */
+  int32_t batch_one_wave_only;
+  int32_t rotate;          /* WINDOWED: 1 = chunk walk i ^ ((global segment id & 7) >> 1) in the dot products of the passes */
+  int64_t window;          /* WINDOWED: opposing vectors per window */
+  int64_t windows_per_sup; /* WINDOWED: windows per super-tile; 0 = the whole list is one super-tile and nothing is re-added */
+  int32_t private_order;   /* 1 = the engine walks a private copy of the list in another order than the caller's (tile sort, grouping by
+                              loss kind): the order above applies to THAT copy and cannot be reproduced from the caller's lists */
+  int32_t reserved;
+} glrm_sum_order; /* 80 bytes */
+
+/* which: 0 = the row view (X half-step), 1 = the column view (Y half-step).  Needs a finalized handle. */
+int glrm_hip_sum_order(glrm_handle* h, int32_t which, glrm_sum_order* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -110,12 +110,28 @@ class CKernelStats(C.Structure):
         return {f: getattr(self, f) for f, _ in self._fields_}
 
 
+class CSumOrder(C.Structure):
+    """glrm_sum_order: the order in which a handle adds the terms of a segment's sums (include/glrm_hip.h)."""
+    _fields_ = [("family", C.c_int32), ("lanes", C.c_int32), ("comps", C.c_int32), ("waves", C.c_int32),
+                ("waves4_from", C.c_int64), ("waves8_from", C.c_int64), ("cached_maxlen", C.c_int64),
+                ("cached_waves", C.c_int32), ("batch", C.c_int32), ("batch_one_wave_only", C.c_int32), ("rotate", C.c_int32),
+                ("window", C.c_int64), ("windows_per_sup", C.c_int64), ("private_order", C.c_int32), ("reserved", C.c_int32)]
+    FAMILIES = {0: "reference", 1: "strided", 2: "windowed", 3: "other"}
+
+    def asdict(self):
+        d = {f: int(getattr(self, f)) for f, _ in self._fields_ if f != "reserved"}
+        d["family_name"] = self.FAMILIES.get(d["family"], "?")
+        return d
+
+
+assert C.sizeof(CSumOrder) == 80
+
 #: every symbol include/glrm_hip.h declares (suffix after the prefix); the CPU test-suite checks
 #: that the built library exports all of them.
 ABI_SYMBOLS = (
     "version", "last_error", "create", "destroy", "signature", "finalize", "fit", "fit_sparse", "objective", "factor_ld", "bind_buffers",
     "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "gradstep_x", "gradstep_y", "col_losses", "row_penalties",
-    "col_penalties", "set_regularizers", "subset", "init_svd", "error_metric", "impute", "sum", "synchronize", "kernel_stats",
+    "col_penalties", "set_regularizers", "subset", "init_svd", "error_metric", "impute", "sum", "synchronize", "kernel_stats", "sum_order",
     "multi_create", "multi_fit", "multi_set_regularizers", "multi_info", "multi_destroy",
 )
 
@@ -195,6 +211,7 @@ class Api:
             "sum": (C.c_int, [H, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]),
             "synchronize": (C.c_int, [H]),
             "kernel_stats": (C.c_int, [H, C.POINTER(CKernelStats), C.c_int]),
+            "sum_order": (C.c_int, [H, C.c_int32, C.POINTER(CSumOrder)]),
             "multi_create": (C.c_int, [C.POINTER(H), C.POINTER(CProblem), C.POINTER(COptions), C.POINTER(CMultiOptions)]),
             "multi_fit": (C.c_int, [H, C.POINTER(CParams), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
                                     C.POINTER(C.c_int64)]),
@@ -414,6 +431,13 @@ class Api:
         st = CKernelStats()
         self._ck(self._f["kernel_stats"](h, C.byref(st), 1 if reset else 0))
         return st.asdict()
+
+
+    def sum_order(self, h, which) -> CSumOrder:
+        """which: 0 = row view (X half-step), 1 = column view (Y half-step)."""
+        o = CSumOrder()
+        self._ck(self._f["sum_order"](h, int(which), C.byref(o)))
+        return o
 
 
 class ProblemArrays:

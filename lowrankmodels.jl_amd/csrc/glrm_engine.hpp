@@ -18,6 +18,11 @@ enum { LOSS_QUAD_UNIFORM = 0, LOSS_SEGMENT = 1, LOSS_PER_OBS = 2, LOSS_SEGMENT_N
 constexpr int loss_mode(int loss) { return loss >= 3 ? loss - 2 : loss; }
 constexpr bool loss_trig(int loss) { return loss < 3; }
 
+// conflict-free tile reads of the LDS-tiled column passes (glrm_tiled.hpp: tile_rot); also read by glrm_hip_sum_order
+#ifndef GLRM_TILE_ROT
+#define GLRM_TILE_ROT 1
+#endif
+
 extern thread_local char g_err[768];
 
 inline int fail(int code, const char* fmt, ...) {

@@ -1274,6 +1274,64 @@ extern "C" int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int
   return GLRM_OK;
 }
 
+// The order in which this handle adds a segment's terms (include/glrm_hip.h: glrm_sum_order) -- a description of what the kernels of
+// the family that run_sweep dispatches do, read from the same handle fields.  The CPU oracle adopts it (glrm_cpu_set_sum_order) and then
+// lands on this engine's factors bit for bit: tests/test_gpu_sum_order.py.
+extern "C" int glrm_hip_sum_order(glrm_handle* h, int32_t which, glrm_sum_order* out) {
+  if (!h || !out || (which != 0 && which != 1)) return fail(GLRM_ERR_INVALID, "bad argument");
+  GLRM_NEED_FINALIZED(h);
+  const bool rows = which == 0;
+  glrm_sum_order o{};
+  o.cached_maxlen = -1;
+  o.waves4_from = GLRM_WAVES4_FROM;
+  o.waves8_from = GLRM_WAVES8_FROM;
+  // the loss variant run_sweep instantiates: 0 = one QuadLoss, segment = one descriptor per segment, per-observation = rows of a heterogeneous model
+  const bool quad = h->loss_quad_uniform, per_obs = !quad && h->n_losses > 1 && rows;
+  const bool tiled = rows ? h->tiled_row != 0 : h->tiled_col != 0;
+  const bool blocked = rows ? h->blocked_row != 0 : h->blocked_col != 0;
+  if (h->multi || h->dense || (blocked && !rows && h->lockstep)) {
+    o.family = GLRM_ORDER_OTHER;
+  } else if (tiled) {
+    const int T = h->order_unit; // vectors per staged tile (half a tile with loader waves)
+    const bool lw = h->tile_lw > 0 && h->tile_cfg && ((h->tile_lw_sides >> (rows && !h->row_split ? 0 : 1)) & 1);
+    o.family = GLRM_ORDER_WINDOWED;
+    o.lanes = h->tG; o.comps = h->tR;
+    o.window = lw ? T : (h->tile_lw > 0 ? 2 * T : T);
+    const int64_t tps = rows ? (h->row_split ? h->tiles_per_sup_r : 0) : h->tiles_per_sup;
+    o.windows_per_sup = lw ? 2 * tps : tps;
+    o.batch = (!quad && (h->tG == 4 || h->tG == 8)) ? h->tG : 2;
+    o.rotate = (!(rows && !h->row_split) && !lw && !quad && GLRM_TILE_ROT && (h->tG == 4 || h->tG == 8) && h->tR == 8) ? 1 : 0;
+    // a private copy in another order: lists the engine tile-sorted, rows regrouped by loss kind inside the tile windows
+    const bool sorted_here = rows ? h->sig_local.rows_unordered != 0 : h->sig_local.cols_unordered != 0;
+    o.private_order = (sorted_here || (rows && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_GROUP_KINDS", 1))) ? 1 : 0;
+  } else if (blocked) {
+    const int Tb = ((150 * 1024) / (h->kp * 8 + 16)) / 16 * 16; // glrm_blocked.hip: tile_rows_b
+    o.family = GLRM_ORDER_WINDOWED;
+    o.lanes = h->G; o.comps = h->R;
+    o.window = (int64_t)Tb * (rows ? h->tiles_per_sup_r : h->tiles_per_sup); // one walk per super-tile: the super-tile is the window
+    o.windows_per_sup = 1;
+    o.batch = (!quad && (h->G == 4 || h->G == 8)) ? h->G : 2;
+  } else {
+    o.family = GLRM_ORDER_STRIDED;
+    o.lanes = h->G; o.comps = h->R;
+    const int forced = rows ? h->opts.waves_row : h->opts.waves_col;
+    o.waves = (forced == 1 || forced == 4 || forced == 8) ? forced : 0;
+    if (rows && h->cached_want) { // which rows the cached sweep takes is a function of the row's own length
+      const int keep = h->cached_row;   // 0 on a shard that holds no such row: the variant is still the whole problem's
+      if (!keep) h->cached_row = env_int("GLRM_HIP_CACHED_REGS", 1) ? 2 : 1;
+      o.cached_maxlen = glrm_cached_maxlen(h);
+      o.cached_waves = h->cached_row == 2 ? env_int("GLRM_HIP_CACHED_WAVES", 2) : 1;
+      h->cached_row = keep;
+    }
+    // four observations per trip with one loss evaluation per lane (sweep_pass: SCATTER): G == 4 and not the uniform QuadLoss kernel;
+    // the per-segment variant only on one-wave segments (launch_sweep_loss)
+    o.batch = (!quad && h->G == 4) ? 4 : 1;
+    o.batch_one_wave_only = (o.batch == 4 && !per_obs) ? 1 : 0;
+  }
+  *out = o;
+  return GLRM_OK;
+}
+
 // ------------------------------------------------------------------ whole-fit API
 
 static bool single_shard(const glrm_handle* h) { return h->rb == 0 && h->re == h->m && h->cb == 0 && h->ce == h->n; }

@@ -316,6 +316,7 @@ typedef struct glrm_cpu_handle {
   int64_t* ystart;    /* n+1: column f owns Y[:, ystart[f] .. ystart[f+1]) (get_yidxs, src/losses.jl:76-93) */
   int dense_faithful; /* 1 = reproduce the reference's Theta(mnk) cost model */
   double* XY;         /* m x n, only in dense_faithful mode */
+  glrm_sum_order order_r, order_c; /* summation order of the row / column half-step: GLRM_ORDER_REFERENCE unless glrm_cpu_set_sum_order adopted an engine order */
   glrm_kernel_stats st;
 } glrm_cpu_handle;
 
@@ -601,6 +602,262 @@ static int64_t max_col_len(const glrm_cpu_handle* h) {
   return mx;
 }
 
+
+/* ------------------------------------------------ engine summation orders (test tool)
+ *
+ * Everything above adds a segment's terms in the REFERENCE's order.  The MI355X engine adds the same
+ * fp64 terms in orders fixed by the lane layout of its sweep families, and the line search decides on a strict `<` between two
+ * such sums (src/algorithms/proxgrad.jl:143,187) -- so an engine trajectory can leave the reference's on the last bit of a sum.
+ * SURVEY.md section 7.3 item 1 asks for the oracle's order to be configurable "so forks can be attributed": with
+ * glrm_cpu_set_sum_order(h, which, order) -- `order` as reported by glrm_hip_sum_order (include/glrm_hip.h: glrm_sum_order) --
+ * the half-steps below add in the ENGINE's order and reproduce the engine's factors bit for bit
+ * (tests/test_gpu_sum_order.py; the loss formulas must be the ones both sides evaluate identically: everything but the
+ * exp / log / sin based losses, whose in-kernel routines differ from libm in the last bits).  oracle(reference order) against
+ * oracle(engine order) then shows what summation order ALONE does to a trajectory (tests/test_sum_order.py, tools/attribute_drift.py).
+ * Nothing here follows a reference line: it restates csrc/glrm_hip.hip (sweep_pass, block_combine), csrc/glrm_cached.hip
+ * (reg_pass, row_combine), csrc/glrm_tiled.hpp (tiled_pass, col_reduce_kernel, col_decide_kernel) and csrc/glrm_device.hpp
+ * (group_sum, across_groups_sum, reg_eval). */
+
+/* xor butterfly over n = 2^b equal-role partials: pairs at distance 1, then 2, 4, ...; every lane ends with the same bits */
+static double eng_butterfly(double* p, int n) {
+  for (int d = 1; d < n; d <<= 1)
+    for (int j = 0; j < n; j += 2 * d) p[j] = p[j] + p[j + d];
+  return p[0];
+}
+
+/* <x, y> in the lane layout: lane j of G holds the components {2 G i + 2 j, + 1}, i = 0 .. R/2 - 1 (zero beyond k), one fma chain
+ * per lane over them in the order i ^ rot, lanes added by the butterfly (glrm_device.hpp: Vec, group_sum; glrm_tiled.hpp: tile_rot) */
+static double eng_dot(const double* x, const double* y, int k, int G, int R, int rot) {
+  double p[16];
+  for (int j = 0; j < G; ++j) {
+    double s = 0.0;
+    for (int i = 0; i < R / 2; ++i) {
+      const int c = ((i ^ rot) * 2 * G) + 2 * j;
+      if (c < k) s = fma(x[c], y[c], s);
+      if (c + 1 < k) s = fma(x[c + 1], y[c + 1], s);
+    }
+    p[j] = s;
+  }
+  return eng_butterfly(p, G);
+}
+
+/* evaluate(r, x) as reg_eval<G, R> forms it (glrm_device.hpp): lane-partial sums, butterfly, times scale */
+static double eng_reg_evaluate(const glrm_reg* r, const double* x, int k, int G, int R) {
+  if (r->kind != GLRM_REG_QUAD && r->kind != GLRM_REG_ONE) return glrm_cpu_reg_evaluate(r, x, k); /* no rounding in the others */
+  double p[16];
+  for (int j = 0; j < G; ++j) {
+    double s = 0.0;
+    for (int i = 0; i < R / 2; ++i) {
+      const int c = i * 2 * G + 2 * j;
+      const double a = c < k ? x[c] : 0.0, b = c + 1 < k ? x[c + 1] : 0.0;
+      if (r->kind == GLRM_REG_QUAD) {
+        s = fma(a, a, s);
+        s = fma(b, b, s);
+      } else {
+        s += fabs(a) + fabs(b);
+      }
+    }
+    p[j] = s;
+  }
+  return r->scale * eng_butterfly(p, G);
+}
+
+static int eng_wave_count(const glrm_sum_order* o, int64_t len, int rows) {
+  if (rows && o->cached_maxlen >= 0 && len <= o->cached_maxlen) return o->cached_waves > 0 ? o->cached_waves : 1;
+  if (o->waves > 0) return o->waves;
+  return len < o->waves4_from ? 1 : (len < o->waves8_from ? 4 : 8);
+}
+
+/* One pass over a segment in the engine's order: *J = sum of losses at xv, g (nullable) = sum of dL * opposing vector.
+ * fac = the opposing factor (k contiguous doubles per vector), lossrow: rows take the loss of the entry's column, columns one loss.
+ * `work` holds (T + 1) * (k + 4) doubles, T <= 128 lane groups. */
+static void eng_pass(const glrm_cpu_handle* h, const glrm_sum_order* o, int rows, int64_t gseg, const int32_t* idx, const double* vals, int64_t len,
+                     const double* xv, const double* fac, const glrm_loss* segloss, double* J, double* g, double* work) {
+  const int k = h->k, G = o->lanes, R = o->comps;
+  if (o->family == GLRM_ORDER_STRIDED) {
+    const int NG = 64 / G, W = eng_wave_count(o, len, rows), T = NG * W;
+    const int cached = rows && o->cached_maxlen >= 0 && len <= o->cached_maxlen;
+    const int batch = (!cached && o->batch == 4 && (!o->batch_one_wave_only || W == 1)) ? 4 : 1;
+    double* Jq = work;               /* T */
+    double* gq = work + 128;         /* T x k */
+    for (int q = 0; q < T; ++q) {
+      double Jp[4] = {0.0, 0.0, 0.0, 0.0};
+      double* gg = gq + (size_t)q * k;
+      if (g) for (int c = 0; c < k; ++c) gg[c] = 0.0;
+      int64_t trip = 0;
+      for (int64_t t = q; t < len; t += T, ++trip) {
+        const double* y = fac + (int64_t)idx[t] * k;
+        const glrm_loss* lo = segloss ? segloss : loss_of(h, idx[t]);
+        const double u = eng_dot(xv, y, k, G, R, 0);
+        Jp[batch == 4 ? (trip & 3) : 0] += glrm_cpu_loss_evaluate(lo, u, vals[t]);
+        if (g) {
+          const double dL = glrm_cpu_loss_grad(lo, u, vals[t]);
+          for (int c = 0; c < k; ++c) gg[c] = fma(dL, y[c], gg[c]);
+        }
+      }
+      Jq[q] = batch == 4 ? (Jp[0] + Jp[1]) + (Jp[2] + Jp[3]) : Jp[0];
+    }
+    double Js = 0.0;
+    if (g) for (int c = 0; c < k; ++c) g[c] = 0.0;
+    double col[16];
+    for (int w = 0; w < W; ++w) { /* across_groups_sum inside a wave, then the waves in order (block_combine / row_combine) */
+      const double Jw = eng_butterfly(Jq + w * NG, NG);
+      if (W == 1) Js = Jw; else Js += Jw;
+      if (g) {
+        for (int c = 0; c < k; ++c) {
+          for (int q = 0; q < NG; ++q) col[q] = gq[(size_t)(w * NG + q) * k + c];
+          const double gw = eng_butterfly(col, NG);
+          if (W == 1) g[c] = gw; else g[c] += gw;
+        }
+      }
+    }
+    *J = Js;
+    return;
+  }
+  /* GLRM_ORDER_WINDOWED: one lane group walks the list in list order */
+  const int batch = o->batch > 0 ? o->batch : 2;
+  const int rot = o->rotate ? (int)((gseg & 7) >> 1) : 0;
+  const int64_t win = o->window, wps = o->windows_per_sup;
+  double Jtot = 0.0, Jp[16];
+  double* gp = work; /* k */
+  if (g) for (int c = 0; c < k; ++c) { g[c] = 0.0; gp[c] = 0.0; }
+  for (int b = 0; b < batch; ++b) Jp[b] = 0.0;
+  int64_t cur_sup = -1, cur_w = -1, posw = 0;
+  for (int64_t t = 0; t <= len; ++t) {
+    const int64_t w = t < len ? (int64_t)idx[t] / win : -2, sup = t < len ? (wps > 0 ? w / wps : 0) : -2;
+    if (sup != cur_sup) {
+      if (cur_sup >= 0) { /* end of a super-tile: its partial sums go to the totals (col_reduce_kernel: in super-tile order from 0) */
+        const double Js = eng_butterfly(Jp, batch);
+        if (wps > 0) {
+          Jtot += Js;
+          if (g) for (int c = 0; c < k; ++c) g[c] += gp[c];
+        } else {
+          Jtot = Js;
+          if (g) for (int c = 0; c < k; ++c) g[c] = gp[c];
+        }
+        for (int b = 0; b < batch; ++b) Jp[b] = 0.0;
+        if (g) for (int c = 0; c < k; ++c) gp[c] = 0.0;
+      }
+      cur_sup = sup;
+      cur_w = -1;
+    }
+    if (t == len) break;
+    if (w != cur_w) { cur_w = w; posw = 0; } /* a window's first entry sits at position 0 of a batch (tiled_pass re-anchors) */
+    const double* y = fac + (int64_t)idx[t] * k;
+    const glrm_loss* lo = segloss ? segloss : loss_of(h, idx[t]);
+    const double u = eng_dot(xv, y, k, G, R, rot);
+    Jp[posw % batch] += glrm_cpu_loss_evaluate(lo, u, vals[t]);
+    if (g) {
+      const double dL = glrm_cpu_loss_grad(lo, u, vals[t]);
+      for (int c = 0; c < k; ++c) gp[c] = fma(dL, y[c], gp[c]);
+    }
+    ++posw;
+  }
+  *J = Jtot;
+}
+
+#define ENG_WORK_DOUBLES(k) ((size_t)128 + (size_t)129 * (size_t)(k))
+
+/* The half-step of local segments [s0, s1) in an engine order: the control flow of sweep_kernel / tiled_sweep_kernel /
+ * col_reduce_kernel + col_decide_kernel (which is the reference's, src/algorithms/proxgrad.jl:118-156,162-201) on eng_pass sums. */
+static int eng_step(glrm_cpu_handle* h, int rows, int64_t s0, int64_t s1, double min_stepsize) {
+  const glrm_sum_order* o = rows ? &h->order_r : &h->order_c;
+  const int k = h->k;
+  if (k > 128 || o->lanes * o->comps < k || o->lanes > 16 || 64 % o->lanes) return fail(GLRM_ERR_INVALID, "sum order: lane layout does not hold rank %d", k);
+  int64_t trials = 0, accepts = 0;
+  int oom = 0;
+#pragma omp parallel num_threads(g_threads) reduction(+ : trials, accepts) reduction(| : oom)
+  {
+    double g[128], xn[128];
+    double* work = (double*)malloc(ENG_WORK_DOUBLES(k) * 8);
+    if (!work) oom = 1;
+#pragma omp for schedule(dynamic, 16)
+    for (int64_t sl = s0; sl < s1; ++sl) {
+      if (!work) continue;
+      const int64_t gseg = (rows ? h->row_begin : h->col_begin) + sl;
+      double* x = (rows ? h->X : h->Y) + gseg * k;
+      const double* fac = rows ? h->Y : h->X;
+      const int64_t b = rows ? h->rowptr[sl] : h->colptr[sl], e = rows ? h->rowptr[sl + 1] : h->colptr[sl + 1];
+      const int32_t* idx = (rows ? h->colidx : h->rowidx) + b;
+      const double* vals = (rows ? h->rowvals : h->colvals) + b;
+      const glrm_loss* segloss = rows ? (h->n_losses == 1 ? &h->losses[0] : NULL) : loss_of(h, gseg);
+      const glrm_reg* r = rows ? rx_of(h, sl) : ry_of(h, sl);
+      double Jold, Jn;
+      eng_pass(h, o, rows, gseg, idx, vals, e - b, x, fac, segloss, &Jold, g, work);
+      Jold += eng_reg_evaluate(r, x, k, o->lanes, o->comps);
+      const double l = (double)(e - b) + 1;
+      double alpha = rows ? h->alpharow[sl] : h->alphacol[sl];
+      while (alpha > min_stepsize) {
+        const double s = alpha / l;
+        for (int c = 0; c < k; ++c) xn[c] = fma(-s, g[c], x[c]);
+        glrm_cpu_reg_prox(r, xn, k, s);
+        eng_pass(h, o, rows, gseg, idx, vals, e - b, xn, fac, segloss, &Jn, NULL, work);
+        Jn += eng_reg_evaluate(r, xn, k, o->lanes, o->comps);
+        ++trials;
+        if (Jn < Jold) {
+          memcpy(x, xn, (size_t)k * 8);
+          alpha *= 1.05;
+          Jold = Jn;
+          ++accepts;
+          break;
+        }
+        alpha *= .7;
+        if (alpha < min_stepsize) {
+          alpha = min_stepsize * 1.1;
+          break;
+        }
+      }
+      if (rows) h->alpharow[sl] = alpha;
+      else { h->alphacol[sl] = alpha; h->objcol[gseg] = Jold; }
+    }
+    free(work);
+  }
+  if (oom) return fail(GLRM_ERR_OOM, "out of memory");
+  if (rows) { h->st.launches_x += 1; h->st.trials_x += trials; h->st.accepts_x += accepts; }
+  else { h->st.launches_y += 1; h->st.trials_y += trials; h->st.accepts_y += accepts; }
+  return GLRM_OK;
+}
+
+/* Adopt (order != NULL) or drop (NULL: back to the reference order) an engine summation order for the row (which = 0) or column
+ * (which = 1) half-step.  Oracle-only entry point (like glrm_cpu_set_dense_faithful). */
+int glrm_cpu_set_sum_order(glrm_cpu_handle* h, int32_t which, const glrm_sum_order* order) {
+  if (!h || (which != 0 && which != 1)) return fail(GLRM_ERR_INVALID, "bad argument");
+  glrm_sum_order* dst = which == 0 ? &h->order_r : &h->order_c;
+  if (!order || order->family == GLRM_ORDER_REFERENCE) { memset(dst, 0, sizeof *dst); return GLRM_OK; }
+  if (h->multi || h->dense_faithful) return fail(GLRM_ERR_UNSUPPORTED, "engine summation orders cover the scalar-loss sparse path only");
+  if (order->family != GLRM_ORDER_STRIDED && order->family != GLRM_ORDER_WINDOWED)
+    return fail(GLRM_ERR_UNSUPPORTED, "summation order family %d is not restated by the oracle", order->family);
+  if (order->private_order) return fail(GLRM_ERR_UNSUPPORTED, "the engine walks a private re-ordered copy of the lists: not reproducible from the caller's");
+  const int G = order->lanes, R = order->comps;
+  if (!(G == 1 || G == 2 || G == 4 || G == 8 || G == 16) || R < 2 || (R & 1) || G * R < h->k || G * R > 128)
+    return fail(GLRM_ERR_INVALID, "sum order: bad lane layout %d x %d for rank %d", G, R, h->k);
+  if (order->family == GLRM_ORDER_WINDOWED) {
+    if (order->window <= 0 || order->windows_per_sup < 0 || !(order->batch == 2 || order->batch == G))
+      return fail(GLRM_ERR_INVALID, "sum order: bad window geometry");
+    /* the walk needs the lists ordered by window, like the engine's own check (glrm_tiled.hpp: check_sorted_kernel) */
+    const int64_t ns = which == 0 ? h->row_end - h->row_begin : h->col_end - h->col_begin;
+    const int64_t* ptr = which == 0 ? h->rowptr : h->colptr;
+    const int32_t* ix = which == 0 ? h->colidx : h->rowidx;
+    for (int64_t s = 0; s < ns; ++s)
+      for (int64_t t = ptr[s] + 1; t < ptr[s + 1]; ++t)
+        if (ix[t] / order->window < ix[t - 1] / order->window) return fail(GLRM_ERR_INVALID, "sum order: a list is not ordered by window");
+  } else {
+    if (!(order->waves == 0 || order->waves == 1 || order->waves == 2 || order->waves == 4 || order->waves == 8) || !(order->batch == 1 || order->batch == 4))
+      return fail(GLRM_ERR_INVALID, "sum order: bad wave count / batch");
+    if (order->cached_maxlen >= 0 && !(order->cached_waves == 1 || order->cached_waves == 2 || order->cached_waves == 4))
+      return fail(GLRM_ERR_INVALID, "sum order: bad cached wave count");
+  }
+  *dst = *order;
+  return GLRM_OK;
+}
+
+/* twin of glrm_hip_sum_order: the order this handle's half-step adds in (GLRM_ORDER_REFERENCE unless one was adopted) */
+int glrm_cpu_sum_order(glrm_cpu_handle* h, int32_t which, glrm_sum_order* out) {
+  if (!h || !out || (which != 0 && which != 1)) return fail(GLRM_ERR_INVALID, "bad argument");
+  *out = which == 0 ? h->order_r : h->order_c;
+  return GLRM_OK;
+}
+
 /* ------------------------------------------------------------- half-steps */
 
 static int step_x_rows(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_stepsize);
@@ -628,6 +885,7 @@ static int gen_penalties(glrm_cpu_handle* h, int rows);
 
 static int step_x_rows(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_stepsize) {
   if (h->multi) return gen_step_x(h, s0, s1, min_stepsize, 0.0);
+  if (h->order_r.family != GLRM_ORDER_REFERENCE) return eng_step(h, 1, s0, s1, min_stepsize);
   const int k = h->k;
   int64_t trials = 0, accepts = 0;
 #pragma omp parallel num_threads(g_threads) reduction(+ : trials, accepts)
@@ -681,6 +939,7 @@ static int step_x_rows(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_st
 int glrm_cpu_step_y(glrm_cpu_handle* h, double min_stepsize) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
   if (h->multi) return gen_step_y(h, min_stepsize, 0.0);
+  if (h->order_c.family != GLRM_ORDER_REFERENCE) return eng_step(h, 0, 0, h->col_end - h->col_begin, min_stepsize);
   const int k = h->k;
   const int64_t nl = h->col_end - h->col_begin;
   const int64_t mlen = max_col_len(h) + (h->dense_faithful ? h->m : 0);

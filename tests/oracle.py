@@ -53,6 +53,7 @@ def oracle_lib():
         _lib.glrm_cpu_set_threads.argtypes = [C.c_int]
         _lib.glrm_cpu_set_dense_faithful.argtypes = [C.c_void_p, C.c_int]
         _lib.glrm_cpu_get_stepsizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib.glrm_cpu_set_sum_order.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     return _lib
 
 
@@ -63,6 +64,22 @@ def oracle_api():
         from lowrankmodels.jl_amd import _capi
         _api = _capi.Api(oracle_lib(), "glrm_cpu_", "cpu")
     return _api
+
+
+def set_sum_order(h, which, order):
+    """Make the oracle add the terms of the row (which = 0) / column (1) half-step in an ENGINE order: `order` is the CSumOrder
+    glrm_hip_sum_order reported for a handle of the HIP engine (or one built by hand); None returns to the reference order."""
+    api = oracle_api()
+    api._ck(oracle_lib().glrm_cpu_set_sum_order(h, int(which), C.byref(order) if order is not None else None))
+
+
+def make_sum_order(family, lanes, comps, waves=0, cached_maxlen=-1, cached_waves=0, batch=0, batch_one_wave_only=0, rotate=0, window=0,
+                   windows_per_sup=0):
+    """A glrm_sum_order by hand (CPU tests; on the GPU the engine reports its own through glrm_hip_sum_order)."""
+    from lowrankmodels.jl_amd import _capi
+    fam = {"reference": 0, "strided": 1, "windowed": 2}[family]
+    return _capi.CSumOrder(fam, lanes, comps, waves, 1536, 98304, cached_maxlen, cached_waves, batch or (1 if fam == 1 else 2), batch_one_wave_only, rotate,
+                           window, windows_per_sup, 0, 0)
 
 
 def set_threads(n):
