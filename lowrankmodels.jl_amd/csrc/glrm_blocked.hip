@@ -122,9 +122,11 @@ template <int G, int R, int LOSS, bool GRAD>
 static int launch_blocked_inst(glrm_handle* h, TiledArgs a) {
   constexpr int KP = G * R, T = tile_rows_b(KP), SPB = BNW * (64 / G);
   auto kernel = tiled_col_pass_kernel<G, R, BNW, T, LOSS, GRAD, true>;
-  static std::atomic<int64_t> cap_cache{0}; // per instantiation; shards of one process call this concurrently (same value on every device of a node)
-  int64_t cap = cap_cache.load(std::memory_order_relaxed);
-  if (cap == 0) { cap = slice_capacity(kernel, h->device, SPB); cap_cache.store(cap, std::memory_order_relaxed); }
+  // per handle and pass kind (the occupancy query depends on the instantiation, the CU count on the handle's device, the fill percentage
+  // on the environment at the handle's first sweep)
+  int64_t& cap_slot = h->blocked_cap[GRAD ? 0 : 1];
+  if (cap_slot == 0) cap_slot = slice_capacity(kernel, h->device, SPB);
+  const int64_t cap = cap_slot;
   const int64_t nseg = a.nseg;
   // equal slices: ceil(nseg / cap) launches per super-tile, all of the same size (a last slice of a few percent of the others is a launch
   // that cannot fill the chip)

@@ -610,27 +610,27 @@ __global__ void __launch_bounds__(128, 2) regcached_persist_kernel(const CachedA
 }
 
 template <int G, int R, int LOSS>
-int launch_reg_inst(const CachedArgs& a, hipStream_t st) { // a.cap = trips of one wave the longest row needs (64 / G observations each)
+int launch_reg_inst(const CachedArgs& a, hipStream_t st, glrm_handle* h) { // a.cap = trips of one wave the longest row needs (64 / G observations each)
   // Two waves per row (each holds every other trip's vectors: half the registers, two waves per SIMD, so one wave's loads overlap the
   // other's arithmetic).  Measured at C4, X half-step: one wave per row 101.5 ms, two 85.4 ms, four 130.3 ms (phase-aligned passes 120.6).
   // ALWAYS two, also for rows one wave could hold: the wave count fixes the order of the sums, and it must not depend on the
   // longest row of the launch (MAXT only adds empty trips).  GLRM_HIP_CACHED_WAVES = 1 | 4 are the experiment switches.
   const int waves = env_int("GLRM_HIP_CACHED_WAVES", 2);
   if (waves == 2 && env_int("GLRM_HIP_CACHED_PERSIST", 1)) { // the persistent form of the two-wave kernel (same bits)
-    static std::atomic<int> blocks7{0}, blocks4{0};
+    // resident grid per handle (its device's CU count, its loss variant's occupancy, the fill percentage at its first sweep)
     const bool small = (a.cap + 1) / 2 <= 4;
-    std::atomic<int>& cache = small ? blocks4 : blocks7;
-    int nb = cache.load(std::memory_order_relaxed);
+    int& cache = h->cached_grid[small ? 1 : 0];
+    int nb = cache;
     if (nb == 0) {
-      int per_cu = 0, dev = 0;
+      int per_cu = 0;
       hipDeviceProp_t prop;
       const void* k = small ? (const void*)regcached_persist_kernel<G, R, LOSS, 4> : (const void*)regcached_persist_kernel<G, R, LOSS, 7>;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 128, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
       int cus = 256;
-      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+      if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
       nb = (int)((int64_t)per_cu * cus * env_int("GLRM_HIP_CACHED_PERSIST_FILL", 100) / 100); // percent of the resident grid
       if (nb < 1) nb = 1;
-      cache.store(nb, std::memory_order_relaxed);
+      cache = nb;
     }
     const unsigned grid = (unsigned)std::min<int64_t>(a.nseg, nb);
     if (small) hipLaunchKernelGGL((regcached_persist_kernel<G, R, LOSS, 4>), dim3(grid), dim3(128), 0, st, a);
@@ -651,13 +651,13 @@ int launch_reg_inst(const CachedArgs& a, hipStream_t st) { // a.cap = trips of o
 }
 
 template <int G, int R>
-int launch_reg_layout(int loss, const CachedArgs& a, hipStream_t st) {
+int launch_reg_layout(int loss, const CachedArgs& a, hipStream_t st, glrm_handle* h) {
   switch (loss) {
-    case LOSS_QUAD_UNIFORM: return launch_reg_inst<G, R, LOSS_QUAD_UNIFORM>(a, st);
-    case LOSS_SEGMENT: return launch_reg_inst<G, R, LOSS_SEGMENT>(a, st);
-    case LOSS_SEGMENT_NOTRIG: return launch_reg_inst<G, R, LOSS_SEGMENT_NOTRIG>(a, st);
-    case LOSS_PER_OBS_NOTRIG: return launch_reg_inst<G, R, LOSS_PER_OBS_NOTRIG>(a, st);
-    default: return launch_reg_inst<G, R, LOSS_PER_OBS>(a, st);
+    case LOSS_QUAD_UNIFORM: return launch_reg_inst<G, R, LOSS_QUAD_UNIFORM>(a, st, h);
+    case LOSS_SEGMENT: return launch_reg_inst<G, R, LOSS_SEGMENT>(a, st, h);
+    case LOSS_SEGMENT_NOTRIG: return launch_reg_inst<G, R, LOSS_SEGMENT_NOTRIG>(a, st, h);
+    case LOSS_PER_OBS_NOTRIG: return launch_reg_inst<G, R, LOSS_PER_OBS_NOTRIG>(a, st, h);
+    default: return launch_reg_inst<G, R, LOSS_PER_OBS>(a, st, h);
   }
 }
 
@@ -759,7 +759,7 @@ int glrm_run_cached(glrm_handle* h, int loss, double min_stepsize, const int32_t
     a.trials += s0; a.accepts += s0;
   }
   int rc;
-  if (h->cached_row == 2) rc = h->G == 4 ? launch_reg_layout<4, 8>(loss, a, st) : launch_reg_layout<8, 8>(loss, a, st);
+  if (h->cached_row == 2) rc = h->G == 4 ? launch_reg_layout<4, 8>(loss, a, st, h) : launch_reg_layout<8, 8>(loss, a, st, h);
   else rc = h->G == 4 ? launch_layout<4, 8>(loss, a, st) : launch_layout<8, 8>(loss, a, st);
   if (rc) return rc;
   HIPCK(hipGetLastError());

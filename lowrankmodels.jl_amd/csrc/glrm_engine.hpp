@@ -125,6 +125,11 @@ struct glrm_handle {
   int32_t *seglist_r = nullptr, *seglist_c = nullptr;
   int64_t ncls_r[4] = {0, 0, 0, 0}, ncls_c[4] = {0, 0, 0, 0};
   bool finalized = false;             // false between a GLRM_PROBLEM_DEFER_SETUP create and glrm_hip_finalize
+  bool finalize_failed = false;       // glrm_hip_finalize ran and failed half way: the handle can only be destroyed
+  // launch geometry of the persistent / sliced kernels, per handle (device and fill percentage at finalize; a process may drive devices
+  // with different CU counts, and the knobs are read per handle): 0 = not computed yet
+  int64_t blocked_cap[2] = {0, 0};    // phase-aligned passes: segments per launch slice, gradient / trial instantiation
+  int cached_grid[2] = {0, 0};        // persistent cached row sweep: resident workgroups, MAXT = 7 / 4 instantiation
   glrm_signature sig_local{}, sig{};  // this shard's contribution / the whole problem's
   int order_unit = 0;                 // opposing vectors per unit of the tile-order check (glrm_tiled.hip)
   hipStream_t side_stream = nullptr;  // the launches of the minority classes run beside the main launch

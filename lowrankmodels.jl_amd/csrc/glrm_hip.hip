@@ -846,8 +846,12 @@ extern "C" int glrm_hip_signature(glrm_handle* h, glrm_signature* local) {
 extern "C" int glrm_hip_finalize(glrm_handle* h, const glrm_signature* whole) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
   if (h->finalized) return fail(GLRM_ERR_INVALID, "the handle is already set up (glrm_hip_finalize follows a GLRM_PROBLEM_DEFER_SETUP create, once)");
+  if (h->finalize_failed)  // a set-up that failed half way (out of memory in a family's buffers) has re-ordered private views and partial buffers
+    return fail(GLRM_ERR_INVALID, "an earlier glrm_hip_finalize on this handle failed: destroy it and create the shard again");
   DeviceGuard dg(h->device);
-  return finalize_impl(h, whole);
+  const int rc = finalize_impl(h, whole);
+  if (rc) h->finalize_failed = true;
+  return rc;
 }
 
 #define GLRM_NEED_FINALIZED(h) \
@@ -1127,17 +1131,26 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
       HIPCK(hipEventRecord(h->ev_fork, h->stream));
       HIPCK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
       int64_t off = 0;
-      for (int c = 0; c < 4; off += ncls[c], ++c) {
+      int rc_cls = GLRM_OK;
+      for (int c = 0; c < 4 && !rc_cls; off += ncls[c], ++c) {
         if (ncls[c] <= 0) continue;
         hipStream_t st = c == main_cls ? h->stream : h->side_stream;
         if (c == 0 && !eval_only) {
-          if ((rc = glrm_run_cached(h, loss, min_stepsize, lst + off, ncls[0], st))) return rc;
+          rc_cls = glrm_run_cached(h, loss, min_stepsize, lst + off, ncls[0], st);
         } else {
           SweepArgs b = a;
           b.seglist = lst + off;
           b.nseg = ncls[c];
           launch_sweep(h->G, h->R, c == 0 ? 1 : glrm_class_waves(c), loss, c <= 1 ? unroll : 1, b, st);
         }
+      }
+      if (rc_cls) { // join before reporting: later work on h->stream (and a stream capture) must stay ordered after what the side stream already holds
+        char keep[sizeof g_err];
+        memcpy(keep, g_err, sizeof keep);
+        (void)hipEventRecord(h->ev_join, h->side_stream);
+        (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);
+        memcpy(g_err, keep, sizeof keep);
+        return rc_cls;
       }
       HIPCK(hipEventRecord(h->ev_join, h->side_stream));
       HIPCK(hipStreamWaitEvent(h->stream, h->ev_join, 0));

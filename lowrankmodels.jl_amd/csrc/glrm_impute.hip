@@ -113,6 +113,7 @@ __global__ void __launch_bounds__(ET) impute_kernel(const EvalArgs a) {
 int prepare(glrm_handle* h, const double* X, const double* Y, const glrm_domain* domains, EvalArgs& a, glrm_domain** ddom, int** dbad) {
   if (!(h->rb == 0 && h->re == h->m && h->cb == 0 && h->ce == h->n)) return fail(GLRM_ERR_INVALID, "needs a single-shard handle");
   if (h->dense) return fail(GLRM_ERR_UNSUPPORTED, "post-fit evaluation works on list handles (create the handle without dense_A)");
+  if (!h->finalized) return fail(GLRM_ERR_INVALID, "the handle was created with GLRM_PROBLEM_DEFER_SETUP: call glrm_hip_finalize first");
   for (int64_t f = 0; f < h->n; ++f)
     if (domains[f].kind < 0 || domains[f].kind >= GLRM_DOMAIN_KIND_COUNT || domains[f].reserved != 0)
       return fail(GLRM_ERR_INVALID, "domain descriptor %lld is invalid", (long long)f);

@@ -157,6 +157,7 @@ extern "C" int glrm_hip_subset(glrm_handle* parent, const uint8_t* row_tags, con
   if (!parent || !out) return fail(GLRM_ERR_INVALID, "NULL argument");
   *out = nullptr;
   if (parent->dense) return fail(GLRM_ERR_UNSUPPORTED, "glrm_hip_subset needs a list (not dense) parent handle");
+  if (!parent->finalized) return fail(GLRM_ERR_INVALID, "the handle was created with GLRM_PROBLEM_DEFER_SETUP: call glrm_hip_finalize first");
   if ((parent->nnz_r > 0 && !row_tags) || (parent->nnz_c > 0 && !col_tags)) return fail(GLRM_ERR_INVALID, "NULL tag array");
   if (hipSetDevice(parent->device) != hipSuccess) return fail(GLRM_ERR_HIP, "cannot select device %d", parent->device);
   View rv, cv;
@@ -175,5 +176,11 @@ extern "C" int glrm_hip_subset(glrm_handle* parent, const uint8_t* row_tags, con
   p.ry = parent->ry_h.data(); p.n_ry = (int64_t)parent->ry_h.size();
   glrm_options o = parent->opts;
   o.device_id = parent->device;
+  // The child of ONE SHARD of a sharded fit is a shard of the subset problem: like its parent it must choose its kernels from the
+  // signature of the WHOLE (subset) problem, so it is created deferred and the host finalizes it with the combined signature of the
+  // shards' children (glrm_hip_signature on each child, sum / max, glrm_hip_finalize) -- the protocol of the parents.  A single-shard
+  // parent's child is set up here.
+  const bool shard = !(parent->rb == 0 && parent->re == parent->m && parent->cb == 0 && parent->ce == parent->n);
+  if (shard) p.flags |= GLRM_PROBLEM_DEFER_SETUP;
   return glrm_hip_create(out, &p, &o); // copies the compacted views; rv / cv are released on return
 }

@@ -358,6 +358,7 @@ extern "C" int glrm_hip_init_svd(glrm_handle* h, double* X, double* Y, int32_t m
   if (!h || !X || !Y) return fail(GLRM_ERR_INVALID, "NULL argument");
   if (!(h->rb == 0 && h->re == h->m && h->cb == 0 && h->ce == h->n)) return fail(GLRM_ERR_INVALID, "glrm_hip_init_svd needs a single-shard handle");
   if (h->dense) return fail(GLRM_ERR_UNSUPPORTED, "glrm_hip_init_svd works on the observation lists (create the handle without dense_A)");
+  if (!h->finalized) return fail(GLRM_ERR_INVALID, "the handle was created with GLRM_PROBLEM_DEFER_SETUP: call glrm_hip_finalize first");
   const int k = h->k;
   const int64_t m = h->m, d = h->d;
   if (k > m || k > d) return fail(GLRM_ERR_INVALID, "k = %d exceeds min(m, d): no k singular triplets", k);

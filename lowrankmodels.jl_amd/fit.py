@@ -258,6 +258,9 @@ class ShardedFit:
         #              kept on every rank (the probe is published as `exchange_probe_ms`); otherwise all-gather on nccl, broadcasts elsewhere
         mode = os.environ.get("GLRM_GATHER", "auto")
         self._p2p = self.world > 1 and mode == "p2p"
+        # ragged blocks (nnz-balanced partitions of real data): one grouped point-to-point exchange instead of one broadcast per owner
+        # whenever the backend is RCCL and nothing else was asked for (every transfer carries its own size)
+        self._ragged_p2p = self.world > 1 and mode == "auto" and self.device.type == "cuda" and dist.get_backend(group) == "nccl"
         self._inplace_ok = self.world > 1 and mode not in ("broadcast", "p2p") and (mode == "allgather" or dist.get_backend(group) == "nccl")
         self.exchange_ms = {"x": 0.0, "y": 0.0, "objective": 0.0}   # time the rank's stream spent in the exchanges (profile runs)
         self._timed = []                                            # (kind, start event, end event) awaiting a synchronisation
@@ -273,23 +276,27 @@ class ShardedFit:
         set_factors afterwards) and keep the faster on every rank; a failing p2p path leaves the all-gather in place."""
         torch, dist = self.torch, self.dist
         res = {}
+        sync = (lambda: torch.cuda.synchronize(self.device)) if self.device.type == "cuda" else (lambda: None)
         for name in ("allgather", "p2p"):
             self._p2p = name == "p2p"
-            try:
-                sync = (lambda: torch.cuda.synchronize(self.device)) if self.device.type == "cuda" else (lambda: None)
-                for rep in range(2):  # first repetition: connection set-up
-                    sync()
-                    dist.barrier(group=self.group)
-                    t0 = time.perf_counter()
+            # Every rank runs the SAME sequence of collectives whatever fails where: only the exchange under test sits inside the try, and
+            # (ok, time) is reduced unconditionally afterwards -- a rank whose p2p leg throws still pairs its all_reduce with the others'.
+            ok, dt, err = 1.0, float("inf"), None
+            for rep in range(2):  # first repetition: connection set-up
+                sync()
+                dist.barrier(group=self.group)
+                t0 = time.perf_counter()
+                try:
                     self._gather(self.dX, self.row_bounds, self.ld)
                     sync()
-                    dt = (time.perf_counter() - t0) * 1e3
-                t = torch.tensor([dt], dtype=torch.float64, device=self.device)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-                res[name] = float(t.item())
-            except Exception as e:  # noqa: BLE001 -- an unsupported path must not take the fit down
-                res[name] = float("inf")
-                res[name + "_error"] = repr(e)
+                except Exception as e:  # noqa: BLE001 -- an unsupported path must not take the fit down
+                    ok, err = 0.0, repr(e)
+                dt = (time.perf_counter() - t0) * 1e3
+            t = torch.tensor([dt if ok else 0.0, -ok], dtype=torch.float64, device=self.device)   # MAX of (time, -ok): any failure -> -ok = 0
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            res[name] = float(t[0].item()) if float(t[1].item()) < -0.5 else float("inf")
+            if err is not None:
+                res[name + "_error"] = err
         flag = torch.tensor([1.0 if res["p2p"] < res["allgather"] else 0.0], dtype=torch.float64, device=self.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)   # every rank must have seen p2p win
         self._p2p = bool(flag.item() > 0.5)
@@ -327,7 +334,7 @@ class ShardedFit:
     def _gather(self, buf, bounds, unit):
         """Make ``buf`` (global length) identical on every rank: rank r contributed
         buf[bounds[r]*unit : bounds[r+1]*unit].  Equal blocks -> one in-place all-gather (each GPU
-        pushes its 1/G slice to its peers); ragged blocks -> one broadcast per owner."""
+        pushes its 1/G slice to its peers); ragged blocks -> one grouped point-to-point exchange on RCCL, one broadcast per owner elsewhere."""
         if self.world == 1:
             return
         dist, sizes = self.dist, [(bounds[r + 1] - bounds[r]) * unit for r in range(self.world)]
@@ -339,6 +346,9 @@ class ShardedFit:
             # NCCL / RCCL allow sendbuff == recvbuff + rank * count; GLRM_GATHER_INPLACE=0 sends a copy of the block instead
             src = own if os.environ.get("GLRM_GATHER_INPLACE", "1") != "0" else own.clone()
             dist.all_gather_into_tensor(buf, src, group=self.group)
+            return
+        if self._ragged_p2p:
+            self._p2p_ranges(buf, [(bounds[r] * unit, bounds[r + 1] * unit) for r in range(self.world)])
             return
         for r in range(self.world):
             if sizes[r]:

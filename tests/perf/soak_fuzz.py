@@ -24,6 +24,7 @@ spec = importlib.util.spec_from_file_location("fz", os.path.join(ROOT, "tests", 
 fz = importlib.util.module_from_spec(spec)
 spec.loader.exec_module(fz)
 TOL = 1e-5
+LAST = {"iterations": 0}   # iterations the last call of one() compared (tests/test_gpu_fuzz.py keeps the books)
 FAMILY_ENV = ("GLRM_HIP_BLOCKED", "GLRM_HIP_BLOCKED_TPS", "GLRM_HIP_BLOCKED_FILL", "GLRM_HIP_CACHED", "GLRM_HIP_CACHED_PERSIST")
 FAMILIES = {
     "auto": ({}, {}),
@@ -105,6 +106,7 @@ def one(seed):
     os.environ.update(env)
     try:
         o_g, X_g, Y_g, st_g = cases.run_engine(_capi.hip_api(), pa, X0, Y0, p, **kw)
+        LAST["iterations"] = len(o_g) - 1
         e = (cases.rel_err(o_g, o_c), cases.fro_err(X_g, X_c), cases.fro_err(Y_g, Y_c))
         ok = len(o_g) == len(o_c) and max(e) < TOL and st_g["nnz_rows"] == st_c["nnz_rows"]
         detail = (stable, e, st_g["tiled"])

@@ -1,23 +1,22 @@
-"""Summarise rocprofv3 --pmc counter_collection.csv files (one directory per pass) per sweep kernel.
-usage: python tools/pmc_summary.py gpurun_out > profiles/rNN_pmc_summary.md"""
+"""Summarise rocprofv3 --pmc counter_collection.csv files per sweep kernel: dispatches, mean and SUM per counter (the pass families launch
+many slices per half-step: their per-half-step figure is the sum over the run / the half-steps of the run).
+usage: python tools/pmc_summary.py DIR [kernel-name regex] > profiles/rNN_xxx_pmc.md      (DIR is searched recursively)"""
 import collections
 import csv
 import glob
 import os
+import re
 import sys
 
 root = sys.argv[1]
-rows = collections.defaultdict(dict)
-for path in sorted(glob.glob(os.path.join(root, "pmc_*", "pmc_counter_collection.csv"))):
-    per = collections.defaultdict(lambda: collections.defaultdict(list))
+pat = re.compile(sys.argv[2] if len(sys.argv) > 2 else "sweep|tiled|pass|cached|dense|multi")
+rows = collections.defaultdict(lambda: collections.defaultdict(list))
+for path in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
     for r in csv.DictReader(open(path)):
-        if "sweep" in r["Kernel_Name"] or "tiled" in r["Kernel_Name"]:
-            per[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-    for k, cs in per.items():
-        for c, v in cs.items():
-            rows[k][c] = (len(v), sum(v) / len(v), v[-1])
-print("| kernel | counter | dispatches | mean | last dispatch |\n|---|---|---|---|---|")
+        if pat.search(r["Kernel_Name"]):
+            rows[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("| kernel | counter | dispatches | mean | sum | last dispatch |\n|---|---|---|---|---|---|")
 for k in sorted(rows):
     for c in sorted(rows[k]):
-        n, mean, last = rows[k][c]
-        print(f"| `{k}` | {c} | {n} | {mean:.6g} | {last:.6g} |")
+        v = rows[k][c]
+        print(f"| `{k}` | {c} | {len(v)} | {sum(v) / len(v):.6g} | {sum(v):.6g} | {v[-1]:.6g} |")
