@@ -169,6 +169,23 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
     return dict(best=best, candidates=cands, algorithmic_GBps=alg / t / 1e9)
 
 
+def side_summary(rl):
+    """The best-priced limiter of one half-step for the `kernels` block.  A fraction at or above 1 is the SURVEY 8(d) algorithmic byte count
+    of a family whose gathers are partly served by the caches: it is labelled as such, never as a roofline fraction (the dominant
+    kernel's `roofline` block replaces it by the PMC traffic fraction)."""
+    if not rl:
+        return None
+    b = rl["best"]
+    out = {kk: b[kk] for kk in ("bound", "achieved", "peak", "unit")}
+    if b["frac"] >= 1.0:
+        out["algorithmic_frac"] = b["frac"]
+        out["frac"] = None
+        out["frac_note"] = "algorithmic bytes / time exceeds the peak (cache-served gathers): see roofline.frac (PMC traffic) for the dominant kernel"
+    else:
+        out["frac"] = b["frac"]
+    return out
+
+
 def family_step_bytes(family, nnz, nseg, nopp, k, ld, hbm_floor=False):
     """Bytes one half-step of the family has to bring in from beyond the CU: the (index, value) stream once per pass, the own factor
     read and written, and the opposing k-vectors -- once per update and pass for the families that gather them (gather, phase-aligned
@@ -314,21 +331,22 @@ def load_jref_fixture(config, seed):
 
 
 def jref_device_problem(fixture, cfg, seed, api, device):
-    """The fixture's problem regenerated in HBM from the same counter-based generator: (handle, X0, Y0 as host k x m / k x n arrays)."""
+    """The fixture's problem regenerated in HBM from the same counter-based generator (Omega and values are bit-identical between the
+    device and the CPU generator, tests/test_synth.py): (handle, X0, Y0 as host k x m / k x n arrays)."""
     import numpy as np
     from lowrankmodels.jl_amd import synth
     ms, n, q, k = fixture["m"], fixture["n"], fixture["q"], cfg["k"]
     reg = cfg["reg"]
     w = synth.DeviceWorkload(ms, n, k, q, seed=seed, value_model=cfg["value_model"], loss_mix=cfg["loss_mix"], rx=reg, ry=reg, device=device)
     h = api.create(w.problem(), device_id=device.index or 0)
-    ld = api.factor_ld(h)
-    dX, dY = w.init_factors(ld)
     w.free_sources()
+    # the start comes from the CPU generator, like the fixture's: its Box-Muller normals go through the host's libm, the device
+    # generator's through ocml -- the same numbers to the last bit or two, which is not the same start for a bit-for-bit comparison
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    X0, Y0 = O.synth_cpu_init(ms, n, k, q, seed=seed)
     if nonneg_start(cfg):
-        dX.abs_().mul_(1.0 / k ** 0.5); dY.abs_().mul_(1.0 / k ** 0.5)
-    X0 = np.asfortranarray(dX.cpu().numpy().reshape(ms, ld)[:, :k].T)
-    Y0 = np.asfortranarray(dY.cpu().numpy().reshape(n, ld)[:, :k].T)
-    del dX, dY
+        X0, Y0 = np.asfortranarray(np.abs(X0) * (1.0 / k ** 0.5)), np.asfortranarray(np.abs(Y0) * (1.0 / k ** 0.5))
     return h, X0, Y0
 
 
@@ -1068,8 +1086,7 @@ def main():
                        "waves_row": st["waves_row"], "waves_col": st["waves_col"], "row_sweep": fam_r, "col_sweep": fam_c},
             "roofline": roof,
             "kernels": {"row_sweep_ms": ms_x, "col_sweep_ms": ms_y,
-                        "row_sweep": None if not rl_r else {kk: rl_r["best"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac")},
-                        "col_sweep": None if not rl_c else {kk: rl_c["best"][kk] for kk in ("bound", "achieved", "peak", "unit", "frac")},
+                        "row_sweep": side_summary(rl_r), "col_sweep": side_summary(rl_c),
                         "mean_trials_per_row": st["trials_x"] / max(args.steps * nseg_r, 1),
                         "mean_trials_per_col": st["trials_y"] / max(args.steps * nseg_c, 1)},
             "exchange": None if exch is None else {

@@ -191,6 +191,17 @@ class SynthSpec(C.Structure):
                 ("value_model", C.c_int32), ("loss_mix", C.c_int32), ("noise", C.c_double)]
 
 
+def synth_cpu_init(m, n, k, q, seed=20260926, init_seed=1):
+    """Only the start X0 (k x m), Y0 (k x n) of synth_cpu (the generator's Box-Muller normals through THIS host's libm: the device
+    generator's differ from them in the last bits, so a bit-for-bit comparison with an oracle run hands these to the engine)."""
+    lib = oracle_lib()
+    s = SynthSpec(m, n, k, q, seed, 0, 0, 0.1)
+    X0 = np.zeros((k, m), order="F")
+    Y0 = np.zeros((k, n), order="F")
+    assert lib.glrm_synth_cpu_init(C.byref(s), C.c_uint64(init_seed), C.c_int(k), C.c_void_p(X0.ctypes.data), C.c_void_p(Y0.ctypes.data)) == 0
+    return X0, Y0
+
+
 def synth_cpu(m, n, k, q, seed=20260926, value_model=0, loss_mix=0, noise=0.1, init_seed=1,
               rows=None, cols=None, transpose=False):
     """Generate (rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0) with oracle/synth.c.

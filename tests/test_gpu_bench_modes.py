@@ -40,3 +40,18 @@ def test_borrowed_lists_give_the_same_bench_objective():
     assert not a["setup_s"]["lists_borrowed_in_place"] and b["setup_s"]["lists_borrowed_in_place"]
     assert a["objective"] == b["objective"] and a["config"]["row_sweep"] == b["config"]["row_sweep"]
     assert a["step_model"]["within_peak"]
+
+
+def test_inlib_host_equals_the_single_device_objective():
+    """bench.py --host inlib: the fit a Julia fit!(glrm, HipProxGradParams(ngpus = N)) ccalls -- glrm_hip_multi_create / _fit, one process,
+    N shards (here all on device 0) -- on the C4 recipe: same JSON shape as the torch.distributed host, the same objective bits as the
+    one-GPU line after the same number of iterations (shards are bit-identical to the single handle), exchange diagnostics present."""
+    common = ["--config", "C4", "--rows", "200000", "--cols", "10000", "--steps", "4", "--warmup", "2"]
+    one = run(common + QUIET)
+    lib = run(common + ["--host", "inlib", "--gpus", "4", "--shared-device"])
+    assert lib["n_gpus"] == 4 and lib["config"]["host"] == "inlib" and lib["host"]["shared_device"]
+    assert lib["objective"]["after_warmup_and_steps"] == one["objective"]["after_warmup_and_steps"]
+    assert lib["value"] > 0 and lib["ms_per_step"] > 0 and lib["host"]["exchange_ms_per_step_exposed"] >= 0
+    assert len(lib["host"]["row_bounds"]) == 5 and lib["host"]["row_bounds"][-1] == 200000
+    m = lib["host"]["model_ms"]["X_block"]
+    assert m["ring"] == pytest.approx(3 * m["direct"]) and m["link_GBps_one_direction"] == 76.8
