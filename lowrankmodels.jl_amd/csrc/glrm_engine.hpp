@@ -61,6 +61,9 @@ struct glrm_handle {
   int nsup = 0, tiles_per_sup = 0;
   int blocked_row = 0, blocked_col = 0; // phase-aligned gather passes (glrm_blocked.hip) instead of the one-kernel gather sweep
   int row_split = 0, tiles_per_sup_r = 0; // row sweep in super-tile passes (nsup_r super-tiles; buffers part_r ... ntrial_r below)
+  int tile_rounds = 0;                // LDS-tiled sweeps: line-search rounds over the still-searching segments only (bit0 rows, bit1 columns)
+  int32_t* actlist = nullptr;         // two lists of actlist_cap segment ids (glrm_tiled.hpp: TiledArgs::actlist_out / actlist_in)
+  int64_t actlist_cap = 0;
   double *part = nullptr, *gsum = nullptr, *trialbuf = nullptr, *joldbuf = nullptr;
   int32_t *activebuf = nullptr, *ntrialbuf = nullptr;
   unsigned int* nactive = nullptr;

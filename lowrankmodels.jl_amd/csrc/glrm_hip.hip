@@ -585,7 +585,7 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
                   h->activebuf, h->ntrialbuf, h->nactive, h->dflag, h->Arow, h->Acol, h->part_r, h->gsum_r, h->trial_r,
                   h->jold_r, h->active_r, h->ntrial_r, h->ystart, h->mtrial, h->mpart_loss, h->mpart_G, h->mgtot,
                   h->mobjold, h->mactive, h->mnactive, h->colperm, h->rowperm, h->seglist_r, h->seglist_c, h->rowdescid, h->udesc,
-                  h->gramH, h->gram_part, h->jloss_r, h->jloss_c, h->lock_ctr};
+                  h->gramH, h->gram_part, h->jloss_r, h->jloss_c, h->lock_ctr, h->actlist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->iter_exec) (void)hipGraphExecDestroy(h->iter_exec);
@@ -775,11 +775,14 @@ static int finalize_impl(glrm_handle* h, const glrm_signature* whole) {
     return fail(GLRM_ERR_INVALID, "the signature of the whole problem cannot be smaller than this shard's (sum the counts, max the rest)");
   int rc;
   if (!h->multi && !h->dense) {
+    // a failure from here on leaves re-ordered private views and partial buffers behind: the handle can then only be destroyed
+    h->finalize_failed = true;
     if ((rc = glrm_setup_tiled(h))) return rc;
     if ((rc = glrm_setup_cached(h))) return rc;
     if ((rc = glrm_setup_blocked(h))) return rc;
     if (!h->tiled_row && !h->blocked_row && (rc = build_class_plan(h, true))) return rc;
     if (!h->tiled_col && !h->blocked_col && (rc = build_class_plan(h, false))) return rc;
+    h->finalize_failed = false;
   } else {
     h->waves_row = h->opts.waves_row ? h->opts.waves_row : 1;
     h->waves_col = h->opts.waves_col ? h->opts.waves_col : 4;
@@ -849,9 +852,7 @@ extern "C" int glrm_hip_finalize(glrm_handle* h, const glrm_signature* whole) {
   if (h->finalize_failed)  // a set-up that failed half way (out of memory in a family's buffers) has re-ordered private views and partial buffers
     return fail(GLRM_ERR_INVALID, "an earlier glrm_hip_finalize on this handle failed: destroy it and create the shard again");
   DeviceGuard dg(h->device);
-  const int rc = finalize_impl(h, whole);
-  if (rc) h->finalize_failed = true;
-  return rc;
+  return finalize_impl(h, whole);
 }
 
 #define GLRM_NEED_FINALIZED(h) \
@@ -1310,7 +1311,7 @@ extern "C" int glrm_hip_sum_order(glrm_handle* h, int32_t which, glrm_sum_order*
     o.family = GLRM_ORDER_WINDOWED;
     o.lanes = h->tG; o.comps = h->tR;
     o.window = lw ? T : (h->tile_lw > 0 ? 2 * T : T);
-    const int64_t tps = rows ? (h->row_split ? h->tiles_per_sup_r : 0) : h->tiles_per_sup;
+    const int64_t tps = rows ? (h->row_split ? h->tiles_per_sup_r : 0) : h->tiles_per_sup; // (row rounds: one super-tile, nothing re-added = 0)
     o.windows_per_sup = lw ? 2 * tps : tps;
     o.batch = (!quad && (h->tG == 4 || h->tG == 8)) ? h->tG : 2;
     o.rotate = (!(rows && !h->row_split) && !lw && !quad && GLRM_TILE_ROT && (h->tG == 4 || h->tG == 8) && h->tR == 8) ? 1 : 0;

@@ -227,6 +227,16 @@ int glrm_setup_tiled(glrm_handle* h) {
     if ((rc0 = make_segperm(h, false, &h->colperm))) return rc0;
   }
   if (h->tiled_row && (rc0 = make_segperm(h, true, &h->rowperm))) return rc0;
+  // Line-search rounds over the still-searching segments only (glrm_tiled.hpp: TiledArgs::actlist_out).  Columns: the passes after the
+  // first trial; rows: everything after the first trial, which stays fused with the gradient pass in one kernel (GLRM_HIP_TILE_ROUNDS:
+  // bit0 rows, bit1 columns, default 3; 0 = the round-3 forms).  Two lists (the decide kernel reads one and writes the next).
+  h->tile_rounds = env_int("GLRM_HIP_TILE_ROUNDS", 3);
+  if (h->tile_cfg12) h->tile_rounds &= ~1; // the 12-wave experiment exists for the one-kernel row sweep only
+  if ((h->tiled_row && (h->tile_rounds & 1)) || (h->tiled_col && (h->tile_rounds & 2))) {
+    const int64_t cap = std::max<int64_t>(1, std::max(h->tiled_row ? h->ml : 0, h->tiled_col ? h->nl : 0));
+    HIPCK(hipMalloc((void**)&h->actlist, (size_t)cap * 2 * sizeof(int32_t)));
+    h->actlist_cap = cap;
+  }
   // Row sweep in super-tile passes.  The one-kernel row sweep streams the WHOLE opposing factor through LDS per workgroup and pass;
   // workgroups that started at different times are at different tiles, so once Y no longer fits the 4 MB L2 of an XCD every tile
   // they stage comes from the Infinity Cache (~8 TB/s for the whole chip, profiles/r02_ubench_gather.txt) -- at 1M x 50k, k = 32
@@ -235,10 +245,22 @@ int glrm_setup_tiled(glrm_handle* h) {
   // the same L2-sized super-tile.  Super-tile = ~2.5 MB of Y, a function of (n, tile, kp) only.
   h->row_split = 0;
   if (h->tiled_row) {
-    const int64_t ybytes = h->n * (int64_t)h->kp * 8;
-    (void)ybytes;
     const int want_split = env_int("GLRM_HIP_ROW_SPLIT", 0); // measured: no gain (the staged tiles already hit L2 at 88 %); kept as an experiment switch
+    if (!want_split && (h->tile_rounds & 1)) { // the pass buffers of the row rounds: ONE super-tile (nothing is re-added: the bits of the one-kernel sweep)
+      const int64_t nt = (h->n + T - 1) / T;
+      h->tiles_per_sup_r = (int)(nt > 0 ? nt : 1);
+      h->nsup_r = 1;
+      const int64_t ml1 = h->ml > 0 ? h->ml : 1;
+      HIPCK(hipMalloc((void**)&h->part_r, (size_t)ml1 * (h->kp + 2) * 8));
+      HIPCK(hipMalloc((void**)&h->gsum_r, (size_t)ml1 * h->kp * 8));
+      HIPCK(hipMalloc((void**)&h->trial_r, (size_t)ml1 * h->kp * 8));
+      HIPCK(hipMalloc((void**)&h->jold_r, (size_t)ml1 * 8));
+      HIPCK(hipMalloc((void**)&h->active_r, (size_t)ml1 * 4));
+      HIPCK(hipMalloc((void**)&h->ntrial_r, (size_t)ml1 * 4));
+      if (!h->nactive) HIPCK(hipMalloc((void**)&h->nactive, 4));
+    }
     if (want_split) {
+      h->tile_rounds &= ~1;
       const int64_t nt = (h->n + T - 1) / T;
       int64_t tps = ((int64_t)5 * 512 * 1024) / ((int64_t)T * h->kp * 8);
       tps = env_int("GLRM_HIP_ROW_TPS", (int)(tps < 1 ? 1 : tps));
@@ -264,8 +286,9 @@ static int set_lds(K kernel, int bytes) {
   return GLRM_OK;
 }
 
-// kind: 0 = whole sweep (tiled_sweep_kernel), 1 = column pass 1, 2 = column trial pass.  LW > 0: double-buffered half tiles, the
-// first LW waves of the workgroup are LDS-DMA loaders (glrm_tiled.hpp)
+// kind: 0 = whole sweep (tiled_sweep_kernel), 1 = column pass 1, 2 = column trial pass, 3 = row sweep in rounds form (gradient pass +
+// first trial, the rest handed to the rounds), 4 = trial pass of the row rounds.  LW > 0: double-buffered half tiles, the first LW waves
+// of the workgroup are LDS-DMA loaders (glrm_tiled.hpp)
 template <int G, int R, int NW, int TILE, int LOSS, int LW = 0>
 static int launch_tiled_inst(int kind, const TiledArgs& a, hipStream_t st) {
   constexpr int SPB = (NW - LW) * (64 / G);
@@ -278,6 +301,12 @@ static int launch_tiled_inst(int kind, const TiledArgs& a, hipStream_t st) {
   } else if (kind == 0) {
     if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS, false, LW>, lds))) return rc;
     hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS, false, LW>), dim3(gx), dim3(NW * 64), lds, st, a);
+  } else if (kind == 3) {
+    if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS, false, LW, true>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS, false, LW, true>), dim3(gx), dim3(NW * 64), lds, st, a);
+  } else if (kind == 4) {
+    if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false, false, LW, true>, lds))) return rc;
+    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false, false, LW, true>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
   } else if (kind == 1) {
     if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true, false, LW>, lds))) return rc;
     hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true, false, LW>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
@@ -293,7 +322,7 @@ static int launch_tiled_layout(int cfg, int loss, int kind, const TiledArgs& a, 
   constexpr int KP = G * R, T0 = tile_rows_c(KP, 0), T1 = tile_rows_c(KP, 1);
   if constexpr ((G == 4 || G == 8) && R == 8) {
     // heterogeneous row sweep on 12 waves (3 per SIMD, 168 VGPRs: no spills) instead of 16 (128 VGPRs, ~45 spilled)
-    if (cfg == 2 && kind == 0 && a.fixed_alpha <= 0.0 && (loss == LOSS_PER_OBS || loss == LOSS_PER_OBS_NOTRIG))
+    if (cfg == 2 && kind == 0 && a.fixed_alpha <= 0.0 && (loss == LOSS_PER_OBS || loss == LOSS_PER_OBS_NOTRIG)) // (legacy one-kernel form only)
       return loss == LOSS_PER_OBS ? launch_tiled_inst<G, R, 12, T1, 2>(kind, a, st) : launch_tiled_inst<G, R, 12, T1, 4>(kind, a, st);
   }
   if (cfg == 2) cfg = 1;
@@ -324,7 +353,7 @@ static int launch_tiled_layout(int cfg, int loss, int kind, const TiledArgs& a, 
 }
 
 static int launch_tiled(glrm_handle* h, int loss, int kind, const TiledArgs& a) {
-  const bool lw_here = h->tile_lw > 0 && h->tile_cfg && ((h->tile_lw_sides >> (kind == 0 ? 0 : 1)) & 1);
+  const bool lw_here = h->tile_lw > 0 && h->tile_cfg && ((h->tile_lw_sides >> ((kind == 0 || kind == 3 || kind == 4) ? 0 : 1)) & 1);
   const int cfg = lw_here ? 10 + h->tile_lw : (h->tile_cfg12 && h->tile_cfg) ? 2 : h->tile_cfg;
   switch (h->tG * 100 + h->tR) {
     case 402: return launch_tiled_layout<4, 2>(cfg, loss, kind, a, h->stream);
@@ -390,11 +419,12 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
     if (!a.reg_single) a.regs += s0;
     a.trials += s0; a.accepts += s0;
   }
-  if (rows && !h->row_split) {
+  const bool row_rounds = rows && !h->row_split && (h->tile_rounds & 1) && !eval_only && a.fixed_alpha <= 0.0 && h->actlist;
+  if (rows && !h->row_split && !row_rounds) {
     a.segperm = h->rng_e >= 0 ? nullptr : h->rowperm; // a sub-range sweep keeps the natural order
     return launch_tiled(h, loss, 0, a);
   }
-  if (rows) { // super-tile passes over the rows (glrm_setup_tiled): the column machinery with the roles swapped
+  if (rows) { // pass buffers of the rows (row_split: super-tile passes, glrm_setup_tiled; rounds: one super-tile)
     const int64_t s0 = h->rng_e >= 0 ? h->rng_b : 0;
     a.nsup = h->nsup_r;
     a.tiles_per_sup = h->tiles_per_sup_r;
@@ -409,21 +439,44 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
     a.segperm = h->colperm;
   }
   int rc;
+  const bool lists = h->actlist && (rows ? (h->tile_rounds & 1) != 0 : (h->tile_rounds & 2) != 0) && a.nseg <= h->actlist_cap;
+  int32_t* list[2] = {lists ? h->actlist : nullptr, lists ? h->actlist + h->actlist_cap : nullptr};
+  int cur = 0; // the list the kernels of this stage append to
   HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
-  if ((rc = launch_tiled(h, loss, 1, a))) return rc;
-  launch_col_small_any(h, 0, a);
+  a.actlist_out = list[cur];
+  if (row_rounds) {
+    if ((rc = launch_tiled(h, loss, 3, a))) return rc; // gradient pass + first trial; rejected rows are listed
+  } else {
+    if ((rc = launch_tiled(h, loss, 1, a))) return rc;
+    launch_col_small_any(h, 0, a);
+  }
   HIPCK(hipGetLastError());
   if (eval_only || a.fixed_alpha > 0.0) return GLRM_OK;
+  const TiledArgs full = a;
   for (int round = 0; round < 64; ++round) {
     unsigned int nact = 0;
     HIPCK(hipMemcpyAsync(&nact, h->nactive, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));
     if (nact == 0) break;
     HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
-    if ((rc = launch_tiled(h, loss, 2, a))) return rc;
-    launch_col_small_any(h, 1, a);
+    TiledArgs t = full;
+    // the trial pass: over the listed segments when they are the minority (a full grid keeps the length / kind order of segperm, which
+    // pays while nearly every segment still takes part: the first trial of the columns)
+    const bool compact = lists && (row_rounds || (int64_t)nact * 4 < full.nseg * 3);
+    if (compact) {
+      t.segperm = list[cur];
+      t.nseg = nact;
+    }
+    if ((rc = launch_tiled(h, loss, rows && row_rounds ? 4 : 2, t))) return rc;
+    TiledArgs d = full;
+    if (lists) {
+      d.actlist_in = list[cur];
+      d.nact_in = nact;
+      d.actlist_out = list[cur ^ 1];
+      cur ^= 1;
+    }
+    launch_col_small_any(h, 1, d);
     HIPCK(hipGetLastError());
   }
   return GLRM_OK;
 }
-

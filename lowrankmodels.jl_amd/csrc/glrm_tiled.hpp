@@ -70,6 +70,16 @@ struct TiledArgs {
   const int32_t* segperm; // lane-group slot -> local segment (nullptr = identity).  Which segment a group works on changes no sum:
                           // columns are handed out sorted by (loss kind, length), rows by length, so that the 16 groups of a wave
                           // evaluate the same loss formula and finish their lists together.
+  // Line-search rounds over the segments that are STILL SEARCHING only (round 4).  A workgroup stages every tile of the opposing factor
+  // per pass whether one of its 256 segments needs the pass or all of them: with the search inside the kernel (rows) or a pass over
+  // every workgroup that holds an active segment (columns), a few percent of rejected first trials made EVERY workgroup run another
+  // pass (C2: 4 % of the rows, 1.4 % of the columns; C5: the tail of rows on their 3rd .. 6th trial).  Whoever leaves a segment searching
+  // appends it to `actlist_out` (slot = the old value of *nactive); the next trial pass runs over that list (`segperm` = the list,
+  // nseg = its length: ceil(count / 256) workgroups) and the decide kernel reads it as `actlist_in`.  Which slot a segment sits in
+  // changes no sum (see segperm), so the bits are those of the uncompacted rounds.
+  int32_t* actlist_out;       // nullable
+  const int32_t* actlist_in;  // col_decide_kernel: nullable; the segments to decide (nact_in of them) instead of all nseg
+  int64_t nact_in;
 };
 
 // v from lane (lane ^ X) for X = 4 or 8 (ds_swizzle bit-mask mode: and 0x1F, or 0, xor X; no LDS memory touched)
@@ -531,7 +541,11 @@ __device__ __forceinline__ void stage_udesc(const TiledArgs& a, char* lds) {
 // Workgroup = NW waves, SPB = NW*64/G segments; each pass streams the WHOLE opposing factor through LDS.
 // FIXED = true is the SparseProxGradParams step (one gradient pass, x <- prox(x - (alpha/l) g), no line search); it is a
 // separate instantiation so that the line-search kernel keeps its register budget.
-template <int G, int R, int NW, int TILE, int LOSS, bool FIXED, int LW = 0>
+// ROUNDS = true (round 4, the default): the kernel makes the gradient pass and the FIRST trial; a segment whose first trial is rejected
+// leaves its state -- gradient, J_old, shrunk step size, next trial point -- in the pass buffers (gsum, jold, alpha, trial, ntrial,
+// active) and its id in actlist_out, and the host runs the remaining trials as rounds of (tiled_col_pass_kernel<GRAD = false, ROWS> over
+// the listed segments, col_decide_kernel): only workgroups made of still-searching rows stage tiles again.  Same sums, same bits.
+template <int G, int R, int NW, int TILE, int LOSS, bool FIXED, int LW = 0, bool ROUNDS = false>
 __global__ void __launch_bounds__(NW * 64, NW == 12 ? 3 : 4) tiled_sweep_kernel(const TiledArgs a) {
   constexpr int KP = G * R, NGW = 64 / G, SPB = (NW - LW) * NGW; // the first LW waves are loaders (double-buffered tiles)
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -583,7 +597,9 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 3 : 4) tiled_sweep_kernel(
   int ntrials = 0;
   bool accepted = false;
   bool searching = have && alpha > a.min_stepsize;
-  while (__syncthreads_or(searching ? 1 : 0)) {
+  bool first = true;
+  while ((!ROUNDS || first) && __syncthreads_or(searching ? 1 : 0)) {
+    first = false;
     const double s = alpha / l;
 #pragma unroll
     for (int i = 0; i < R / 2; ++i) {
@@ -613,6 +629,37 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 3 : 4) tiled_sweep_kernel(
           searching = false;
         }
       }
+    }
+  }
+  if constexpr (ROUNDS) {
+    if (have) {
+      if (searching) { // first trial rejected, step size still above the minimum: hand the segment over to the rounds
+        const double s = alpha / l;
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+          const double2 xi = ownp[i * G + j];
+          xn.v[i].x = fma(-s, g.v[i].x, xi.x);
+          xn.v[i].y = fma(-s, g.v[i].y, xi.y);
+        }
+        reg_prox<G, R>(rd, xn, s, j, a.k);
+        double2* gp = reinterpret_cast<double2*>(a.gsum + seg * (int64_t)KP);
+        double2* tp = reinterpret_cast<double2*>(a.trial + seg * (int64_t)KP);
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) {
+          gp[i * G + j] = g.v[i];
+          tp[i * G + j] = xn.v[i];
+        }
+        if (j == 0) {
+          a.alpha[seg] = alpha;
+          a.jold[seg] = Jold;
+          a.ntrial[seg] = ntrials;
+          a.active[seg] = 1;
+          const unsigned slot_out = atomicAdd(a.nactive, 1u);
+          a.actlist_out[slot_out] = (int32_t)seg;
+        }
+        return; // col_decide_kernel books trials / accepts when the segment's search ends
+      }
+      if (j == 0) a.active[seg] = 0;
     }
   }
   if (have && j == 0) {
@@ -645,7 +692,7 @@ __device__ __forceinline__ int64_t lower_bound_idx(const int32_t* idx, int64_t b
 // L2 = true: the phase-aligned gather pass (no LDS tile, tiled_pass<..., L2>).  One launch covers ONE super-tile (a.sup_fixed) and
 // a slice [a.seg_begin, a.seg_begin + a.nseg_slice) of the segments that is at most what the chip holds at once, so every group of
 // the launch starts its walk through the super-tile at the same moment; the host issues the launches super-tile by super-tile.
-template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false, int LW = 0>
+template <int G, int R, int NW, int TILE, int LOSS, bool GRAD, bool L2 = false, int LW = 0, bool ROWS = false>
 __global__ void __launch_bounds__(NW * 64, L2 ? 1 : 4) tiled_col_pass_kernel(const TiledArgs a) {
   constexpr int KP = G * R, NGW = 64 / G, SPB = (NW - LW) * NGW, PSTRIDE = KP + 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -664,7 +711,8 @@ __global__ void __launch_bounds__(NW * 64, L2 ? 1 : 4) tiled_col_pass_kernel(con
   const int tb = sup * a.tiles_per_sup;
   const int te = tb + a.tiles_per_sup < ntiles ? tb + a.tiles_per_sup : ntiles;
   const double2* xp = reinterpret_cast<const double2*>(GRAD ? a.own + gseg * KP : a.trial + (have ? seg : 0) * (int64_t)KP);
-  constexpr bool ROT = !L2 && LW == 0 && LOSS != 0 && tile_rot<G, R>();
+  // ROWS: the trial rounds of the row view (the row sweep's own passes read padded tiles without rotation: the same bits here)
+  constexpr bool ROT = !ROWS && !L2 && LW == 0 && LOSS != 0 && tile_rot<G, R>();
   const int rot = ROT ? tile_rot_of(gseg) : 0; // register i <-> chunk i ^ rot (conflict-free tile reads, see tile_rot)
   Vec<G, R> x, g;
 #pragma unroll
@@ -754,7 +802,10 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const TiledArgs a) {
     a.active[seg] = searching ? 1 : 0;
     a.ntrial[seg] = 0;
     if (a.obj) a.obj[gseg] = Jold;
-    if (searching) atomicAdd(a.nactive, 1u);
+    if (searching) {
+      const unsigned slot = atomicAdd(a.nactive, 1u);
+      if (a.actlist_out) a.actlist_out[slot] = (int32_t)seg;
+    }
   }
 }
 
@@ -764,7 +815,11 @@ __global__ void __launch_bounds__(256) col_decide_kernel(const TiledArgs a) {
   constexpr int KP = G * R, NGW = 64 / G, PSTRIDE = KP + 2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % G, gi = lane / G;
-  const int64_t seg = ((int64_t)blockIdx.x * 4 + wave) * NGW + gi;
+  int64_t seg = ((int64_t)blockIdx.x * 4 + wave) * NGW + gi;
+  if (a.actlist_in) { // the still-searching segments only
+    if (seg >= a.nact_in) return;
+    seg = a.actlist_in[seg];
+  }
   if (seg >= a.nseg) return;
   if (a.active[seg] == 0) return; // group-uniform
   const int64_t gseg = a.own_offset + seg;
@@ -813,7 +868,8 @@ __global__ void __launch_bounds__(256) col_decide_kernel(const TiledArgs a) {
     const int nt = a.ntrial[seg] + 1;
     a.ntrial[seg] = nt;
     if (still) {
-      atomicAdd(a.nactive, 1u);
+      const unsigned slot = atomicAdd(a.nactive, 1u);
+      if (a.actlist_out) a.actlist_out[slot] = (int32_t)seg;
     } else if (a.trials) {
       a.trials[seg] += nt;
       a.accepts[seg] += acc;
