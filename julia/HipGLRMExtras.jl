@@ -5,7 +5,7 @@ module HipGLRMExtras
 
 using LowRankModels
 using ..HipGLRM
-import ..HipGLRM: LIB, check, with_handle
+import ..HipGLRM: LIB, check, with_handle, CSumOrder
 
 export hip_init_svd!, hip_error_metric, hip_impute, hip_subset
 
@@ -60,6 +60,15 @@ function hip_subset(parent::Ptr{Cvoid}, tags::Vector{UInt8}, ctags::Vector{UInt8
     check(ccall((:glrm_hip_subset, LIB), Cint, (Ptr{Cvoid}, Ptr{UInt8}, Ptr{UInt8}, Int32, Int32, Ref{Ptr{Cvoid}}),
                 parent, tags, ctags, fold, invert ? 1 : 0, child))
     child[]
+end
+
+# The order in which the engine adds a row's (which = 0) or a column's (which = 1) loss and gradient terms for THIS model -- the
+# attribution tool for trajectories that leave the CPU solver's on the last bit of a line-search sum (src/algorithms/proxgrad.jl:143,187
+# compare two long sums with a strict `<`; include/glrm_hip.h: glrm_sum_order).  `h` is the engine handle fit! keeps per model.
+function hip_sum_order(h::Ptr{Cvoid}, which::Integer)
+    o = Ref(CSumOrder(0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0))
+    check(ccall((:glrm_hip_sum_order, LIB), Cint, (Ptr{Cvoid}, Int32, Ref{CSumOrder}), h, Int32(which), o))
+    o[]
 end
 
 end # module

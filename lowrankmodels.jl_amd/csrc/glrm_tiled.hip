@@ -409,6 +409,7 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
   a.eval_only = eval_only;
   a.fixed_alpha = eval_only ? 0.0 : h->fixed_alpha;
   a.descid = rows ? h->rowdescid : nullptr;
+  a.stagger = env_int("GLRM_HIP_TILE_STAGGER", 0);
   a.udesc = h->udesc;
   a.n_udesc = h->n_udesc;
   if (rows && h->rng_e >= 0) { // glrm_hip_step_x_range

@@ -77,6 +77,7 @@ struct TiledArgs {
   // appends it to `actlist_out` (slot = the old value of *nactive); the next trial pass runs over that list (`segperm` = the list,
   // nseg = its length: ceil(count / 256) workgroups) and the decide kernel reads it as `actlist_in`.  Which slot a segment sits in
   // changes no sum (see segperm), so the bits are those of the uncompacted rounds.
+  int stagger;                // > 0: workgroup i of the 32 an XCD holds at a time starts i x stagger x ~0.2 us late (tile_stagger below)
   int32_t* actlist_out;       // nullable
   const int32_t* actlist_in;  // col_decide_kernel: nullable; the segments to decide (nact_in of them) instead of all nseg
   int64_t nact_in;
@@ -208,6 +209,9 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ other, int64
 #ifndef GLRM_TILE_DMA_ALL
 #define GLRM_TILE_DMA_ALL 1
 #endif
+#ifndef GLRM_TILE_NT
+#define GLRM_TILE_NT 0
+#endif
 template <int G, int R, int NW, bool ROT>
 __device__ __forceinline__ void dma_tile_all(const double* __restrict__ other, int64_t lo, int64_t hi, char* buf, int wave, int lane) {
   constexpr int KPB = G * R * 8, ROWB = tile_row_stride<G, R, ROT>(), CPR = ROWB / 16;
@@ -279,12 +283,26 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
   const uint8_t* __restrict__ descid = a.descid;
   const bool have_ids = UDESC && descid != nullptr;    // uniform
   const char* udesc_lds = lds + tile_lds_bytes<G, R, TILE, LW>(); // the kernel staged the distinct descriptors there
+  // GLRM_TILE_NT: the (index, value, descriptor id) stream is read ONCE per pass -- 13 bytes per observation, 1.1 MB per tile step and XCD at
+  // the C5 shape -- and with the default policy it pushes the staged tiles, which the other workgroups of the XCD are about to read, out
+  // of the 4 MB L2; non-temporal loads keep it from being retained.
   auto load_entry = [&](int64_t p, int& c, double& av, int& did) {
     const int64_t q = p < last ? p : last;
+#if GLRM_TILE_NT
+    c = __builtin_nontemporal_load(idx + q);
+    av = __builtin_nontemporal_load(vals + q);
+#else
     c = idx[q];
     av = vals[q];
+#endif
     did = 0;
-    if constexpr (UDESC) { if (have_ids) did = descid[q]; }
+    if constexpr (UDESC) {
+#if GLRM_TILE_NT
+      if (have_ids) did = __builtin_nontemporal_load(descid + q);
+#else
+      if (have_ids) did = descid[q];
+#endif
+    }
   };
   if constexpr (LW > 0) {
     if ((int)(threadIdx.x >> 6) < LW) { // loader wave: half tile t+1 lands in the other buffer while the compute waves consume t
@@ -523,6 +541,17 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
   J = group_sum<G>(J) * (FOUR ? 1.0 : 2.0 / G); // two per step: lanes hold parity-partial sums, each observation counted G/2 times
 }
 
+// Experiment (GLRM_HIP_TILE_STAGGER): the workgroups an XCD holds at a time all stage the SAME tile at the same moment -- they start
+// together and do equal work -- and 32 simultaneous requests for a line that is not in L2 yet are 32 misses.  Started a fraction of a
+// tile step apart, the first one misses and the others find the line in L2.  Workgroup b runs on XCD b % 8; its place among the 32 the
+// XCD holds is (b / 8) % 32.  Changes no result.
+__device__ __forceinline__ void tile_stagger(int stagger, unsigned linear_block) {
+  if (stagger > 0) {
+    const int n = (int)((linear_block >> 3) & 31u) * stagger;
+    for (int t = 0; t < n; ++t) __builtin_amdgcn_s_sleep(8); // ~512 clocks each
+  }
+}
+
 // distinct loss descriptors -> LDS behind the tile (read after the first tile barrier of tiled_pass); see TiledArgs::descid
 template <int G, int R, int NW, int TILE, int LOSS, int LW = 0>
 __device__ __forceinline__ void stage_udesc(const TiledArgs& a, char* lds) {
@@ -558,6 +587,7 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 3 : 4) tiled_sweep_kernel(
   const int64_t gseg = a.own_offset + (have ? seg : 0);
   double2* ownp = reinterpret_cast<double2*>(a.own + gseg * KP);
   const int ntiles = (int)((a.n_other + TILE - 1) / TILE);
+  tile_stagger(a.stagger, blockIdx.x);
   stage_udesc<G, R, NW, TILE, LOSS, LW>(a, lds);
 
   Vec<G, R> g, xn;
@@ -704,7 +734,10 @@ __global__ void __launch_bounds__(NW * 64, L2 ? 1 : 4) tiled_col_pass_kernel(con
   const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[slot] : slot; // which column a group works on does not change any sum
   if (!GRAD && have) have = a.active[seg] != 0;
   if (!GRAD && !__syncthreads_or(have ? 1 : 0)) return; // nothing left to evaluate in this column group
-  if constexpr (!L2) stage_udesc<G, R, NW, TILE, LOSS, LW>(a, lds);
+  if constexpr (!L2) {
+    tile_stagger(a.stagger, blockIdx.y * gridDim.x + blockIdx.x);
+    stage_udesc<G, R, NW, TILE, LOSS, LW>(a, lds);
+  }
   const int64_t beg = have ? a.ptr[seg] : 0, end = have ? a.ptr[seg + 1] : 0;
   const int64_t gseg = a.own_offset + (have ? seg : 0);
   const int ntiles = (int)((a.n_other + TILE - 1) / TILE);

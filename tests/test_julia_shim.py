@@ -12,7 +12,7 @@ SHIM = os.path.join(ROOT, "julia", "HipGLRM.jl")
 HEADER = os.path.join(ROOT, "include", "glrm_hip.h")
 
 PAIRS = {"CLoss": "glrm_loss", "CReg": "glrm_reg", "CProblem": "glrm_problem", "CParams": "glrm_params", "COptions": "glrm_options",
-         "CMultiOptions": "glrm_multi_options", "CSignature": "glrm_signature"}
+         "CMultiOptions": "glrm_multi_options", "CSignature": "glrm_signature", "CSumOrder": "glrm_sum_order"}
 JL_C = {"Int32": ("int32_t", 4), "Int64": ("int64_t", 8), "Float64": ("double", 8), "UInt64": ("uint64_t", 8)}
 
 
