@@ -340,3 +340,39 @@ def test_persistent_cached_sweep_gives_the_bits_of_one_row_per_workgroup(monkeyp
     o1, X1, Y1, _ = cases.run_engine(api, pa, X0, Y0, params, tiled=0)
     o2, X2, Y2, _ = cases.run_shards_on_one_device(api, pa, X0, Y0, params, [0, 250, 600], [0, 100, 400], x_chunks=3, tiled=0)
     assert np.array_equal(X1, X2) and np.array_equal(Y1, Y2) and np.array_equal(o1[1:], o2)
+
+
+# ------------------------------------------------------------------------------------------------ LDS-tiled sweeps: rounds over the still-searching segments
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_lds_tiled_rounds_over_the_searching_segments_give_the_bits_of_the_in_kernel_search(monkeypatch, mixed):
+    """Round 4: the LDS-tiled row sweep makes the gradient pass and the first trial in one kernel and runs every further trial as a round
+    over the rows that are still searching (compacted: csrc/glrm_tiled.hpp TiledArgs::actlist_out); the column passes compact their trial
+    rounds the same way.  Which workgroup slot a segment sits in changes no sum: factors, step sizes' effects and trial counts must equal
+    the round-3 forms (GLRM_HIP_TILE_ROUNDS=0: the whole search inside the row kernel, column rounds over every workgroup that holds an
+    active column) bit for bit -- from a start and a step size that make most segments reject several trials."""
+    m, n, k, q = 4000, 1500, 32, 150
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, q, value_model=0, loss_mix=1 if mixed else 0)
+    if mixed:
+        kinds = [L.QuadLoss().descriptor(), L.LogisticLoss().descriptor(), L.OrdinalHingeLoss(1, 5).descriptor()]
+        losses = np.array([kinds[f % 3] for f in range(n)], dtype=_capi.LOSS_DTYPE)
+    else:
+        losses = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 0.5)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, losses, reg, reg)
+    params = L.ProxGradParams(stepsize=40.0, max_iter=6, abs_tol=0.0, rel_tol=-1.0)   # alpha starts 40 x too large: every segment rejects several trials in its first half-steps
+    res = {}
+    for rounds in ("0", "3", "1", "2"):
+        monkeypatch.setenv("GLRM_HIP_TILE_ROUNDS", rounds)
+        res[rounds] = cases.run_engine(hip(), pa, X0, Y0, params, tiled=2)
+        assert res[rounds][3]["tiled"] & 3 == 3
+    base = res["0"]
+    assert base[3]["trials_x"] > 2 * m * 6 and base[3]["trials_y"] > 2 * n * 6      # the search really ran for several rounds per segment
+    for rounds in ("3", "1", "2"):
+        r = res[rounds]
+        assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]) and np.array_equal(r[2], base[2]), rounds
+        for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
+            assert r[3][key] == base[3][key], (rounds, key)
+    O.set_threads(4)
+    o_c, X_c, Y_c, st_c = cases.run_engine(O.oracle_api(), pa, X0, Y0, params)
+    assert cases.rel_err(res["3"][0], o_c) < TOL and cases.fro_err(res["3"][1], X_c) < TOL and cases.fro_err(res["3"][2], Y_c) < TOL
