@@ -1019,8 +1019,10 @@ def main():
         rl, dom_ms, dom_nnz, dom_fam = (rl_r, ms_x, nnz_r, fam_r) if dom == "row" else (rl_c, ms_y, nnz_c, fam_c)
         kname = {("row", "gather"): ("sweep_kernel (X half-step, k-vector gather)", "sweep_kernel"),
                  ("col", "gather"): ("sweep_kernel (Y half-step, k-vector gather)", "sweep_kernel"),
-                 ("row", "tiled"): ("tiled_sweep_kernel (X half-step, LDS-tiled)", "tiled_sweep_kernel"),
-                 ("col", "tiled"): ("tiled_col_pass_kernel x2 + col_reduce/col_decide (Y half-step, LDS-tiled)", "tiled_col_pass_kernel"),
+                 ("row", "tiled"): ("tiled_sweep_kernel<ROUNDS> (gradient pass + first trial) + tiled_col_pass_kernel<ROWS> rounds over the still-searching rows "
+                                    "(X half-step, LDS-tiled)", r"tiled_sweep_kernel|tiled_col_pass_kernel<[^>]*, true>"),
+                 ("col", "tiled"): ("tiled_col_pass_kernel gradient pass + trial rounds + col_reduce/col_decide (Y half-step, LDS-tiled)",
+                                    r"tiled_col_pass_kernel<[^>]*, false>"),
                  ("row", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (X half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
                  ("col", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (Y half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
                  ("row", "cached"): ("regcached_sweep_kernel<G, R, LOSS, 7, 2> (X half-step: the row's list and opposing vectors fetched once into "
@@ -1039,8 +1041,7 @@ def main():
                 # the row and the column pass of the blocked family are the same kernel instantiation: the child runs only the dominant
                 # side on it (the other side on the one-kernel gather sweep), so its dispatches can be told apart by name
                 cenv = {"GLRM_HIP_BLOCKED": "1" if dom == "row" else "2"} if dom_fam == "blocked" else None
-                traffic, traffic_src, l2_hits = pmc_traffic(args, kre, per_halfstep=dom_fam == "blocked" or (dom_fam == "tiled" and dom == "col"),
-                                                            child_env=cenv)
+                traffic, traffic_src, l2_hits = pmc_traffic(args, kre, per_halfstep=dom_fam in ("blocked", "tiled"), child_env=cenv)
                 if traffic is not None and dom_fam == "gather" and st["waves_row"] == st["waves_col"]:
                     traffic_src += " (row and column sweeps run the same instantiation here: the mean is over both)"
             except Exception as e:  # the bench line must survive a profiler problem

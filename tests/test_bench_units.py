@@ -119,11 +119,14 @@ def test_quad_gram_prices_the_flop_that_are_left():
 
 
 def test_exchange_model_and_signature_combine():
-    """xGMI model printed beside the shard measurements: direct = one block per link, ring = N - 1 hops; the whole problem's signature is
-    the sum of the shards' observation counts and the max of everything else."""
+    """xGMI model printed beside the shard measurements: direct = one block per link in ONE direction (76.8 GB/s: AMD's 153.6 GB/s per link
+    counts both), ring = N - 1 hops, the optimistic variant and the equivalent all-gather bus bandwidth printed beside it; the whole
+    problem's signature is the sum of the shards' observation counts and the max of everything else."""
     from lowrankmodels.jl_amd import _capi
     ex = bench.exchange_model_ms(640e6, 8)
-    assert ex["direct"] == pytest.approx(640e6 / 153e9 * 1e3) and ex["ring"] == pytest.approx(7 * ex["direct"])
+    assert ex["direct"] == pytest.approx(640e6 / 76.8e9 * 1e3) and ex["ring"] == pytest.approx(7 * ex["direct"])
+    assert ex["optimistic_direct_if_153GBps_were_per_direction"] == pytest.approx(ex["direct"] / 2) and ex["link_GBps_one_direction"] == 76.8
+    assert ex["busbw_equivalent_GBps_direct"] == pytest.approx(7 * 76.8)
     assert bench.exchange_model_ms(1e9, 1) == {"direct": 0.0, "ring": 0.0}
     a, b = _capi.CSignature(10, 12, 3, 5, 0, 1), _capi.CSignature(7, 1, 9, 2, 1, 0)
     w = _capi.CSignature.combine([a, b.astuple()])
