@@ -212,6 +212,9 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ other, int64
 #ifndef GLRM_TILE_NT
 #define GLRM_TILE_NT 0
 #endif
+#ifndef GLRM_TILE_CHUNK_MAJOR
+#define GLRM_TILE_CHUNK_MAJOR 1
+#endif
 template <int G, int R, int NW, bool ROT>
 __device__ __forceinline__ void dma_tile_all(const double* __restrict__ other, int64_t lo, int64_t hi, char* buf, int wave, int lane) {
   constexpr int KPB = G * R * 8, ROWB = tile_row_stride<G, R, ROT>(), CPR = ROWB / 16;
@@ -387,6 +390,25 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
             else ro[u] = ((ok[u] ? c[u] : c[0]) - (int)lo) * ROWB + jrot;
             mine = (j == u) ? ok[u] : mine;
             p[u] = 0.0;
+          }
+#if GLRM_TILE_CHUNK_MAJOR
+          // chunk-major: the G reads of a chunk are issued together and feed G INDEPENDENT fma chains (round 4: the observation-major
+          // order compiled to sixteen serialized LDS round trips per step -- one read in flight, `s_waitcnt lgkmcnt(0)` after each --
+          // because the scheduler minimises registers in a kernel at its VGPR cap).  Every p[u] still adds its chunks in ascending order.
+#pragma unroll
+          for (int i = 0; i < R / 2; ++i) {
+            double2 yv[G];
+#pragma unroll
+            for (int u = 0; u < G; ++u) yv[u] = L2 ? *reinterpret_cast<const double2*>(rp[u] + i * CB) : tile_chunk<ROT, CB>(mem, ro[u], i);
+#pragma unroll
+            for (int u = 0; u < G; ++u) {
+              p[u] = fma(xv.v[i].x, yv[u].x, p[u]);
+              p[u] = fma(xv.v[i].y, yv[u].y, p[u]);
+            }
+          }
+#else
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
 #pragma unroll
             for (int i = 0; i < R / 2; ++i) {
               const double2 y = L2 ? *reinterpret_cast<const double2*>(rp[u] + i * CB) : tile_chunk<ROT, CB>(mem, ro[u], i);
@@ -394,6 +416,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
               p[u] = fma(xv.v[i].y, y.y, p[u]);
             }
           }
+#endif
           const bool hi2 = (j & 2) != 0;
           double q[G / 2]; // q[i]: observation 2i + odd, summed over lanes {j, j^1}
 #pragma unroll
@@ -430,6 +453,22 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
           J += L; // every observation once
           if (GRAD) {
             asm volatile("" ::: "memory"); // the reads below are real re-reads, not the values of the first ones kept in VGPRs
+#if GLRM_TILE_CHUNK_MAJOR
+            double dv[G]; // observations past the tile window carry a zero derivative
+#pragma unroll
+            for (int u = 0; u < G; ++u) dv[u] = group_bcast_f64<G>(dL, u, lane);
+#pragma unroll
+            for (int i = 0; i < R / 2; ++i) { // chunk-major like the dot products; every component still adds its terms in list order
+              double2 yv[G];
+#pragma unroll
+              for (int u = 0; u < G; ++u) yv[u] = L2 ? *reinterpret_cast<const double2*>(rp[u] + i * CB) : tile_chunk<ROT, CB>(mem, ro[u], i);
+#pragma unroll
+              for (int u = 0; u < G; ++u) {
+                g.v[i].x = fma(dv[u], yv[u].x, g.v[i].x);
+                g.v[i].y = fma(dv[u], yv[u].y, g.v[i].y);
+              }
+            }
+#else
 #pragma unroll
             for (int u = 0; u < G; ++u) { // list order; observations past the tile window carry a zero derivative
               const double d = group_bcast_f64<G>(dL, u, lane);
@@ -440,6 +479,7 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
                 g.v[i].y = fma(d, y.y, g.v[i].y);
               }
             }
+#endif
           }
 #pragma unroll
           for (int u = 0; u < G; ++u) nproc += ok[u] ? 1 : 0;
