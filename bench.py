@@ -753,12 +753,14 @@ def inlib_host(args):
     return out
 
 
-def inlib_child(args, n_gpus, timeout_s=420):
+def inlib_child(args, n_gpus, timeout_s=420, shared_device=False):
     """`bench.py --host inlib --gpus N` as a child process with a time limit (the first multi-GPU run of a path that has only ever run
     with its shards on one device must not take the job's line with it): returns the child's JSON line, or what went wrong."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--host", "inlib", "--gpus", str(n_gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--config", args.config, "--rows", str(args.rows), "--cols", str(args.cols), "--obs-per-row", str(args.obs_per_row), "--rank", str(args.k),
            "--seed", str(args.seed), "--tiled", str(args.tiled), "--x-chunks", str(args.x_chunks), "--waves-row", str(args.waves_row), "--waves-col", str(args.waves_col)]
+    if shared_device:
+        cmd.append("--shared-device")
     env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
                                                                "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
     t0 = time.time()
@@ -1111,10 +1113,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             c3 = args.config == "C3"  # the oracle has no dense hand-over: its list path on the same fully observed recipe
             out["cpu_baseline"] = cpu_baseline(args, cfg, k, q if not c3 else n, n, m)
-        if world > 1 and backend == "nccl" and not args.no_inlib_leg and args.config != "C3" and args.scaling == "strong":
-            # the same problem once more through the host the reference would bind (one process, N devices); every rank of this job has
-            # released its shard, and waits at the barrier below while rank 0's child runs
-            out["inlib_host"] = inlib_child(args, world)
+        # the same problem once more through the host the reference would bind (one process, N devices); every rank of this job has
+        # released its shard, and waits at the barrier below while rank 0's child runs.  GLRM_BENCH_INLIB=shared: all shards on device 0
+        # (the gloo plumbing mode of a box with fewer GPUs than ranks: tests/test_gpu_multirank.py drives this very code path)
+        inlib_shared = os.environ.get("GLRM_BENCH_INLIB") == "shared"
+        if world > 1 and (backend == "nccl" or inlib_shared) and not args.no_inlib_leg and args.config != "C3" and args.scaling == "strong":
+            out["inlib_host"] = inlib_child(args, world, shared_device=inlib_shared)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

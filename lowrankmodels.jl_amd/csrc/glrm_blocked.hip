@@ -354,7 +354,9 @@ int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, d
   glrm_launch_col_small(h->kp, 0, a, h->stream);                 // reduce in super-tile order, J_old, first trial point
   HIPCK(hipGetLastError());
   if (eval_only || a.fixed_alpha > 0.0) return GLRM_OK;
-  for (int round = 0; round < 64; ++round) {
+  constexpr int MAX_ROUNDS = 4096; // see glrm_run_tiled: a guard, never a silent cut
+  for (int round = 0;; ++round) {
+    if (round == MAX_ROUNDS) return fail(GLRM_ERR_INVALID, "line search still running after %d rounds (min_stepsize %g)", MAX_ROUNDS, min_stepsize);
     unsigned int nact = 0;
     HIPCK(hipMemcpyAsync(&nact, h->nactive, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));

@@ -238,7 +238,9 @@ int glrm_run_dense(glrm_handle* h, bool rows, double min_stepsize, int eval_only
   DenseArgs t = d;
   t.xsrc = a.trial; // trial points are stored per local segment
   t.own_offset = 0;
-  for (int round = 0; round < 64; ++round) {
+  constexpr int MAX_ROUNDS = 4096; // see glrm_run_tiled: a guard against a loop that cannot end, never a silent cut of the search
+  for (int round = 0;; ++round) {
+    if (round == MAX_ROUNDS) return fail(GLRM_ERR_INVALID, "line search still running after %d rounds (min_stepsize %g)", MAX_ROUNDS, min_stepsize);
     unsigned int nact = 0;
     HIPCK(hipMemcpyAsync(&nact, h->nactive, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));

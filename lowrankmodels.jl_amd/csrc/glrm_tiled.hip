@@ -454,7 +454,12 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
   HIPCK(hipGetLastError());
   if (eval_only || a.fixed_alpha > 0.0) return GLRM_OK;
   const TiledArgs full = a;
-  for (int round = 0; round < 64; ++round) {
+  // A segment leaves the search when a trial is accepted or its step size falls below min_stepsize: at most log(alpha / min_stepsize) /
+  // log(1 / 0.7) rounds (13 from alpha = 1 and the default 0.01; ~2 100 from any finite alpha down to 0).  The bound below is a guard
+  // against a loop that cannot end, never a silent cut: running into it is an error.
+  constexpr int MAX_ROUNDS = 4096;
+  for (int round = 0;; ++round) {
+    if (round == MAX_ROUNDS) return fail(GLRM_ERR_INVALID, "line search still running after %d rounds (min_stepsize %g)", MAX_ROUNDS, min_stepsize);
     unsigned int nact = 0;
     HIPCK(hipMemcpyAsync(&nact, h->nactive, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(hipStreamSynchronize(h->stream));

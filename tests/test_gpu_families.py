@@ -376,3 +376,27 @@ def test_lds_tiled_rounds_over_the_searching_segments_give_the_bits_of_the_in_ke
     O.set_threads(4)
     o_c, X_c, Y_c, st_c = cases.run_engine(O.oracle_api(), pa, X0, Y0, params)
     assert cases.rel_err(res["3"][0], o_c) < TOL and cases.fro_err(res["3"][1], X_c) < TOL and cases.fro_err(res["3"][2], Y_c) < TOL
+
+
+@pytest.mark.parametrize("family", ["tiled", "blocked", "gather"])
+def test_a_line_search_of_two_hundred_rounds_runs_to_its_end(monkeypatch, family):
+    """fit!(glrm, ProxGradParams(1e30, min_stepsize=1e-3)): every segment shrinks its step ~200 times before a trial is accepted
+    (src/algorithms/proxgrad.jl:136-155 has no bound on the trials of a line search).  The pass families run the search as host-driven
+    rounds; until round 4 the loop stopped after 64 rounds and silently left the segments mid-search.  Trial counts and factors against the oracle."""
+    if family == "blocked":
+        force_blocked(monkeypatch)
+    m, n, k, q = 3000, 1200, 32, 120
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, q, value_model=0)
+    one = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(0, 0, 1.0)], dtype=_capi.REG_DTYPE)   # ZeroReg: nothing shrinks the trial point, the step size has to come down by itself
+    pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, one, reg, reg)
+    params = L.ProxGradParams(stepsize=1e30, max_iter=2, abs_tol=0.0, rel_tol=-1.0, min_stepsize=1e-3)   # (the default minimum is stepsize / 100)
+    O.set_threads(4)
+    o_c, X_c, Y_c, st_c = cases.run_engine(O.oracle_api(), pa, X0, Y0, params)
+    o_g, X_g, Y_g, st_g = cases.run_engine(hip(), pa, X0, Y0, params, tiled={"tiled": 2, "blocked": 1, "gather": 1}[family])
+    want = {"tiled": 3, "blocked": BLOCKED_ROWS | BLOCKED_COLS, "gather": 0}[family]
+    assert st_g["tiled"] & want == want
+    assert st_c["trials_x"] > 150 * m and st_c["trials_y"] > 150 * n
+    for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
+        assert abs(st_g[key] - st_c[key]) <= max(5, 1e-3 * st_c[key]), (key, st_g[key], st_c[key])
+    assert cases.rel_err(o_g, o_c) < TOL and cases.fro_err(X_g, X_c) < TOL and cases.fro_err(Y_g, Y_c) < TOL

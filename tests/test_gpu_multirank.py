@@ -51,10 +51,16 @@ def test_c4_recipe_strong_scaling_equals_one_rank(nranks):
     """bench.py's default mode: the C4 recipe (rank 64, NonNegConstraint, non-negative start) as ONE fixed problem whose rows and
     columns are cut into `nranks` shards (strong scaling) -- same recorded objectives, bit for bit, as the single-rank run."""
     common = ["--config", "C4", "--rows", "48000", "--cols", "4000", "--obs-per-row", "100", "--steps", "3", "--warmup", "2"] + QUIET
-    env = dict(os.environ, GLRM_BENCH_BACKEND="gloo", GLRM_GATHER="allgather")
+    env = dict(os.environ, GLRM_BENCH_BACKEND="gloo", GLRM_GATHER="allgather", GLRM_BENCH_INLIB="shared")
     many = run(torchrun(nranks) + common, env)
     one = run([sys.executable, "bench.py"] + common, dict(os.environ))
     assert many["n_gpus"] == nranks and many["scaling"] == "strong" and many["config"]["k"] == 64
+    # rank 0 ran the in-library host (glrm_hip_multi_fit: what the Julia shim ccalls) on the same problem as a child process and
+    # embedded its line: same shard count, same objective bits as both other hosts
+    lib = many["inlib_host"]
+    assert "error" not in lib, lib
+    assert lib["n_gpus"] == nranks and lib["config"]["host"] == "inlib" and lib["host"]["shared_device"]
+    assert lib["objective"]["after_warmup_and_steps"] == one["objective"]["after_warmup_and_steps"]
     assert many["config"]["observed"] == one["config"]["observed"] == 48000 * 100
     assert many["objective"] == one["objective"]
     assert 0 < one["roofline"]["frac"] <= 1.0 and one["roofline"]["bound"] in ("hbm", "l2", "lds", "mfma")
