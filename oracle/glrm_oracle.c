@@ -317,8 +317,19 @@ typedef struct glrm_cpu_handle {
   int dense_faithful; /* 1 = reproduce the reference's Theta(mnk) cost model */
   double* XY;         /* m x n, only in dense_faithful mode */
   glrm_sum_order order_r, order_c; /* summation order of the row / column half-step: GLRM_ORDER_REFERENCE unless glrm_cpu_set_sum_order adopted an engine order */
+  double accept_bias;              /* test knob, 0 = the reference's strict `<` (glrm_cpu_set_accept_bias) */
   glrm_kernel_stats st;
 } glrm_cpu_handle;
+
+/* The accept test of the line search, src/algorithms/proxgrad.jl:143,187: `new < old`, strict.  With a nonzero accept_bias (TEST KNOB,
+ * glrm_cpu_set_accept_bias) the comparison becomes new < old + bias * |old| for finite `old`: a run with bias = +eps and one with
+ * bias = -eps (eps = a few ulps) bracket every decision that hangs on the last bits of the two sums.  If either leaves the unbiased
+ * trajectory, the trajectory contains a line-search TIE at rounding level and parity with any other summation order is undefined on
+ * it (tests/perf/soak_fuzz.py: ill_conditioned). */
+static inline int accept_test(const glrm_cpu_handle* h, double nobj, double obj) {
+  if (h->accept_bias == 0.0 || !isfinite(obj)) return nobj < obj;
+  return nobj < obj + h->accept_bias * fabs(obj);
+}
 
 static const glrm_loss* loss_of(const glrm_cpu_handle* h, int64_t f) {
   return h->n_losses == 1 ? &h->losses[0] : &h->losses[f];
@@ -794,7 +805,7 @@ static int eng_step(glrm_cpu_handle* h, int rows, int64_t s0, int64_t s1, double
         eng_pass(h, o, rows, gseg, idx, vals, e - b, xn, fac, segloss, &Jn, NULL, work);
         Jn += eng_reg_evaluate(r, xn, k, o->lanes, o->comps);
         ++trials;
-        if (Jn < Jold) {
+        if (accept_test(h, Jn, Jold)) {
           memcpy(x, xn, (size_t)k * 8);
           alpha *= 1.05;
           Jold = Jn;
@@ -848,6 +859,13 @@ int glrm_cpu_set_sum_order(glrm_cpu_handle* h, int32_t which, const glrm_sum_ord
       return fail(GLRM_ERR_INVALID, "sum order: bad cached wave count");
   }
   *dst = *order;
+  return GLRM_OK;
+}
+
+/* Oracle-only test knob: see accept_test.  bias = 0 restores the reference's comparison. */
+int glrm_cpu_set_accept_bias(glrm_cpu_handle* h, double bias) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  h->accept_bias = bias;
   return GLRM_OK;
 }
 
@@ -913,7 +931,7 @@ static int step_x_rows(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_st
         for (int c = 0; c < k; ++c) newx[c] = fma(-stepsize, g[c], x[c]); /* axpy!(-stepsize,g,newve[e]) :140 */
         glrm_cpu_reg_prox(r, newx, k, stepsize);                            /* :142 */
         ++trials;
-        if (row_objective(h, el, newx, scratch) < obj_old) { /* :143 */
+        if (accept_test(h, row_objective(h, el, newx, scratch), obj_old)) { /* :143 */
           memcpy(x, newx, (size_t)k * 8);
           alpha *= 1.05;
           ++accepts;
@@ -979,7 +997,7 @@ int glrm_cpu_step_y(glrm_cpu_handle* h, double min_stepsize) {
         nobj += col_loss(h, fl, newy, mapped);
         nobj += glrm_cpu_reg_evaluate(r, newy, k);
         ++trials;
-        if (nobj < obj) { /* :187-191 */
+        if (accept_test(h, nobj, obj)) { /* :187-191 */
           memcpy(y, newy, (size_t)k * 8);
           alpha *= 1.05;
           obj = nobj;
@@ -1590,7 +1608,7 @@ static int gen_step_x(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_ste
         for (int c = 0; c < k; ++c) newx[c] = fma(-stepsize, g[c], x[c]);
         glrm_cpu_reg_prox_block(r, newx, k, 1, stepsize);
         ++trials;
-        if (gen_row_objective(h, el, newx) < obj_old) {
+        if (accept_test(h, gen_row_objective(h, el, newx), obj_old)) {
           memcpy(x, newx, (size_t)k * 8);
           alpha *= 1.05;
           ++accepts;
@@ -1658,7 +1676,7 @@ static int gen_step_y(glrm_cpu_handle* h, double min_stepsize, double fixed_alph
         nobj += gen_col_loss(h, fl, newy, mapped);
         nobj += glrm_cpu_reg_evaluate_block(r, newy, k, d);
         ++trials;
-        if (nobj < obj) {
+        if (accept_test(h, nobj, obj)) {
           memcpy(y, newy, (size_t)k * d * 8);
           alpha *= 1.05;
           obj = nobj;

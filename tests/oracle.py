@@ -54,6 +54,7 @@ def oracle_lib():
         _lib.glrm_cpu_set_dense_faithful.argtypes = [C.c_void_p, C.c_int]
         _lib.glrm_cpu_get_stepsizes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.glrm_cpu_set_sum_order.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        _lib.glrm_cpu_set_accept_bias.argtypes = [C.c_void_p, C.c_double]
     return _lib
 
 
@@ -71,6 +72,12 @@ def set_sum_order(h, which, order):
     glrm_hip_sum_order reported for a handle of the HIP engine (or one built by hand); None returns to the reference order."""
     api = oracle_api()
     api._ck(oracle_lib().glrm_cpu_set_sum_order(h, int(which), C.byref(order) if order is not None else None))
+
+
+def set_accept_bias(h, bias):
+    """Test knob: the line search accepts iff new < old + bias * |old| (0 = the reference's strict `<`).  Runs with +eps and -eps bracket
+    every decision that hangs on the last bits of the two sums (oracle/glrm_oracle.c: accept_test)."""
+    oracle_api()._ck(oracle_lib().glrm_cpu_set_accept_bias(h, float(bias)))
 
 
 def make_sum_order(family, lanes, comps, waves=0, cached_maxlen=-1, cached_waves=0, batch=0, batch_one_wave_only=0, rotate=0, window=0,
