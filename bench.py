@@ -439,7 +439,7 @@ def jref_leg(args, cfg, api, device, fixture=None):
         h, Xg, Yg = jref_device_problem(fixture, cfg, args.seed, api, device)
         cpu = {"cpu_iterations_to_own_stop": it_cpu, "cpu_seconds": fixture["cpu_seconds"], "cpu_cores": fixture["cpu_cores"],
                "cpu_where": fixture["cpu_where"], "fixture": f"tests/golden/jref_{fixture['config']}.json (tools/make_jref.py)",
-               "cpu_objective_initial": fixture["objective"][0]}
+               "cpu_objective_initial": fixture["objective"][0], "cpu_on_gpu_box": fixture.get("cpu_on_gpu_box")}
         nobs = fixture["observations"]
         try:
             parity = jref_parity(fixture, api, h, Xg, Yg)
@@ -485,6 +485,12 @@ def jref_leg(args, cfg, api, device, fixture=None):
     if cpu.get("cpu_seconds") and it is not None and sec_gpu[it] > 0:
         same_box = cpu.get("cpu_where", "").startswith("this host")
         out["speedup_to_J_ref_vs_cpu" if same_box else "cross_box_ratio_cpu_seconds_over_gpu_seconds"] = cpu["cpu_seconds"] / float(sec_gpu[it])
+        gb = cpu.get("cpu_on_gpu_box")
+        if not same_box and gb:
+            # the same CPU run, timed on the cores of a GPU box of this pool in an earlier session (bit-identical trajectory): the CPU leg of
+            # "wall-clock to reference convergence" on the box class the GPU number comes from
+            out["speedup_to_J_ref_vs_cpu_on_a_gpu_box"] = {"ratio": gb["cpu_seconds"] / float(sec_gpu[it]), "cpu_seconds": gb["cpu_seconds"], "cores": gb["cores"],
+                                                           "gpu_seconds": float(sec_gpu[it]), "cpu_measured": gb["where"]}
         if not same_box:
             out["cross_box_note"] = ("the CPU seconds were measured on the 8 cores of the build container when the fixture was made, the GPU seconds on this box: "
                                      "not a same-box speed-up (cpu_baseline is the same-box CPU rate)")

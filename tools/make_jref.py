@@ -105,7 +105,9 @@ def main():
     ap.add_argument("--cols", type=int, default=0)
     ap.add_argument("--obs-per-row", type=int, default=0)
     ap.add_argument("--seed", type=int, default=20260926)
-    ap.add_argument("--out-tag", default="", help="suffix of the output files (cuts of the recipe for tools/attribute_drift.py)")
+    ap.add_argument("--out-tag", default="", help="suffix of the output files (cuts of the recipe)")
+    ap.add_argument("--time-only", action="store_true", help="re-run the reference-order fit on THIS host's cores, check it against the committed fixture bit for "
+                    "bit and print its seconds (the fixture is not rewritten): the CPU leg of `wall-clock to reference convergence` on the GPU box")
     a = ap.parse_args()
     cfg = dict(bench.CONFIGS[a.config])
     n, q, k = a.cols or cfg["cols"], a.obs_per_row or cfg["q"], cfg["k"]
@@ -121,6 +123,12 @@ def main():
 
     obj, X, Y, st, t_fit = run(api, pa, X0, Y0, None)
     print("reference order:", obj[-1], len(obj) - 1, f"{t_fit:.0f} s", flush=True)
+    if a.time_only:
+        same = old is not None and old.get("objective") == [float(v) for v in obj]
+        print(json.dumps({"mode": "jref-time-only", "config": a.config, "m": a.rows, "n": n, "k": k, "observations": int(pa.rowptr[-1]), "cores": cores,
+                          "iterations_to_own_stop": len(obj) - 1, "J_ref": float(obj[-1]), "cpu_seconds": t_fit, "cpu_seconds_per_iteration": t_fit / max(len(obj) - 1, 1),
+                          "generate_seconds": t_gen, "trajectory_equals_the_committed_fixture_bit_for_bit": bool(same), "where": "this host"}), flush=True)
+        return
     obj_e, X_e, Y_e, st_e, t_fit_e = run(api, pa, X0, Y0, orders)
     print("engine order:   ", obj_e[-1], len(obj_e) - 1, f"{t_fit_e:.0f} s", flush=True)
 
