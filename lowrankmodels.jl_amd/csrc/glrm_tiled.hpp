@@ -215,6 +215,9 @@ __device__ __forceinline__ void dma_tile(const double* __restrict__ other, int64
 #ifndef GLRM_TILE_CHUNK_MAJOR
 #define GLRM_TILE_CHUNK_MAJOR 1
 #endif
+#ifndef GLRM_TILE_QUAD_FOUR
+#define GLRM_TILE_QUAD_FOUR 0
+#endif
 template <int G, int R, int NW, bool ROT>
 __device__ __forceinline__ void dma_tile_all(const double* __restrict__ other, int64_t lo, int64_t hi, char* buf, int wave, int lane) {
   constexpr int KPB = G * R * 8, ROWB = tile_row_stride<G, R, ROT>(), CPR = ROWB / 16;
@@ -269,7 +272,10 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
     tile_begin *= 2;
     tile_end *= 2;
   }
-  constexpr bool FOUR = (G == 4 || G == 8) && LOSS != 0; // the whole batch of G observations per step (below)
+  // the whole batch of G observations per step (below).  GLRM_TILE_QUAD_FOUR: the uniform QuadLoss kernels too (G = 4 only).  The first
+  // attempt (round 2, trial pass only, observation-major loops) lost to the two-observation step: one long dependent chain per four
+  // observations.  With the chunk-major loops of round 4 the four chains are independent and interleaved.
+  constexpr bool FOUR = (G == 4 || G == 8) && (LOSS != 0 || (GLRM_TILE_QUAD_FOUR && G == 4));
   const double two_scale = 2 * segloss.scale;
   J = 0.0;
   if (GRAD && !ACC) { // ACC: the caller's gradient is carried on (lockstep windows, glrm_blocked.hip)
@@ -431,7 +437,11 @@ __device__ __forceinline__ void tiled_pass(const TiledArgs& a, char* lds, const 
             dot = (hi4 ? r1 : r0) + swizzle_xor_f64<4>(hi4 ? r0 : r1);                     // observation j
           }
           double L, dL;
-          if constexpr (loss_mode(LOSS) == 1) {
+          if constexpr (LOSS == 0) { // one QuadLoss descriptor (src/losses.jl:144,146)
+            const double dq = dot - ab;
+            L = segloss.scale * (dq * dq);
+            dL = dq * two_scale;
+          } else if constexpr (loss_mode(LOSS) == 1) {
             loss_both<GRAD, loss_trig(LOSS)>(segloss, dot, ab, L, dL);
           } else {
             LossDesc lo_;
