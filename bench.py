@@ -46,6 +46,10 @@ LDS_PEAK_GBS = 150000.0
 MFMA_F64_PEAK_TFLOPS = 78.6
 MALL_BYTES = 256 * 2 ** 20
 MALL_GATHER_GBS = 8200.0   # measured, not spec: random 512-byte reads out of the Infinity Cache (profiles/r02_ubench_gather.txt)
+# roofline.frac is ALWAYS achieved / peak of the best-priced limiter (for the gathering families: SURVEY 8(d)'s algorithmic bytes over the
+# HBM peak).  A fraction above this mark cannot come from HBM alone (MI355X_MICROARCH.md: 6.29 TB/s measured copy ceiling = 0.79 of the
+# spec) and is flagged `cache_served`; `traffic_frac` (PMC bytes that crossed the fabric / time / HBM peak) always stands beside it.
+CACHE_SERVED_ABOVE = 0.9
 
 
 def passes_priced(family):
@@ -170,20 +174,42 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
 
 
 def side_summary(rl):
-    """The best-priced limiter of one half-step for the `kernels` block.  A fraction at or above 1 is the SURVEY 8(d) algorithmic byte count
-    of a family whose gathers are partly served by the caches: it is labelled as such, never as a roofline fraction (the dominant
-    kernel's `roofline` block replaces it by the PMC traffic fraction)."""
+    """The best-priced limiter of one half-step for the `kernels` block: `frac` = achieved / peak of that limiter, always the same kind of
+    number (never swapped for another definition on a threshold); `cache_served` marks a fraction that HBM alone could not deliver
+    (> 0.9 of the 8 TB/s spec, whose measured copy ceiling is 6.3 TB/s): the caches served part of the bytes that were priced."""
     if not rl:
         return None
     b = rl["best"]
-    out = {kk: b[kk] for kk in ("bound", "achieved", "peak", "unit")}
-    if b["frac"] >= 1.0:
-        out["algorithmic_frac"] = b["frac"]
-        out["frac"] = None
-        out["frac_note"] = "algorithmic bytes / time exceeds the peak (cache-served gathers): see roofline.frac (PMC traffic) for the dominant kernel"
-    else:
-        out["frac"] = b["frac"]
+    out = {kk: b[kk] for kk in ("bound", "achieved", "peak", "unit", "frac")}
+    out["cache_served"] = bool(b["bound"] == "hbm" and b["frac"] > CACHE_SERVED_ABOVE)
     return out
+
+
+def roofline_block(rl, kernel_name, dom_ms, dom_nnz, traffic, traffic_src, l2_hits):
+    """The `roofline` object of the JSON line for the dominant kernel.  ONE definition, whatever the timing noise does (VERDICT r4 weak 7:
+    rounds 3-4 replaced `frac` by the PMC fraction whenever the algorithmic one reached 1.0, so two runs 1 % apart printed 0.995 and 0.876
+    for the same kernel):
+      frac          achieved / peak of the best-priced limiter (kernel_roofline) -- for the gathering families SURVEY 8(d)'s algorithmic
+                    bytes P x (12 + 8k) x updates / launch time / 8 TB/s.  It may pass 1 when L2 / the Infinity Cache serve part of the
+                    gathers; cache_served says so.
+      traffic_frac  what crossed the fabric (PMC: 2 x FETCH_SIZE + WRITE_SIZE of the kernel's launches) / launch time / 8 TB/s; None when
+                    no PMC pass ran."""
+    if not rl:
+        return None
+    best = rl["best"]
+    gbps = traffic / (dom_ms * 1e-3) / 1e9 if traffic and dom_ms > 0 else None
+    return {"bound": best["bound"], "kernel": kernel_name, "achieved": best["achieved"], "peak": best["peak"], "unit": best["unit"],
+            "frac": best["frac"], "cache_served": bool(best["bound"] == "hbm" and best["frac"] > CACHE_SERVED_ABOVE),
+            "traffic": traffic, "traffic_frac": gbps / HBM_PEAK_GBS if gbps is not None else None, "traffic_GBps": gbps, "traffic_source": traffic_src,
+            "per_launch": best["per_launch"], "per_launch_is": best["what"], "updates_per_launch": dom_nnz, "avg_launch_ms": dom_ms,
+            "candidates": [{kk: c[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "what")} for c in rl["candidates"]],
+            "survey_8d_algorithmic_GBps": rl["algorithmic_GBps"], "algorithmic_frac": rl["algorithmic_GBps"] / HBM_PEAK_GBS, "l2": l2_hits,
+            "frac_is": ("achieved / peak of the limiter named in `bound` (per_launch_is; the largest fraction among `candidates`), the same "
+                        "definition in every run; cache_served = above %.1f of the HBM spec, which HBM alone cannot deliver (6.29 TB/s measured "
+                        "copy ceiling): L2 / Infinity Cache hits serve part of it (l2.hit_rate); traffic_frac = PMC bytes across the fabric / launch "
+                        "time / HBM peak; algorithmic_frac = SURVEY 8(d) bytes at P = 2 / launch time / HBM peak (above 1 for families that "
+                        "re-use the opposing vectors on chip); durations are HIP events on the launch stream around every sweep of the timed "
+                        "region" % CACHE_SERVED_ABOVE)}
 
 
 def family_step_bytes(family, nnz, nseg, nopp, k, ld, hbm_floor=False):
@@ -1058,35 +1084,7 @@ def main():
                     traffic_src += " (row and column sweeps run the same instantiation here: the mean is over both)"
             except Exception as e:  # the bench line must survive a profiler problem
                 traffic, traffic_src = None, f"PMC pass failed: {e!r}"
-        best = rl["best"] if rl else None
-        roof = None
-        if best:
-            roof = {"bound": best["bound"], "kernel": kname[0], "achieved": best["achieved"], "peak": best["peak"], "unit": best["unit"],
-                    "frac": best["frac"], "traffic": traffic, "traffic_source": traffic_src,
-                    "per_launch": best["per_launch"], "per_launch_is": best["what"], "updates_per_launch": dom_nnz,
-                    "avg_launch_ms": dom_ms, "candidates": [{kk: c[kk] for kk in ("bound", "achieved", "peak", "unit", "frac", "what")} for c in rl["candidates"]],
-                    "survey_8d_algorithmic_GBps": rl["algorithmic_GBps"],
-                    "traffic_GBps": traffic / (dom_ms * 1e-3) / 1e9 if traffic and dom_ms > 0 else None,
-                    "traffic_frac_of_hbm_peak": traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if traffic and dom_ms > 0 else None,
-                    "note": "frac = the largest achieved/peak among the limiters that apply to this kernel family (candidates); "
-                            "durations are HIP events on the launch stream around every sweep of the timed region"}
-            roof["l2"] = l2_hits
-            if roof["frac"] >= 1.0:
-                # SURVEY 8(d)'s byte count prices every k-vector gather as HBM traffic; a family that keeps the window being read on chip
-                # (phase-aligned passes: L2 + Infinity Cache) delivers more "algorithmic" bytes per second than HBM has.  That is no
-                # roofline fraction: `frac` is then what actually crossed the fabric (PMC traffic: L2 misses, Infinity-Cache hits
-                # included) over the HBM peak, and the algorithmic figure is kept beside it.
-                roof["algorithmic_frac"] = roof["frac"]
-                roof["algorithmic_achieved"] = roof["achieved"]
-                if roof["traffic_frac_of_hbm_peak"] is not None:
-                    roof["frac"] = roof["traffic_frac_of_hbm_peak"]
-                    roof["achieved"] = roof["traffic_GBps"]
-                    roof["frac_is"] = ("PMC traffic of the dominant kernel (2 x FETCH_SIZE + WRITE_SIZE: what crossed the fabric, Infinity-Cache hits "
-                                       "included) / launch time / HBM peak -- the SURVEY 8(d) algorithmic bytes (algorithmic_frac) exceed the peak "
-                                       "because L2 serves part of the gathers (l2.hit_rate)")
-                else:
-                    roof["frac"] = None
-                    roof["frac_is"] = "the algorithmic fraction passed 1 (cache-served gathers) and no PMC traffic was collected to replace it: unpriced"
+        roof = roofline_block(rl, kname[0], dom_ms, dom_nnz, traffic, traffic_src, l2_hits)
         out = {
             "metric": "observed-entry updates/sec", "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,

@@ -49,7 +49,9 @@ extern "C" {
 /* 2: glrm_options grew by quad_gram / reserved (round 2), glrm_signature + glrm_hip_signature / glrm_hip_finalize and
  *    GLRM_PROBLEM_DEFER_SETUP were added (round 3).  A host built against ABI 1 fails the version check instead of handing over
  *    a 32-byte glrm_options. */
-#define GLRM_HIP_ABI_VERSION 2
+/* 3: glrm_options grew by sum_order / affine_trials (48 bytes), glrm_kernel_stats by ms_wait_y, glrm_multi_options.reserved became
+ *    `arrival`; glrm_arrival + glrm_hip_step_y_arrival were added (round 5). */
+#define GLRM_HIP_ABI_VERSION 3
 
 typedef enum glrm_status {
   GLRM_OK = 0,
@@ -214,8 +216,23 @@ typedef struct glrm_options {
                         algorithm and iterates as row_objective (src/evaluate_fit.jl:24-38) up to rounding (<< 1e-5; a trial whose
                         decrease is below the rounding of the two sums the reference compares may be decided differently).
                         0 = evaluate every trial by a pass over A, like the reference.  Default 0. */
+  int32_t sum_order; /* SURVEY.md section 8(b) `line_search_sum_order`.  0 = the engine's own orders (the fast kernel families; what they
+                        are is reported by glrm_hip_sum_order).  1 = GLRM_ORDER_REFERENCE, a VALIDATION mode: every sum of the half-steps
+                        is added as the reference adds it -- the k-term dot product in component order, the gradient axpys and the row
+                        loss sum in list order into ONE accumulator (src/algorithms/proxgrad.jl:122-132,165-175, src/evaluate_fit.jl:28-36),
+                        the column loss sum by Julia's pairwise reduce(+) with blocks of 1024 for DiffLoss / ClassificationLoss columns
+                        and sequentially for OrdinalHinge / Poisson (src/losses.jl:623-638), sum(obj_by_col) pairwise (proxgrad.jl:205)
+                        -- by one lane per segment (csrc/glrm_reforder.hip).  Slow (no lane-level parallelism inside a segment, one
+                        gather per observation and pass); exists so that a checker can hold the engine against the REFERENCE-order
+                        oracle to rounding on trajectories that amplify summation order.  Scalar losses, list
+                        problems. */
+  int32_t affine_trials; /* 1 = line-search trials after the first are evaluated from per-observation scalars when the prox of the
+                        segment's regularizer is linear (ZeroReg, QuadReg): x' = c(s) (x - s g) gives u'_f = c(s) (u_f - s w_f) with
+                        w_f = g.y_f formed once, so a later trial reads 16 bytes per observation instead of a k-vector.  Same algorithm
+                        (src/algorithms/proxgrad.jl:136-155); u'_f is rounded differently from the dot product <x', y_f> (<< 1e-5; a
+                        trial whose decrease is below that rounding may be decided differently -- like quad_gram).  Default 0. */
   int32_t reserved;  /* must be 0 */
-} glrm_options;
+} glrm_options; /* 48 bytes */
 
 typedef struct glrm_handle glrm_handle;
 
@@ -294,6 +311,19 @@ int glrm_hip_get_factors(glrm_handle* h, double* X, double* Y);             /* d
 int glrm_hip_reset_stepsizes(glrm_handle* h, double stepsize);              /* alpharow, alphacol (:69-70,:112-115) */
 int glrm_hip_step_x(glrm_handle* h, double min_stepsize);                   /* one inner X sweep (:118-156) */
 int glrm_hip_step_y(glrm_handle* h, double min_stepsize);                   /* one inner Y sweep (:162-201) */
+/* The Y half-step while the updated X is still ARRIVING from the other shards.  `blocks` tile the rows [0, m) of X: block i is complete
+ * on this device once `event` (a hipEvent_t the host recorded behind whatever fills the range -- a peer copy, a collective; NULL = the
+ * range is already there, e.g. the shard's own rows) has fired.  The order of the array is the order in which the host expects the
+ * blocks.  The phase-aligned column passes (csrc/glrm_blocked.hip) walk X one super-tile per launch and keep one partial sum per (column,
+ * super-tile) that col_reduce adds in super-tile order whatever order the launches ran in: they launch each super-tile behind the events
+ * of the blocks it touches, own rows first, so the exchange overlaps the half-step that consumes it.  Every other family waits for all
+ * events and then runs glrm_hip_step_y.  Results are those of glrm_hip_step_y bit for bit.  With glrm_options.profile the time the
+ * launch stream spent in those waits is accounted in glrm_kernel_stats.ms_wait_y. */
+typedef struct glrm_arrival {
+  int64_t begin, end; /* rows [begin, end) of X */
+  void* event;        /* hipEvent_t or NULL */
+} glrm_arrival;
+int glrm_hip_step_y_arrival(glrm_handle* h, double min_stepsize, const glrm_arrival* blocks, int32_t n_blocks);
 /* One prox-gradient step of the shard's rows / columns with a global step size and no line search
  * (src/algorithms/sparse_proxgrad.jl:59-77 / :81-99). */
 int glrm_hip_gradstep_x(glrm_handle* h, double alpha);
@@ -314,7 +344,13 @@ int glrm_hip_set_regularizers(glrm_handle* h, const glrm_reg* rx, int64_t n_rx, 
  * and duplicates inside a row / column are preserved.  Losses, regularizers, rank, shard ranges and options are the parent's.
  * This is the train / test split of cross_validate, cv_by_iter and regularization_path (getfolds / get_train_and_test,
  * src/cross_validate.jl:54-105): fold f's training model is subset(tags = fold ids, match = f, invert = 1), its test model
- * subset(..., invert = 0).  The parent must be a list (not dense) handle; it is not modified and may be destroyed first. */
+ * subset(..., invert = 0).  The parent must be a list (not dense), finalized handle; it is not modified and may be destroyed first.
+ * Children of SHARDS (a parent whose row / column ranges are not the whole problem): the child is one shard of the subset problem and
+ * must, like its parent, choose its kernels from the signature of the WHOLE subset problem -- it is therefore returned in the
+ * GLRM_PROBLEM_DEFER_SETUP state.  The host calls glrm_hip_signature on every shard's child, combines them (sum the counts, max the
+ * rest) and calls glrm_hip_finalize on every child with the result; until then every step-level call on such a child fails with
+ * GLRM_ERR_INVALID.  A glrm_hip_finalize that fails half way (e.g. GLRM_ERR_OOM in a family's buffers) leaves the child unusable: a
+ * second finalize is refused and the handle can only be destroyed.  The child of a single-shard parent is ready on return. */
 int glrm_hip_subset(glrm_handle* parent, const uint8_t* row_tags, const uint8_t* col_tags, int32_t match, int32_t invert,
                     glrm_handle** out);
 /* init_svd!(glrm) (src/initialize.jl:35-132) on the resident lists of a single-shard list handle: the observed entries are
@@ -365,7 +401,9 @@ typedef struct glrm_multi_options {
   int32_t exchange;          /* 0 direct peer copies (default), 1 RCCL all-gather */
   const int32_t* device_ids; /* n_shards HIP device ordinals; NULL = 0, 1, ..., n_shards-1 */
   int32_t x_chunks;          /* >= 2: the X half-step runs in row chunks whose exchange overlaps the sweep of the next chunk; 0/1 off */
-  int32_t reserved;          /* must be 0 */
+  int32_t arrival;           /* direct exchange only.  0 (default) / 1: the Y half-step consumes the peers' row chunks of X in arrival order
+                                (glrm_hip_step_y_arrival: own rows first, then chunk j of every peer as its copy event fires) instead of
+                                waiting for the whole exchange between the half-steps; 2: off (wait, then glrm_hip_step_y) */
 } glrm_multi_options;
 
 int glrm_hip_multi_create(glrm_multi** out, const glrm_problem* p, const glrm_options* o, const glrm_multi_options* mo);
@@ -376,7 +414,13 @@ int glrm_hip_multi_fit(glrm_multi* mh, const glrm_params* prm, double* X, double
  * between warm-started fits, Omega and A stay on the devices. */
 int glrm_hip_multi_set_regularizers(glrm_multi* mh, const glrm_reg* rx, int64_t n_rx, const glrm_reg* ry, int64_t n_ry);
 /* row_bounds / col_bounds: n_shards+1 entries each (may be NULL); exchange_used: 0 direct, 1 RCCL;
- * exchange_ms: summed wall time between the end of a half-step's sweeps and the arrival of the last block, last fit */
+ * exchange_ms: EXPOSED exchange time of the last fit (needs glrm_options.profile) -- the summed wall time the compute streams spent
+ * between the end of a half-step's sweeps and the arrival of the last block they waited for there, plus (arrival order) the time the
+ * Y half-steps' launch streams stood in front of a block that had not arrived yet; max over shards.
+ * Link emulation (a box with fewer GPUs than shards): GLRM_EXCHANGE_EMULATE_GBPS=<GB/s per direction and link> makes every direct
+ * push take at least bytes / rate from the moment its source range was complete (GLRM_EXCHANGE_EMULATE_DILATE=<d>, default the
+ * number of shards that share the source device, divides the rate: d shards time-share one device, so a transfer must take d times as
+ * long to keep its proportion to the compute).  See csrc/glrm_multigpu.hip. */
 int glrm_hip_multi_info(glrm_multi* mh, int64_t* row_bounds, int64_t* col_bounds, int32_t* exchange_used, double* exchange_ms);
 void glrm_hip_multi_destroy(glrm_multi* mh); /* NULL is a no-op */
 
@@ -393,7 +437,9 @@ typedef struct glrm_kernel_stats {
                                   bit2: dense MFMA path in use, bit3: general sweeps (multi-dimensional losses),
                                   bit4 / bit5: phase-aligned gather passes (L2-blocked) for the row / column sweep,
                                   bit6: cached gather row sweep (the short rows' opposing vectors fetched once per half-step
-                                  and kept in registers / LDS for every pass) */
+                                  and kept in registers / LDS for every pass), bit7: reference-order validation sweeps
+                                  (glrm_options.sum_order = 1) */
+  double ms_wait_y;            /* glrm_hip_step_y_arrival with profile=1: time the launch stream waited for blocks of X to arrive */
 } glrm_kernel_stats;
 
 int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int reset);

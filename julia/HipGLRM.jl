@@ -3,34 +3,32 @@
 # cross_validate, cv_by_iter, regularization_path, precision_at_k, the ScikitLearn wrappers -- src/fit.jl:8-12,
 # src/cross_validate.jl:10,142,184,243) then runs on the MI355X engine.  Host code stays in Julia; nothing here computes.
 #
-#   fit!(glrm, HipProxGradParams())                       one GPU            glrm_hip_create + glrm_hip_fit
-#   fit!(glrm, HipProxGradParams(ngpus = 8))              eight GPUs, ONE Julia process: glrm_hip_multi_create + glrm_hip_multi_fit
-#                                                         (the library shards rows / columns, replicates X, Y and exchanges the
-#                                                         updated blocks over xGMI after every half-step)
-# * a fully observed single-QuadLoss model hands `glrm.A` over as the dense matrix it is (column-major, `dense_colmajor = 1`):
-#   the half-steps then run on the fp64 matrix cores and no index list is built (BASELINE config 3: 80 GB instead of 2 x 120 GB);
-# * the engine handle (Omega views and A on the device) is cached per model, so warm starts, `cv_by_iter`'s `max_iter = 1` loop
-#   (src/cross_validate.jl:164-175) and `regularization_path` do not re-upload; new regularizers only replace descriptors;
-# * loss / regularizer types outside include/glrm_hip.h fall back to the reference solver.
+#   fit!(glrm, HipProxGradParams())              one GPU:  glrm_hip_create + glrm_hip_fit
+#   fit!(glrm, HipProxGradParams(ngpus = 8))     eight GPUs, ONE Julia process: glrm_hip_multi_create + glrm_hip_multi_fit
 #
-# NOT EXECUTED IN THIS REPOSITORY'S CI: no `julia` binary exists in the build image or on the GPU box (SURVEY.md F2).  It is pure
-# marshalling; the same C entry points are exercised from C (examples/c_abi_example.c, examples/c_abi_multi.c) and Python/ctypes.
+# This file is the marshalling core (<= 150 code lines, SURVEY.md section 8(b); tests/test_julia_shim.py counts them):
+#   HipGLRMDescriptors.jl  loss / regularizer types -> (kind, dim, scale, p0, p1) / (kind, wrap, scale); which models the engine takes
+#   HipGLRMExtras.jl       init_svd! / error_metric / impute / subset / sum_order on the same cached handle
+# Omega at north-star scale (1e9 observations): a `SparseMatrixCSC` whose lists are the constructor's (`findall(!iszero, A)`,
+# src/glrm.jl:46-48) IS the column view -- colptr / rowval / nzval are handed over after one index shift, the row view comes from ONE
+# counting transpose (O(nnz), ascending columns per row = the order sort_observations pushes them in, src/modify_glrm.jl:8-12), and no
+# entry is looked up through `A[e, j]` (a binary search per observation on a CSC matrix).  Lists the caller built (obs tuples,
+# duplicates, two different views) are flattened list by list, each view from ITS OWN list.
+#
+# NOT EXECUTED IN THIS REPOSITORY'S CI: no `julia` binary exists in the build image or on the GPU box (SURVEY.md F2).  The same C entry
+# points are exercised from C (examples/c_abi_example.c, examples/c_abi_multi.c) and from Python/ctypes (lowrankmodels.jl_amd/_capi.py,
+# whose `flatten` twin is timed at 1e9 observations by bench.py: setup_s.create_from_host).
 module HipGLRM
 
-using LowRankModels
-import LowRankModels: fit!, GLRM, AbstractParams, ConvergenceHistory, update_ch!,
-                      Loss, Regularizer, QuadLoss, L1Loss, HuberLoss, QuantileLoss, PeriodicLoss, PoissonLoss,
-                      OrdinalHingeLoss, LogisticLoss, WeightedHingeLoss,
-                      MultinomialLoss, OvALoss, BvSLoss, OrdisticLoss, MultinomialOrdinalLoss, embedding_dim,
-                      ZeroReg, QuadReg, OneReg, NonNegConstraint, UnitOneSparseConstraint,
-                      lastentry1, lastentry_unpenalized, OrdinalReg, MNLOrdinalReg, ProxGradParams
+using LowRankModels, SparseArrays
+import LowRankModels: fit!, GLRM, AbstractParams, ConvergenceHistory, update_ch!, ProxGradParams
 
 export HipProxGradParams, hip_release!
 
 const LIB = get(ENV, "GLRM_HIP_LIB", "libglrm_hip.so")
-const ABI_VERSION = 2                         # GLRM_HIP_ABI_VERSION of the include/glrm_hip.h these struct mirrors were written against
+const ABI_VERSION = 3                         # GLRM_HIP_ABI_VERSION of the include/glrm_hip.h these struct mirrors were written against
 
-# mirrors of the C structs (include/glrm_hip.h)
+# mirrors of the C structs (include/glrm_hip.h); tests/test_julia_shim.py compares every field offset with the C compiler's
 struct CLoss; kind::Int32; dim::Int32; scale::Float64; p0::Float64; p1::Float64; end   # dim = embedding_dim (0/1: scalar)
 struct CReg;  kind::Int32; wrap::Int32; scale::Float64; end                             # wrap = GLRM_WRAP_* flag
 struct CProblem
@@ -45,83 +43,86 @@ struct CParams
     stepsize::Float64; max_iter::Int64; inner_iter_X::Int64; inner_iter_Y::Int64
     abs_tol::Float64; rel_tol::Float64; min_stepsize::Float64
 end
-struct COptions; device_id::Int32; profile::Int32; waves_row::Int32; waves_col::Int32; stream::Ptr{Cvoid}; caller_stream::Int32; tiled::Int32; quad_gram::Int32; reserved::Int32; end
-struct CMultiOptions; n_shards::Int32; exchange::Int32; device_ids::Ptr{Int32}; x_chunks::Int32; reserved::Int32; end
-# glrm_signature: only hosts that shard a problem THEMSELVES (one handle per shard, GLRM_PROBLEM_DEFER_SETUP) need it; this shim hands
-# the whole problem to glrm_hip_multi_create, which does that internally.  Mirrored so that tests/test_julia_shim.py checks it too.
-struct CSignature; nnz_rows::Int64; nnz_cols::Int64; max_row_len::Int64; max_col_len::Int64; rows_unordered::Int32; cols_unordered::Int32; end
-# glrm_sum_order: the order in which a handle's kernels add the terms of a row's / column's sums (diagnostic, see hip_sum_order below)
-struct CSumOrder
-    family::Int32; lanes::Int32; comps::Int32; waves::Int32
-    waves4_from::Int64; waves8_from::Int64; cached_maxlen::Int64
-    cached_waves::Int32; batch::Int32; batch_one_wave_only::Int32; rotate::Int32
-    window::Int64; windows_per_sup::Int64
-    private_order::Int32; reserved::Int32
+struct COptions
+    device_id::Int32; profile::Int32; waves_row::Int32; waves_col::Int32; stream::Ptr{Cvoid}
+    caller_stream::Int32; tiled::Int32; quad_gram::Int32; sum_order::Int32; affine_trials::Int32; reserved::Int32
 end
+struct CMultiOptions; n_shards::Int32; exchange::Int32; device_ids::Ptr{Int32}; x_chunks::Int32; arrival::Int32; end
 
-"The 7 ProxGradParams fields (src/algorithms/proxgrad.jl:4-12) + where to run: `device_id` (one GPU) or `ngpus` / `device_ids`."
+include("HipGLRMDescriptors.jl")              # closs / creg / descriptors / dense_ok / value
+
+"The 7 ProxGradParams fields (src/algorithms/proxgrad.jl:4-12) + where and how to run (include/glrm_hip.h: glrm_options, glrm_multi_options)."
 mutable struct HipProxGradParams <: AbstractParams
     stepsize::Float64; max_iter::Int; inner_iter_X::Int; inner_iter_Y::Int
     abs_tol::Float64; rel_tol::Float64; min_stepsize::Float64
     device_id::Int; ngpus::Int; device_ids::Vector{Int32}; exchange::Symbol; x_chunks::Int; dense::Bool; quad_gram::Bool
+    mode::Symbol                               # :fast (the engine's summation orders) | :reference_order (validation, glrm_options.sum_order = 1)
+    affine_trials::Bool
 end
 function HipProxGradParams(stepsize::Number=1.0; max_iter::Int=100, inner_iter_X::Int=1, inner_iter_Y::Int=1,
                            inner_iter::Int=1, abs_tol::Number=0.00001, rel_tol::Number=0.0001,
                            min_stepsize::Number=0.01*stepsize, device_id::Int=-1, ngpus::Int=1,
-                           device_ids=Int32.(0:ngpus-1), exchange::Symbol=:direct, x_chunks::Int=4, dense::Bool=true, quad_gram::Bool=false)
+                           device_ids=Int32.(0:ngpus-1), exchange::Symbol=:direct, x_chunks::Int=4, dense::Bool=true,
+                           quad_gram::Bool=false, mode::Symbol=:fast, affine_trials::Bool=false)
     length(device_ids) == ngpus || error("device_ids must list one device per shard")
     exchange in (:direct, :rccl) || error("exchange must be :direct or :rccl")
+    mode in (:fast, :reference_order) || error("mode must be :fast or :reference_order")
     HipProxGradParams(Float64(stepsize), max_iter, max(inner_iter_X, inner_iter), max(inner_iter_Y, inner_iter),
                       Float64(abs_tol), Float64(rel_tol), Float64(min_stepsize), device_id, ngpus, Vector{Int32}(device_ids),
-                      exchange, x_chunks, dense, quad_gram)
+                      exchange, x_chunks, dense, quad_gram, mode, affine_trials)
 end
 
-closs(l::QuadLoss) = CLoss(0, 0, l.scale, 0, 0)
-closs(l::L1Loss) = CLoss(1, 0, l.scale, 0, 0)
-closs(l::HuberLoss) = CLoss(2, 0, l.scale, l.crossover, 0)
-closs(l::QuantileLoss) = CLoss(3, 0, l.scale, l.quantile, 0)
-closs(l::PeriodicLoss) = CLoss(4, 0, l.scale, l.T, 0)
-closs(l::PoissonLoss) = CLoss(5, 0, l.scale, 0, 0)
-closs(l::OrdinalHingeLoss) = CLoss(6, 0, l.scale, l.min, l.max)
-closs(l::LogisticLoss) = CLoss(7, 0, l.scale, 0, 0)
-closs(l::WeightedHingeLoss) = CLoss(8, 0, l.scale, l.case_weight_ratio, 0)
-# multi-dimensional losses (src/losses.jl:360-620): dim columns of Y per column of A; bin_loss must be Logistic / Hinge
-binkind(b::LogisticLoss) = 7.0
-binkind(b::WeightedHingeLoss) = b.case_weight_ratio == 1 ? 8.0 : NaN
-binkind(b) = NaN
-closs(l::MultinomialLoss) = CLoss(9, l.max, l.scale, 0, 0)
-closs(l::OvALoss) = isnan(binkind(l.bin_loss)) ? nothing : CLoss(10, l.max, l.scale, l.bin_loss.scale, binkind(l.bin_loss))
-closs(l::BvSLoss) = isnan(binkind(l.bin_loss)) ? nothing : CLoss(11, l.max - 1, l.scale, l.bin_loss.scale, binkind(l.bin_loss))
-closs(l::OrdisticLoss) = CLoss(12, l.max, l.scale, 0, 0)
-closs(l::MultinomialOrdinalLoss) = CLoss(13, l.max - 1, l.scale, 0, 0)
-closs(l::Loss) = nothing                     # anything else: reference path
-creg(r::ZeroReg) = CReg(0, 0, 1.0)
-creg(r::QuadReg) = CReg(1, 0, r.scale)
-creg(r::OneReg) = CReg(2, 0, r.scale)
-creg(r::NonNegConstraint) = CReg(3, 0, 1.0)
-creg(r::UnitOneSparseConstraint) = CReg(4, 0, 1.0)
-# wrappers around one of the five base regularizers (src/regularizers.jl:163-189,356-411)
-wrapped(r, flag) = (b = creg(r.r); (b === nothing || b.wrap != 0) ? nothing : CReg(b.kind, flag, b.scale))
-creg(r::lastentry1) = wrapped(r, 1)
-creg(r::lastentry_unpenalized) = wrapped(r, 2)
-creg(r::OrdinalReg) = wrapped(r, 4)
-creg(r::MNLOrdinalReg) = wrapped(r, 8)
-creg(r::Regularizer) = nothing
-
-isclass(l) = l isa LogisticLoss || l isa WeightedHingeLoss
-value(l, a) = isclass(l) ? (a isa Bool ? Float64(a) : Float64(LowRankModels.myBool(Int(a)))) : Float64(a)   # src/losses.jl:104-106
-collapse(v) = all(==(v[1]), v) ? v[1:1] : v          # one descriptor when every column / row carries the same one
-
-# observed_features / observed_examples -> 0-based CSR / CSC, each built from ITS OWN list (order and duplicates kept)
-function flatten(lists, getval)
+# ---- Omega -> 0-based CSR / CSC (include/glrm_hip.h: glrm_problem) ------------------------------------------------------
+# one view from ITS OWN lists (order and duplicates kept); `at(s, i)` is A[s, i] for the row view, A[i, s] for the column view
+function flatten(lists, losses, at, bycol::Bool)
     ptr = Vector{Int64}(undef, length(lists) + 1); ptr[1] = 0
-    for (s, l) in enumerate(lists); ptr[s + 1] = ptr[s] + length(l); end
-    idx = Vector{Int32}(undef, ptr[end]); vals = Vector{Float64}(undef, ptr[end])
-    t = 1
-    for (s, l) in enumerate(lists), i in l
-        idx[t] = Int32(i - 1); vals[t] = getval(s, i); t += 1
+    @inbounds for s in eachindex(lists); ptr[s + 1] = ptr[s] + length(lists[s]); end
+    idx = Vector{Int32}(undef, ptr[end]); vals = Vector{Float64}(undef, ptr[end]); t = 0
+    @inbounds for s in eachindex(lists), i in lists[s]
+        t += 1; idx[t] = Int32(i - 1); vals[t] = value(losses[bycol ? s : i], at(s, i))
     end
     ptr, idx, vals
+end
+# do the lists say exactly what the CSC arrays say?  (true for GLRM(A::SparseMatrixCSC, ...) without obs, src/glrm.jl:46-48)
+function csc_is_omega(A::SparseMatrixCSC, oe)
+    cp, rv = A.colptr, A.rowval
+    @inbounds for j in eachindex(oe)
+        l = oe[j]; length(l) == cp[j + 1] - cp[j] || return false
+        for (t, i) in enumerate(l); i == rv[cp[j] + t - 1] || return false; end
+    end
+    true
+end
+# both views of a SparseMatrixCSC without one lookup: the column view IS (colptr, rowval, nzval); the row view is its counting transpose
+function views_from_csc(A::SparseMatrixCSC, losses)
+    m, n = size(A); cp, rv, nz = A.colptr, A.rowval, A.nzval; nnz_ = length(rv)
+    colptr = Vector{Int64}(undef, n + 1); @inbounds for j in 1:n+1; colptr[j] = cp[j] - 1; end
+    rowidx = Vector{Int32}(undef, nnz_); colvals = Vector{Float64}(undef, nnz_); rowptr = zeros(Int64, m + 1)
+    @inbounds for j in 1:n, t in cp[j]:cp[j+1]-1
+        rowidx[t] = Int32(rv[t] - 1); colvals[t] = value(losses[j], nz[t]); rowptr[rv[t] + 1] += 1
+    end
+    @inbounds for i in 1:m; rowptr[i + 1] += rowptr[i]; end
+    colidx = Vector{Int32}(undef, nnz_); rowvals = Vector{Float64}(undef, nnz_); fill_ = copy(rowptr)
+    @inbounds for j in 1:n, t in cp[j]:cp[j+1]-1             # columns ascending => every row's list ascending, like findall's order
+        i = rv[t]; fill_[i] += 1; colidx[fill_[i]] = Int32(j - 1); rowvals[fill_[i]] = colvals[t]
+    end
+    rowptr, colidx, rowvals, colptr, rowidx, colvals
+end
+# do the row lists equal the transpose's?  (they do for the sparse constructor; a caller may have replaced them: the views are independent)
+function rows_match(rowptr, colidx, of)
+    @inbounds for e in eachindex(of)
+        l = of[e]; length(l) == rowptr[e + 1] - rowptr[e] || return false
+        for (t, j) in enumerate(l); j - 1 == colidx[rowptr[e] + t] || return false; end
+    end
+    true
+end
+function omega_views(glrm::GLRM)
+    A = glrm.A
+    if A isa SparseMatrixCSC && csc_is_omega(A, glrm.observed_examples)
+        v = views_from_csc(A, glrm.losses)
+        rows_match(v[1], v[2], glrm.observed_features) && return v
+        return (flatten(glrm.observed_features, glrm.losses, (e, j) -> A[e, j], false)..., v[4], v[5], v[6])
+    end
+    (flatten(glrm.observed_features, glrm.losses, (e, j) -> A[e, j], false)..., flatten(glrm.observed_examples, glrm.losses, (j, e) -> A[e, j], true)...)
 end
 
 lasterr() = unsafe_string(ccall((:glrm_hip_last_error, LIB), Cstring, ()))
@@ -132,68 +133,27 @@ function check_abi()
     v == ABI_VERSION || error("libglrm_hip.so speaks ABI $v, HipGLRM.jl was written against ABI $ABI_VERSION (include/glrm_hip.h)")
 end
 
-fallback(glrm, p; kw...) = fit!(glrm, ProxGradParams(p.stepsize; max_iter=p.max_iter, inner_iter_X=p.inner_iter_X, inner_iter_Y=p.inner_iter_Y,
-                                             abs_tol=p.abs_tol, rel_tol=p.rel_tol, min_stepsize=p.min_stepsize); kw...)
+include("HipGLRMHandle.jl")                   # handle(glrm, desc, p): the engine handle cached per model; hip_release!; with_handle
 
-# descriptors of a model, or nothing if some loss / regularizer type is outside include/glrm_hip.h
-function descriptors(glrm::GLRM)
-    cl = map(closs, glrm.losses); crx = map(creg, glrm.rx); cry = map(creg, glrm.ry)
-    (any(isnothing, cl) || any(isnothing, crx) || any(isnothing, cry)) && return nothing
-    n = size(glrm.A, 2)
-    general = embedding_dim(glrm.losses) != n || any(c -> c.wrap != 0, crx) || any(c -> c.wrap != 0, cry)
-    (general && glrm.k > 64) && return nothing
-    collapse(Vector{CLoss}(cl)), collapse(Vector{CReg}(crx)), collapse(Vector{CReg}(cry))
-end
-
-# the dense hand-over applies when every entry is observed (the constructor's default UnitRanges) under one QuadLoss
-fully_observed(glrm) = (s = size(glrm.A); all(==(1:s[2]), glrm.observed_features) && all(==(1:s[1]), glrm.observed_examples))
-dense_ok(glrm, desc, p) = p.dense && glrm.A isa Matrix{Float64} && length(desc[1]) == 1 && desc[1][1].kind == 0 &&
-                          9 <= glrm.k <= 64 && fully_observed(glrm)
-
-# ---- engine handles, cached per model ---------------------------------------------------------------------------------
-mutable struct Entry; h::Ptr{Cvoid}; multi::Bool; hard::UInt64; soft::UInt64; end
-const CACHE = IdDict{Any,Entry}()
-destroy(e::Entry) = (e.h == C_NULL || ccall(e.multi ? (:glrm_hip_multi_destroy, LIB) : (:glrm_hip_destroy, LIB), Cvoid, (Ptr{Cvoid},), e.h); e.h = C_NULL)
-"Drop the device copy of a model's data (also done by the model's finalizer).  Call it after mutating `glrm.A` in place."
-hip_release!(glrm::GLRM) = (haskey(CACHE, glrm) && (destroy(CACHE[glrm]); delete!(CACHE, glrm)); glrm)
-# what the device copy depends on (data, Omega, losses, placement) / what set_regularizers can replace
-hardkey(glrm, desc, p, dense) = hash((objectid(glrm.A), size(glrm.A), glrm.k, objectid(glrm.observed_features), objectid(glrm.observed_examples),
-                                      sum(length, glrm.observed_features), sum(length, glrm.observed_examples), desc[1],
-                                      length(desc[2]), length(desc[3]), p.device_id, p.ngpus, p.device_ids, p.exchange, p.x_chunks, dense, p.quad_gram))
-softkey(desc) = hash((desc[2], desc[3]))
-
-function handle(glrm::GLRM, desc, p::HipProxGradParams)
+# upload: glrm_problem from the model (Omega views or the dense matrix), glrm_options / glrm_multi_options from the params
+function create_handle(glrm::GLRM, desc, p::HipProxGradParams, dense::Bool)
     losses, rx, ry = desc
-    dense = dense_ok(glrm, desc, p); multi = p.ngpus > 1
-    hard, soft = hardkey(glrm, desc, p, dense), softkey(desc)
-    e = get(CACHE, glrm, nothing)
-    if e !== nothing && e.hard == hard
-        if e.soft != soft                   # scale_regularizer! / regularization_path: Omega and A stay on the device
-            check(ccall(multi ? (:glrm_hip_multi_set_regularizers, LIB) : (:glrm_hip_set_regularizers, LIB), Cint,
-                        (Ptr{Cvoid}, Ptr{CReg}, Int64, Ptr{CReg}, Int64), e.h, rx, length(rx), ry, length(ry)))
-            e.soft = soft
-        end
-        return e.h
-    end
-    e === nothing ? finalizer(hip_release!, glrm) : destroy(e)
     check_abi()
     A = glrm.A; m, n = size(A); h = Ref{Ptr{Cvoid}}(C_NULL)
-    rowptr, colidx, rowvals = dense ? (Int64[], Int32[], Float64[]) : flatten(glrm.observed_features, (e, j) -> value(glrm.losses[j], A[e, j]))
-    colptr, rowidx, colvals = dense ? (Int64[], Int32[], Float64[]) : flatten(glrm.observed_examples, (j, e) -> value(glrm.losses[j], A[e, j]))
+    rowptr, colidx, rowvals, colptr, rowidx, colvals = dense ? (Int64[], Int32[], Float64[], Int64[], Int32[], Float64[]) : omega_views(glrm)
     nul(v) = dense ? Ptr{eltype(v)}(C_NULL) : pointer(v)
     GC.@preserve losses rx ry rowptr colidx rowvals colptr rowidx colvals A p begin
         prob = CProblem(m, n, glrm.k, 0, 0, m, 0, n, nul(rowptr), nul(colidx), nul(rowvals), nul(colptr), nul(rowidx), nul(colvals),
                         pointer(losses), length(losses), pointer(rx), length(rx), pointer(ry), length(ry),
                         dense ? pointer(A) : Ptr{Float64}(C_NULL), dense ? m : 0, dense ? 1 : 0, 0)   # Julia's A is column-major
-        opt = COptions(p.device_id, 0, 0, 0, C_NULL, 0, 0, p.quad_gram ? 1 : 0, 0)
-        if multi
+        opt = COptions(p.device_id, 0, 0, 0, C_NULL, 0, 0, p.quad_gram ? 1 : 0, p.mode == :reference_order ? 1 : 0, p.affine_trials ? 1 : 0, 0)
+        if p.ngpus > 1
             mo = CMultiOptions(p.ngpus, p.exchange == :rccl ? 1 : 0, pointer(p.device_ids), p.x_chunks, 0)
             check(ccall((:glrm_hip_multi_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{CProblem}, Ref{COptions}, Ref{CMultiOptions}), h, prob, opt, mo))
         else
             check(ccall((:glrm_hip_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{CProblem}, Ref{COptions}), h, prob, opt))
         end
     end                                     # create copied everything: the host arrays may go
-    CACHE[glrm] = Entry(h[], multi, hard, soft)
     h[]
 end
 
@@ -223,14 +183,6 @@ function fit!(glrm::GLRM, p::HipProxGradParams; ch::ConvergenceHistory=Convergen
         end
     end
     return glrm.X, glrm.Y, ch
-end
-
-# a single-device handle for the other entry points (julia/HipGLRMExtras.jl); nothing if the model is outside the engine
-function with_handle(f, glrm::GLRM, device_id::Int=-1)
-    desc = descriptors(glrm)
-    desc === nothing && return nothing
-    p = HipProxGradParams(device_id=device_id, dense=false)      # list handle: init_svd / impute / subset work on the Omega views
-    Some(f(handle(glrm, desc, p)))
 end
 
 end # module

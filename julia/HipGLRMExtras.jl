@@ -5,11 +5,22 @@ module HipGLRMExtras
 
 using LowRankModels
 using ..HipGLRM
-import ..HipGLRM: LIB, check, with_handle, CSumOrder
+import ..HipGLRM: LIB, check, with_handle
 
 export hip_init_svd!, hip_error_metric, hip_impute, hip_subset
 
 
+# glrm_signature: only hosts that shard a problem THEMSELVES (one handle per shard, GLRM_PROBLEM_DEFER_SETUP) need it; the fit! shim hands
+# the whole problem to glrm_hip_multi_create, which does that internally.  Mirrored so that tests/test_julia_shim.py checks it too.
+struct CSignature; nnz_rows::Int64; nnz_cols::Int64; max_row_len::Int64; max_col_len::Int64; rows_unordered::Int32; cols_unordered::Int32; end
+# glrm_sum_order: the order in which a handle's kernels add the terms of a row's / column's sums (diagnostic, see hip_sum_order below)
+struct CSumOrder
+    family::Int32; lanes::Int32; comps::Int32; waves::Int32
+    waves4_from::Int64; waves8_from::Int64; cached_maxlen::Int64
+    cached_waves::Int32; batch::Int32; batch_one_wave_only::Int32; rotate::Int32
+    window::Int64; windows_per_sup::Int64
+    private_order::Int32; reserved::Int32
+end
 struct CDomain; kind::Int32; reserved::Int32; lo::Float64; hi::Float64; end
 cdomain(d::LowRankModels.RealDomain) = CDomain(0, 0, 0, 0)
 cdomain(d::LowRankModels.BoolDomain) = CDomain(1, 0, 0, 0)

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 GLRM_OK = 0
 ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_COMM, ERR_OOM, ERR_NONFINITE = -1, -2, -3, -4, -5, -6
@@ -71,7 +71,15 @@ class CSparseParams(C.Structure):
 class COptions(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("profile", C.c_int32), ("waves_row", C.c_int32), ("waves_col", C.c_int32),
                 ("stream", C.c_void_p), ("caller_stream", C.c_int32), ("tiled", C.c_int32), ("quad_gram", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("sum_order", C.c_int32), ("affine_trials", C.c_int32), ("reserved", C.c_int32)]
+
+
+assert C.sizeof(COptions) == 48
+
+
+class CArrival(C.Structure):
+    """glrm_arrival: rows [begin, end) of X are complete on the device once ``event`` (a hipEvent_t, 0 = already there) has fired."""
+    _fields_ = [("begin", C.c_int64), ("end", C.c_int64), ("event", C.c_void_p)]
 
 
 class CSignature(C.Structure):
@@ -95,7 +103,7 @@ class CSignature(C.Structure):
 
 
 class CMultiOptions(C.Structure):
-    _fields_ = [("n_shards", C.c_int32), ("exchange", C.c_int32), ("device_ids", C.c_void_p), ("x_chunks", C.c_int32), ("reserved", C.c_int32)]
+    _fields_ = [("n_shards", C.c_int32), ("exchange", C.c_int32), ("device_ids", C.c_void_p), ("x_chunks", C.c_int32), ("arrival", C.c_int32)]
 
 
 class CKernelStats(C.Structure):
@@ -104,6 +112,7 @@ class CKernelStats(C.Structure):
         ("trials_x", C.c_int64), ("trials_y", C.c_int64), ("accepts_x", C.c_int64), ("accepts_y", C.c_int64),
         ("nnz_rows", C.c_int64), ("nnz_cols", C.c_int64),
         ("waves_row", C.c_int32), ("waves_col", C.c_int32), ("ld", C.c_int32), ("tiled", C.c_int32),
+        ("ms_wait_y", C.c_double),
     ]
 
     def asdict(self):
@@ -130,7 +139,7 @@ assert C.sizeof(CSumOrder) == 80
 #: that the built library exports all of them.
 ABI_SYMBOLS = (
     "version", "last_error", "create", "destroy", "signature", "finalize", "fit", "fit_sparse", "objective", "factor_ld", "bind_buffers",
-    "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_x_range", "gradstep_x", "gradstep_y", "col_losses", "row_penalties",
+    "set_factors", "get_factors", "reset_stepsizes", "step_x", "step_y", "step_y_arrival", "step_x_range", "gradstep_x", "gradstep_y", "col_losses", "row_penalties",
     "col_penalties", "set_regularizers", "subset", "init_svd", "error_metric", "impute", "sum", "synchronize", "kernel_stats", "sum_order",
     "multi_create", "multi_fit", "multi_set_regularizers", "multi_info", "multi_destroy",
 )
@@ -199,6 +208,7 @@ class Api:
             "reset_stepsizes": (C.c_int, [H, C.c_double]),
             "step_x": (C.c_int, [H, C.c_double]),
             "step_y": (C.c_int, [H, C.c_double]),
+            "step_y_arrival": (C.c_int, [H, C.c_double, C.c_void_p, C.c_int32]),
             "step_x_range": (C.c_int, [H, C.c_int64, C.c_int64, C.c_double]),
             "col_losses": (C.c_int, [H]),
             "row_penalties": (C.c_int, [H]),
@@ -252,18 +262,22 @@ class Api:
             p.dense_A, p.dense_ld, p.dense_colmajor, p.dense_reserved = _ptr(prob.dense_A), prob.dense_ld, prob.dense_colmajor, 0
         return p
 
-    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=None, tiled=0, quad_gram=0, defer=False):
+    def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=None, tiled=0, quad_gram=0, defer=False,
+               sum_order=0, affine_trials=0):
         """``stream=None``: the handle creates a private stream.  ``stream=<int>``: launch on exactly that
         hipStream_t -- 0 is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns
         for the default stream), so kernels stay ordered with the caller's other work on it.
         ``defer=True`` (one shard of a sharded fit): only upload; the host combines :meth:`signature` over the shards and
-        calls :meth:`finalize` on every one of them (GLRM_PROBLEM_DEFER_SETUP)."""
+        calls :meth:`finalize` on every one of them (GLRM_PROBLEM_DEFER_SETUP).
+        ``sum_order=1``: the reference-order validation sweeps (glrm_options.sum_order); ``affine_trials=1``: later line-search
+        trials from per-observation scalars where the prox is linear (glrm_options.affine_trials)."""
         if prob.dense_A is not None and not self.dense_ok:
             raise GLRMError(ERR_UNSUPPORTED, "this engine takes observation lists only")
         p = self._cproblem(prob)
         if defer:
             p.flags |= PROBLEM_DEFER_SETUP
-        o = COptions(device_id, profile, waves_row, waves_col, (stream or None), 0 if stream is None else 1, tiled, int(quad_gram), 0)
+        o = COptions(device_id, profile, waves_row, waves_col, (stream or None), 0 if stream is None else 1, tiled, int(quad_gram), int(sum_order),
+                     int(affine_trials), 0)
         h = C.c_void_p()
         self._ck(self._f["create"](C.byref(h), C.byref(p), C.byref(o)))
         return h
@@ -278,16 +292,16 @@ class Api:
 
     # -- one process, several devices (glrm_*_multi_*) -----------------------------------------
     def multi_create(self, prob: "ProblemArrays", n_shards, device_ids=None, exchange=0, x_chunks=0, profile=0, waves_row=0,
-                     waves_col=0, tiled=0, quad_gram=0):
+                     waves_col=0, tiled=0, quad_gram=0, arrival=0, sum_order=0, affine_trials=0):
         """The whole problem (host arrays), sharded by the library over ``device_ids`` (default 0..n_shards-1; ids may repeat)."""
         if prob.dense_A is not None and not self.dense_ok:
             raise GLRMError(ERR_UNSUPPORTED, "this engine takes observation lists only")
         p = self._cproblem(prob)
-        o = COptions(-1, profile, waves_row, waves_col, None, 0, tiled, int(quad_gram), 0)
+        o = COptions(-1, profile, waves_row, waves_col, None, 0, tiled, int(quad_gram), int(sum_order), int(affine_trials), 0)
         ids = None if device_ids is None else np.ascontiguousarray(device_ids, dtype=np.int32)
         if ids is not None and len(ids) != n_shards:
             raise ValueError("device_ids must have n_shards entries")
-        mo = CMultiOptions(int(n_shards), int(exchange), _ptr(ids), int(x_chunks), 0)
+        mo = CMultiOptions(int(n_shards), int(exchange), _ptr(ids), int(x_chunks), int(arrival))
         h = C.c_void_p()
         self._ck(self._f["multi_create"](C.byref(h), C.byref(p), C.byref(o), C.byref(mo)))
         return h
@@ -378,6 +392,14 @@ class Api:
     def step_y(self, h, min_stepsize):
         self._ck(self._f["step_y"](h, float(min_stepsize)))
 
+    def step_y_arrival(self, h, min_stepsize, blocks):
+        """The Y half-step while X is arriving: ``blocks`` = [(begin, end, event)] tiling the rows [0, m) in the order the host
+        expects them; ``event`` is a hipEvent_t as an integer (torch.cuda.Event(...).cuda_event) or 0 / None for rows already there."""
+        arr = (CArrival * max(len(blocks), 1))()
+        for i, (b, e, ev) in enumerate(blocks):
+            arr[i] = CArrival(int(b), int(e), int(ev) if ev else None)
+        self._ck(self._f["step_y_arrival"](h, float(min_stepsize), C.cast(arr, C.c_void_p), len(blocks)))
+
     def col_losses(self, h):
         self._ck(self._f["col_losses"](h))
 
@@ -394,7 +416,9 @@ class Api:
     def subset(self, h, row_tags, col_tags, match, invert=False):
         """Child handle over the entries whose tag (uint8 per entry of the parent's row view / column view) equals
         ``match`` (or differs from it when ``invert``): the train / test split of the cross-validation drivers, compacted
-        from the parent's resident data."""
+        from the parent's resident data.  The child of a SHARD parent (row / column ranges not the whole problem) comes back
+        deferred: read ``signature`` of every shard's child, combine (sum the counts, max the rest) and ``finalize`` each child
+        with the whole subset problem's signature before the first step-level call (include/glrm_hip.h, glrm_hip_subset)."""
         row_tags = np.ascontiguousarray(row_tags, dtype=np.uint8)
         col_tags = np.ascontiguousarray(col_tags, dtype=np.uint8)
         out = C.c_void_p()

@@ -21,6 +21,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <utility>
+#include <vector>
 
 #include "glrm_engine.hpp"
 #include "glrm_tiled.hpp"
@@ -119,12 +121,13 @@ static int64_t slice_capacity(K kernel, int device, int spb) {
 }
 
 template <int G, int R, int LOSS, bool GRAD>
-static int launch_blocked_inst(glrm_handle* h, TiledArgs a) {
+static int launch_blocked_inst(glrm_handle* h, TiledArgs a, bool rows) {
   constexpr int KP = G * R, T = tile_rows_b(KP), SPB = BNW * (64 / G);
   auto kernel = tiled_col_pass_kernel<G, R, BNW, T, LOSS, GRAD, true>;
-  // per handle and pass kind (the occupancy query depends on the instantiation, the CU count on the handle's device, the fill percentage
-  // on the environment at the handle's first sweep)
-  int64_t& cap_slot = h->blocked_cap[GRAD ? 0 : 1];
+  // per handle, view and pass kind: the row passes (LOSS_PER_OBS* instantiations of a heterogeneous model) and the column passes
+  // (LOSS_SEGMENT*) of one handle are different kernels with their own occupancy; the CU count is the handle's device's, the fill
+  // percentage the environment's at the handle's first sweep
+  int64_t& cap_slot = h->blocked_cap[rows ? 0 : 1][GRAD ? 0 : 1];
   if (cap_slot == 0) cap_slot = slice_capacity(kernel, h->device, SPB);
   const int64_t cap = cap_slot;
   const int64_t nseg = a.nseg;
@@ -132,7 +135,17 @@ static int launch_blocked_inst(glrm_handle* h, TiledArgs a) {
   // that cannot fill the chip)
   const int64_t nslices = (nseg + cap - 1) / cap;
   const int64_t per = nslices > 0 ? ((nseg + nslices - 1) / nslices + SPB - 1) / SPB * SPB : cap;
-  for (int sup = 0; sup < a.nsup; ++sup) {
+  // glrm_hip_step_y_arrival: the gradient pass of the column view walks the super-tiles in the order their rows of X arrive, each behind
+  // the events of the blocks it touches (h->sup_order, glrm_run_blocked); the partial sums are per (segment, super-tile) and col_reduce
+  // adds them in super-tile order, so the launch order changes no bit
+  const bool ordered = GRAD && !rows && h->n_arrival > 0 && (int)h->sup_order.size() == a.nsup;
+  for (int si = 0; si < a.nsup; ++si) {
+    const int sup = ordered ? h->sup_order[si] : si;
+    if (ordered) {
+      const int64_t rows_per_sup = (int64_t)a.tiles_per_sup * T;
+      const int rcw = glrm_arrival_wait(h, sup * rows_per_sup, std::min<int64_t>((sup + 1) * rows_per_sup, a.n_other));
+      if (rcw) return rcw;
+    }
     for (int64_t s0 = 0; s0 < nseg; s0 += per) {
       a.sup_fixed = sup;
       a.seg_begin = s0;
@@ -282,8 +295,8 @@ static int launch_lockstep(glrm_handle* h, int loss, bool grad, const TiledArgs&
 }
 
 template <int G, int R>
-static int launch_blocked_layout(glrm_handle* h, int loss, bool grad, const TiledArgs& a) {
-#define GLRM_BL(LOSSV) (grad ? launch_blocked_inst<G, R, LOSSV, true>(h, a) : launch_blocked_inst<G, R, LOSSV, false>(h, a))
+static int launch_blocked_layout(glrm_handle* h, int loss, bool grad, const TiledArgs& a, bool rows) {
+#define GLRM_BL(LOSSV) (grad ? launch_blocked_inst<G, R, LOSSV, true>(h, a, rows) : launch_blocked_inst<G, R, LOSSV, false>(h, a, rows))
   switch (loss) {
     case LOSS_QUAD_UNIFORM: return GLRM_BL(0);
     case LOSS_SEGMENT: return GLRM_BL(1);
@@ -294,13 +307,13 @@ static int launch_blocked_layout(glrm_handle* h, int loss, bool grad, const Tile
 #undef GLRM_BL
 }
 
-static int launch_blocked(glrm_handle* h, int loss, bool grad, const TiledArgs& a) {
+static int launch_blocked(glrm_handle* h, int loss, bool grad, const TiledArgs& a, bool rows) {
   switch (h->G * 100 + h->R) {
-    case 402: return launch_blocked_layout<4, 2>(h, loss, grad, a);
-    case 404: return launch_blocked_layout<4, 4>(h, loss, grad, a);
-    case 408: return launch_blocked_layout<4, 8>(h, loss, grad, a);
-    case 808: return launch_blocked_layout<8, 8>(h, loss, grad, a);
-    case 1608: return launch_blocked_layout<16, 8>(h, loss, grad, a);
+    case 402: return launch_blocked_layout<4, 2>(h, loss, grad, a, rows);
+    case 404: return launch_blocked_layout<4, 4>(h, loss, grad, a, rows);
+    case 408: return launch_blocked_layout<4, 8>(h, loss, grad, a, rows);
+    case 808: return launch_blocked_layout<8, 8>(h, loss, grad, a, rows);
+    case 1608: return launch_blocked_layout<16, 8>(h, loss, grad, a, rows);
     default: return fail(GLRM_ERR_UNSUPPORTED, "no phase-aligned pass kernel for lane layout G=%d R=%d", h->G, h->R);
   }
 }
@@ -348,9 +361,24 @@ int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, d
   }
   int rc;
   HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
+  h->sup_order.clear();
+  if (!rows && h->n_arrival > 0 && !h->lockstep && !eval_only) {
+    // a super-tile can run once the LAST (in the host's order) of the blocks it touches is there: sort the super-tiles by that position
+    const int64_t rows_per_sup = (int64_t)a.tiles_per_sup * tile_rows_b(h->kp);
+    std::vector<std::pair<int, int>> key((size_t)a.nsup);
+    for (int sup = 0; sup < a.nsup; ++sup) {
+      const int64_t lo = sup * rows_per_sup, hi = std::min<int64_t>((sup + 1) * rows_per_sup, a.n_other);
+      int last = 0;
+      for (int b = 0; b < h->n_arrival; ++b)
+        if (h->arrival[b].begin < hi && h->arrival[b].end > lo && h->arrival[b].event) last = std::max(last, b + 1);
+      key[sup] = {last, sup};
+    }
+    std::sort(key.begin(), key.end());
+    for (auto& kv : key) h->sup_order.push_back(kv.second);
+  }
   const bool lock = !rows && h->lockstep; // the same kernel in every pass (one summation order); it meets at the windows while most columns take part
   if (lock) { if ((rc = launch_lockstep(h, loss, true, a, true))) return rc; }
-  else if ((rc = launch_blocked(h, loss, true, a))) return rc;   // gradient + loss partials, super-tile by super-tile
+  else if ((rc = launch_blocked(h, loss, true, a, rows))) return rc;   // gradient + loss partials, super-tile by super-tile
   glrm_launch_col_small(h->kp, 0, a, h->stream);                 // reduce in super-tile order, J_old, first trial point
   HIPCK(hipGetLastError());
   if (eval_only || a.fixed_alpha > 0.0) return GLRM_OK;
@@ -363,7 +391,7 @@ int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, d
     if (nact == 0) break;
     HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
     if (lock) { if ((rc = launch_lockstep(h, loss, false, a, (int64_t)nact * 4 >= a.nseg))) return rc; }
-    else if ((rc = launch_blocked(h, loss, false, a))) return rc; // loss partials at the trial points of the searching segments
+    else if ((rc = launch_blocked(h, loss, false, a, rows))) return rc; // loss partials at the trial points of the searching segments
     glrm_launch_col_small(h->kp, 1, a, h->stream);               // accept / shrink / give up, next trial point
     HIPCK(hipGetLastError());
   }

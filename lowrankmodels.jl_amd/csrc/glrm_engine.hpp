@@ -131,13 +131,22 @@ struct glrm_handle {
   bool finalize_failed = false;       // glrm_hip_finalize ran and failed half way: the handle can only be destroyed
   // launch geometry of the persistent / sliced kernels, per handle (device and fill percentage at finalize; a process may drive devices
   // with different CU counts, and the knobs are read per handle): 0 = not computed yet
-  int64_t blocked_cap[2] = {0, 0};    // phase-aligned passes: segments per launch slice, gradient / trial instantiation
+  int64_t blocked_cap[2][2] = {{0, 0}, {0, 0}}; // phase-aligned passes: segments per launch slice, [row / column view][gradient / trial instantiation]
   int cached_grid[2] = {0, 0};        // persistent cached row sweep: resident workgroups, MAXT = 7 / 4 instantiation
   glrm_signature sig_local{}, sig{};  // this shard's contribution / the whole problem's
   int order_unit = 0;                 // opposing vectors per unit of the tile-order check (glrm_tiled.hip)
   hipStream_t side_stream = nullptr;  // the launches of the minority classes run beside the main launch
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   int profile = 0;
+  // glrm_hip_step_y_arrival: the blocks of X that are still arriving (valid during that call only), which of them the launch stream has
+  // already been made to wait for, and -- phase-aligned column passes -- the order in which the gradient pass walks the super-tiles
+  const glrm_arrival* arrival = nullptr;
+  int n_arrival = 0;
+  std::vector<char> arrival_waited;
+  std::vector<int> sup_order;
+  double ms_wait = 0;                 // profile: time the launch stream stood in those waits
+  int sum_order_opt = 0;              // glrm_options.sum_order (1: reference-order validation sweeps, glrm_reforder.hip)
+  int affine_opt = 0;                 // glrm_options.affine_trials
   // hipGraph of one outer iteration (gather sweeps on a private stream): small fits are launch bound
   hipGraph_t iter_graph = nullptr;
   hipGraphExec_t iter_exec = nullptr;
@@ -178,6 +187,10 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
 // phase-aligned gather passes (glrm_blocked.hip): setup decides blocked_row / blocked_col and allocates the pass buffers
 int glrm_setup_blocked(glrm_handle* h);
 int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only);
+
+// glrm_hip_step_y_arrival (glrm_hip.hip): make h->stream wait for every block of h->arrival that intersects rows [lo, hi) of X and has
+// not been waited for yet
+int glrm_arrival_wait(glrm_handle* h, int64_t lo, int64_t hi);
 
 // stable segmented sort of a view by tile index (glrm_tilesort.hip)
 int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals, bool free_old);

@@ -684,7 +684,11 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   h->unroll_col = env_int("GLRM_HIP_UNROLL_COL", 1) == 2 ? 2 : 1;
   h->profile = o ? o->profile : 0;
   h->tiled_opt = o ? o->tiled : 0;
+  h->sum_order_opt = o ? o->sum_order : 0;
+  h->affine_opt = o ? o->affine_trials : 0;
   if (o && o->reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_options.reserved must be 0");
+  if (o && (o->sum_order < 0 || o->sum_order > 1)) return fail(GLRM_ERR_INVALID, "glrm_options.sum_order must be 0 (engine orders) or 1 (reference order)");
+  if (o && (o->affine_trials < 0 || o->affine_trials > 1)) return fail(GLRM_ERR_INVALID, "glrm_options.affine_trials must be 0 or 1");
   if (o) h->opts = *o; else { h->opts = glrm_options{}; h->opts.device_id = -1; }
   h->losses_h.assign(p->losses, p->losses + p->n_losses);
   h->rx_h.assign(p->rx, p->rx + p->n_rx);
@@ -777,6 +781,8 @@ static int finalize_impl(glrm_handle* h, const glrm_signature* whole) {
   if (!h->multi && !h->dense) {
     // a failure from here on leaves re-ordered private views and partial buffers behind: the handle can then only be destroyed
     h->finalize_failed = true;
+    if (env_int("GLRM_HIP_TEST_FAIL_FINALIZE", 0))  // test hook (tests/test_gpu_crossval.py): the latch below cannot be reached on purpose otherwise
+      return fail(GLRM_ERR_OOM, "injected set-up failure (GLRM_HIP_TEST_FAIL_FINALIZE)");
     if ((rc = glrm_setup_tiled(h))) return rc;
     if ((rc = glrm_setup_cached(h))) return rc;
     if ((rc = glrm_setup_blocked(h))) return rc;
@@ -1013,7 +1019,7 @@ static int drain_events(glrm_handle* h) {
     HIPCK(hipEventSynchronize(e.b));
     float ms = 0;
     HIPCK(hipEventElapsedTime(&ms, e.a, e.b));
-    (e.which == 0 ? h->ms_x : h->ms_y) += ms;
+    (e.which == 0 ? h->ms_x : e.which == 1 ? h->ms_y : h->ms_wait) += ms;
     h->pool.push_back(e);
   }
   h->pending.clear();
@@ -1192,6 +1198,64 @@ extern "C" int glrm_hip_step_y(glrm_handle* h, double min_stepsize) {
   return run_sweep(h, 1, min_stepsize, 0);
 }
 
+// ---- the Y half-step while X is still arriving (include/glrm_hip.h: glrm_hip_step_y_arrival) ----------------------------------------
+int glrm_arrival_wait(glrm_handle* h, int64_t lo, int64_t hi) {
+  for (int b = 0; b < h->n_arrival; ++b) {
+    const glrm_arrival& blk = h->arrival[b];
+    if (h->arrival_waited[b] || blk.end <= lo || blk.begin >= hi) continue;
+    h->arrival_waited[b] = 1;
+    if (!blk.event) continue;
+    glrm_handle::Ev ev{};
+    if (h->profile) { // what the launch stream spends in front of a block that is not there yet (ms_wait_y)
+      if (!h->pool.empty()) { ev = h->pool.back(); h->pool.pop_back(); }
+      else { HIPCK(hipEventCreate(&ev.a)); HIPCK(hipEventCreate(&ev.b)); }
+      ev.which = 2;
+      HIPCK(hipEventRecord(ev.a, h->stream));
+    }
+    HIPCK(hipStreamWaitEvent(h->stream, (hipEvent_t)blk.event, 0));
+    if (h->profile) {
+      HIPCK(hipEventRecord(ev.b, h->stream));
+      h->pending.push_back(ev);
+    }
+  }
+  return GLRM_OK;
+}
+
+extern "C" int glrm_hip_step_y_arrival(glrm_handle* h, double min_stepsize, const glrm_arrival* blocks, int32_t n_blocks) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (n_blocks < 0 || (n_blocks > 0 && !blocks)) return fail(GLRM_ERR_INVALID, "bad block list");
+  if (n_blocks == 0) return glrm_hip_step_y(h, min_stepsize);
+  { // the blocks must tile [0, m): every row of X is either there or announced by exactly one event
+    std::vector<std::pair<int64_t, int64_t>> r;
+    for (int b = 0; b < n_blocks; ++b) {
+      if (blocks[b].begin < 0 || blocks[b].end > h->m || blocks[b].begin > blocks[b].end) return fail(GLRM_ERR_INVALID, "arrival block %d: rows [%lld, %lld) out of range", b, (long long)blocks[b].begin, (long long)blocks[b].end);
+      if (blocks[b].begin < blocks[b].end) r.emplace_back(blocks[b].begin, blocks[b].end);
+    }
+    std::sort(r.begin(), r.end());
+    int64_t at = 0;
+    for (auto& x : r) {
+      if (x.first != at) return fail(GLRM_ERR_INVALID, "arrival blocks must tile the rows [0, m) of X without gaps or overlaps (at row %lld)", (long long)at);
+      at = x.second;
+    }
+    if (at != h->m) return fail(GLRM_ERR_INVALID, "arrival blocks must tile the rows [0, m) of X (they end at row %lld of %lld)", (long long)at, (long long)h->m);
+  }
+  GLRM_NEED_FINALIZED(h);
+  DeviceGuard dg(h->device);
+  h->arrival = blocks;
+  h->n_arrival = n_blocks;
+  h->arrival_waited.assign((size_t)n_blocks, 0);
+  int rc = GLRM_OK;
+  // only the phase-aligned column passes can start on a part of X; everything else needs all of it
+  const bool by_super_tile = h->blocked_col && !h->lockstep && !h->multi && !h->dense && !h->tiled_col && !h->sum_order_opt && env_int("GLRM_HIP_ARRIVAL", 1);
+  if (!by_super_tile) rc = glrm_arrival_wait(h, 0, h->m);
+  if (!rc) rc = run_sweep(h, 1, min_stepsize, 0);
+  if (!rc) rc = glrm_arrival_wait(h, 0, h->m); // (a shard without columns launches nothing: later work on the stream still follows the arrivals)
+  h->arrival = nullptr;
+  h->n_arrival = 0;
+  h->sup_order.clear();
+  return rc;
+}
+
 // One prox-gradient step with a global step size and no line search (src/algorithms/sparse_proxgrad.jl:59-77, :81-99).
 static int gradstep(glrm_handle* h, int which, double alpha) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
@@ -1267,7 +1331,7 @@ extern "C" int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int
   if (rc) return rc;
   memset(out, 0, sizeof *out);
   out->launches_x = h->launches_x; out->launches_y = h->launches_y;
-  out->ms_x = h->ms_x; out->ms_y = h->ms_y;
+  out->ms_x = h->ms_x; out->ms_y = h->ms_y; out->ms_wait_y = h->ms_wait;
   if ((rc = count_sum(h, h->trials_r, h->ml, &out->trials_x))) return rc;
   if ((rc = count_sum(h, h->accepts_r, h->ml, &out->accepts_x))) return rc;
   if ((rc = count_sum(h, h->trials_c, h->nl, &out->trials_y))) return rc;
@@ -1278,7 +1342,7 @@ extern "C" int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int
                (h->blocked_col ? 32 : 0); // bit0 / bit1: LDS-tiled row / column sweep, bit4 / bit5: phase-aligned gather passes
   if (reset) {
     h->launches_x = h->launches_y = 0;
-    h->ms_x = h->ms_y = 0;
+    h->ms_x = h->ms_y = h->ms_wait = 0;
     const int64_t ml1 = h->ml > 0 ? h->ml : 1, nl1 = h->nl > 0 ? h->nl : 1;
     HIPCK(hipMemsetAsync(h->trials_r, 0, ml1 * 4, h->stream));
     HIPCK(hipMemsetAsync(h->accepts_r, 0, ml1 * 4, h->stream));

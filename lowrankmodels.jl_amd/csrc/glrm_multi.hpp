@@ -897,6 +897,7 @@ __global__ void __launch_bounds__(512) multi_coldecide_kernel(const SplitArgs sa
     } else {
       alpha *= .7;
       if (alpha < a.min_stepsize) { alpha = a.min_stepsize * 1.1; finished = true; }
+      else if (!(alpha > a.min_stepsize)) finished = true; // `while alpha > min_stepsize` (proxgrad.jl:180)
     }
   }
   if (!finished) { // next trial point

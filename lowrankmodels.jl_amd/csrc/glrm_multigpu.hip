@@ -15,11 +15,29 @@
 //                     librccl.so is loaded at run time, needs distinct devices.
 // Each shard's step_* call is issued from its own host thread: the LDS-tiled column sweep reads back an active count per
 // line-search round, and those round trips must not serialise across devices.
+//
+// The exchange is OFF the critical path between the half-steps (round 5).  The X half-step runs in x_chunks row chunks; the push of chunk
+// j leaves while chunk j+1 is swept, and the Y half-step does not wait for the exchange to finish: glrm_hip_step_y_arrival gets the
+// list (own rows -- no event --, then chunk 0 of every peer, chunk 1 of every peer, ...) with the copy event of each range, and the
+// phase-aligned column passes launch each super-tile of X behind the events of the ranges it touches.  Partial sums are per (column,
+// super-tile) and are added in super-tile order, so no bit depends on the arrival order (tests: test_multi_in_process.py,
+// test_gpu_families.py).  The Y blocks (k x n / N: 0.08 ms per link at C4) are exchanged the old way.
+//
+// Link emulation (one box, fewer GPUs than shards): GLRM_EXCHANGE_EMULATE_GBPS=<rate> makes every direct push occupy its (source,
+// destination) link for bytes / rate counted from the moment the source range was complete -- a device-to-device copy on one GPU takes
+// no such time.  Mechanism 1 (default where hipDeviceAttributeCanUseStreamWaitValue is set): the copy stream writes a start mark
+// (hipStreamWriteValue64), copies, then waits (hipStreamWaitValue64) for a release value that a host timer thread posts bytes / rate
+// after it saw the mark -- no CU is occupied by the delay.  Mechanism 2 (GLRM_EXCHANGE_EMULATE_MODE=2): a one-lane kernel that
+// sleeps on wall_clock64 until the deadline (needs a free wave slot: persistent kernels that fill the register file delay it).
+// GLRM_EXCHANGE_EMULATE_DILATE=<d> divides the rate; default = the largest number of shards on one device (d shards time-share the
+// device, so compute is d times slower than on d devices and a transfer has to be as well to keep the proportion).
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <deque>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
@@ -119,6 +137,57 @@ struct ShardPool {
   }
 };
 
+// ---- link emulator ----------------------------------------------------------------------------------------------------
+__global__ void link_mark_kernel(unsigned long long* t0) { *t0 = (unsigned long long)wall_clock64(); }
+__global__ void link_delay_kernel(const unsigned long long* t0, unsigned long long ticks) {
+  const unsigned long long start = *t0;
+  while ((unsigned long long)wall_clock64() - start < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+struct LinkEmu {
+  double bytes_per_s = 0.0; // per direction and link, already divided by the dilation; 0 = off
+  double gbps = 0.0;
+  int dilate = 1, mode = 0; // 1 stream wait-value + host timer, 2 delay kernels
+  // mode 1: one (mark, release) pair of 8-byte signal words per (source, destination) link; tickets count the transfers of a link
+  std::vector<uint64_t*> mark, release;
+  std::vector<uint64_t> ticket;
+  struct Job { int link; uint64_t ticket; double seconds; double due; bool started; };
+  std::deque<Job> jobs; // per link in ticket order (one copy stream per link keeps them ordered on the device too)
+  std::mutex mu;
+  std::thread timer;
+  std::atomic<bool> quit{false};
+  // mode 2
+  std::vector<unsigned long long*> t0;
+  double wall_hz = 1e8;
+  void timer_loop() {
+    // a transfer may not be released before bytes / rate have passed since its mark; a job that never sees its mark (its stream was
+    // torn down) is dropped by destroy, which posts every release value first
+    for (;;) {
+      if (quit.load(std::memory_order_acquire)) return;
+      bool busy = false;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        const double now = now_s();
+        for (auto it = jobs.begin(); it != jobs.end();) {
+          busy = true;
+          if (!it->started && __atomic_load_n(mark[it->link], __ATOMIC_ACQUIRE) >= it->ticket) { it->started = true; it->due = now + it->seconds; }
+          if (it->started && now >= it->due) {
+            __atomic_store_n(release[it->link], it->ticket, __ATOMIC_RELEASE);
+            it = jobs.erase(it);
+          } else ++it;
+        }
+      }
+      if (busy) std::this_thread::sleep_for(std::chrono::microseconds(20));
+      else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+  }
+  void release_all() { // nothing may be left waiting on the device
+    std::lock_guard<std::mutex> lk(mu);
+    for (auto& j : jobs) __atomic_store_n(release[j.link], j.ticket, __ATOMIC_RELEASE);
+    jobs.clear();
+  }
+};
+
 struct glrm_multi {
   int n = 0;
   ShardPool pool;
@@ -132,6 +201,10 @@ struct glrm_multi {
   std::vector<hipEvent_t> ev_done;                   // sweep of shard s finished (timing enabled: start of its exchange wait)
   std::vector<hipEvent_t> ev_ready;                  // every incoming block of shard s has arrived
   std::vector<std::vector<hipEvent_t>> ev_arr;       // ev_arr[s][t]: block of s landed on t
+  std::vector<std::vector<std::vector<hipEvent_t>>> ev_chunk; // ev_chunk[s][t][j]: row chunk j of s's X block landed on t
+  int arrival = 1;                                   // Y half-step consumes the X chunks in arrival order (glrm_hip_step_y_arrival)
+  LinkEmu emu;
+  std::vector<double> wait_y0;                       // ms_wait_y of every shard at the start of the fit
   std::vector<int64_t> rbs, cbs, ybs;                // shard bounds: rows, columns, vectors of Y
   int exchange = 0;                                  // in use: 0 direct, 1 rccl
   std::vector<Rccl::comm_t> comms;
@@ -189,11 +262,38 @@ int run_all(glrm_multi* mh, const std::function<int(int)>& fn) {
     if (e_ != hipSuccess) return fail(GLRM_ERR_COMM, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+// Link emulation around the pushes of source `link` on its link stream c: before / after hooks
+int emu_before(glrm_multi* mh, hipStream_t c, int link) {
+  LinkEmu& e = mh->emu;
+  if (e.bytes_per_s <= 0.0) return GLRM_OK;
+  if (e.mode == 1) COMMCK(hipStreamWriteValue64(c, e.mark[link], e.ticket[link] + 1, 0));
+  else hipLaunchKernelGGL(link_mark_kernel, dim3(1), dim3(1), 0, c, e.t0[link]);
+  return GLRM_OK;
+}
+int emu_after(glrm_multi* mh, hipStream_t c, int link, size_t bytes) {
+  LinkEmu& e = mh->emu;
+  if (e.bytes_per_s <= 0.0) return GLRM_OK;
+  const double seconds = (double)bytes / e.bytes_per_s;
+  if (e.mode == 1) {
+    const uint64_t tk = ++e.ticket[link];
+    {
+      std::lock_guard<std::mutex> lk(e.mu);
+      e.jobs.push_back(LinkEmu::Job{link, tk, seconds, 0.0, false});
+    }
+    COMMCK(hipStreamWaitValue64(c, e.release[link], tk, hipStreamWaitValueGte));
+  } else {
+    hipLaunchKernelGGL(link_delay_kernel, dim3(1), dim3(1), 0, c, e.t0[link], (unsigned long long)(seconds * e.wall_hz));
+    COMMCK(hipGetLastError());
+  }
+  return GLRM_OK;
+}
+
 // Shard s owns buf[bounds[s]*unit .. bounds[s+1]*unit) (doubles) restricted to the sub-range [lo_s, hi_s) of its block given by
-// `sub` (fractions j/C of the block for the pipelined X exchange; 0/1 = the whole block).  Phase 1 (push): after the work already
-// queued on st[s], push that range to every destination.  Phase 2 (wait): st[t] waits for everything pushed to t so far.
+// (cj, cn) (fractions j/C of the block for the pipelined X exchange; 0/1 = the whole block).  Phase 1 (push): after the work already
+// queued on st[s], push that range to every destination and record ev_arr[s][t] (and, chunk_events: ev_chunk[s][t][cj]) behind it.
+// Phase 2 (wait): st[t] waits for everything pushed to t so far.
 int exchange_push(glrm_multi* mh, std::vector<double*>& buf, const std::vector<int64_t>& bounds, int64_t unit, int only_dst, int cj,
-                  int cn) {
+                  int cn, bool chunk_events = false) {
   const int n = mh->n;
   if (n == 1) return GLRM_OK;
   for (int s = 0; s < n; ++s) {
@@ -220,13 +320,38 @@ int exchange_push(glrm_multi* mh, std::vector<double*>& buf, const std::vector<i
     if (rc || rc2) return fail(GLRM_ERR_COMM, "RCCL exchange failed: %s", R.GetErrorString ? R.GetErrorString(rc ? rc : rc2) : "?");
     return GLRM_OK;
   }
+  const bool emulate = mh->emu.bytes_per_s > 0.0;
   for (int s = 0; s < n; ++s) {
     const int64_t blk = bounds[s + 1] - bounds[s];
     const int64_t lo = bounds[s] + blk * cj / cn, hi = bounds[s] + blk * (cj + 1) / cn;
     const size_t bytes = (size_t)((hi - lo) * unit) * 8;
     COMMCK(hipSetDevice(mh->dev[s]));
-    for (int t = 0; t < n; ++t) {
-      if (t == s || (only_dst >= 0 && t != only_dst)) continue;
+    if (emulate) {
+      // ONE stream per source stands for its n - 1 links (they run in parallel and carry equal sizes, so they finish together):
+      // mark, the copies, then the wait for bytes / rate since the mark, then the arrival events.  Few streams on purpose: a queue
+      // that stands in a wait blocks every stream the runtime maps onto the same hardware queue (GPU_MAX_HW_QUEUES).
+      hipStream_t c = mh->cs[s][(s + 1) % n];
+      COMMCK(hipStreamWaitEvent(c, mh->ev_done[s], 0));
+      int rc = bytes ? emu_before(mh, c, s) : GLRM_OK;
+      if (rc) return rc;
+      for (int d = 1; d < n && bytes; ++d) {
+        const int t = (s + d) % n;
+        if (only_dst >= 0 && t != only_dst) continue;
+        if (mh->dev[s] == mh->dev[t]) COMMCK(hipMemcpyAsync(buf[t] + lo * unit, buf[s] + lo * unit, bytes, hipMemcpyDeviceToDevice, c));
+        else COMMCK(hipMemcpyPeerAsync(buf[t] + lo * unit, mh->dev[t], buf[s] + lo * unit, mh->dev[s], bytes, c));
+      }
+      if (bytes && (rc = emu_after(mh, c, s, bytes))) return rc;
+      for (int d = 1; d < n; ++d) {
+        const int t = (s + d) % n;
+        if (only_dst >= 0 && t != only_dst) continue;
+        COMMCK(hipEventRecord(mh->ev_arr[s][t], c));
+        if (chunk_events) COMMCK(hipEventRecord(mh->ev_chunk[s][t][cj], c));
+      }
+      continue;
+    }
+    for (int d = 1; d < n; ++d) { // destinations in ring order from s: no destination is everybody's first
+      const int t = (s + d) % n;
+      if (only_dst >= 0 && t != only_dst) continue;
       hipStream_t c = mh->cs[s][t];
       COMMCK(hipStreamWaitEvent(c, mh->ev_done[s], 0));
       if (bytes) {
@@ -234,6 +359,7 @@ int exchange_push(glrm_multi* mh, std::vector<double*>& buf, const std::vector<i
         else COMMCK(hipMemcpyPeerAsync(buf[t] + lo * unit, mh->dev[t], buf[s] + lo * unit, mh->dev[s], bytes, c));
       }
       COMMCK(hipEventRecord(mh->ev_arr[s][t], c));
+      if (chunk_events) COMMCK(hipEventRecord(mh->ev_chunk[s][t][cj], c));
     }
   }
   return GLRM_OK;
@@ -298,6 +424,11 @@ extern "C" void glrm_hip_multi_destroy(glrm_multi* mh) {
   if (!mh) return;
   int prev = 0;
   (void)hipGetDevice(&prev);
+  if (mh->emu.timer.joinable()) { // nothing may be left waiting for a release on the device
+    mh->emu.release_all();
+    mh->emu.quit.store(true, std::memory_order_release);
+    mh->emu.timer.join();
+  }
   for (int s = 0; s < (int)mh->sh.size(); ++s) {
     if (mh->sh[s]) glrm_hip_destroy(mh->sh[s]);
   }
@@ -313,6 +444,13 @@ extern "C" void glrm_hip_multi_destroy(glrm_multi* mh) {
     if (s < (int)mh->ev_arr.size())
       for (hipEvent_t e : mh->ev_arr[s])
         if (e) (void)hipEventDestroy(e);
+    if (s < (int)mh->ev_chunk.size())
+      for (auto& v : mh->ev_chunk[s])
+        for (hipEvent_t e : v)
+          if (e) (void)hipEventDestroy(e);
+    if (s < (int)mh->emu.mark.size() && mh->emu.mark[s]) (void)hipFree(mh->emu.mark[s]);
+    if (s < (int)mh->emu.release.size() && mh->emu.release[s]) (void)hipFree(mh->emu.release[s]);
+    if (s < (int)mh->emu.t0.size() && mh->emu.t0[s]) (void)hipFree(mh->emu.t0[s]);
     if (s < (int)mh->ev_done.size() && mh->ev_done[s]) (void)hipEventDestroy(mh->ev_done[s]);
     if (s < (int)mh->ev_ready.size() && mh->ev_ready[s]) (void)hipEventDestroy(mh->ev_ready[s]);
     if (s < (int)mh->st.size() && mh->st[s]) (void)hipStreamDestroy(mh->st[s]);
@@ -432,6 +570,57 @@ static int multi_create_impl(glrm_multi* mh, const glrm_problem* p, const glrm_o
     } // else: direct path (shards sharing a device, or no librccl.so)
   }
   mh->x_chunks = (mo->x_chunks >= 2 && n > 1 && !mh->dense && mh->exchange == 0) ? mo->x_chunks : 1;
+  // arrival order: the direct exchange of list problems (the dense path walks A, not X, super-tile by super-tile)
+  mh->arrival = (n > 1 && !mh->dense && mh->exchange == 0 && env_int("GLRM_HIP_MULTI_ARRIVAL", mo->arrival == 2 ? 0 : 1)) ? 1 : 0;
+  mh->ev_chunk.assign(n, std::vector<std::vector<hipEvent_t>>(n));
+  if (mh->arrival)
+    for (int s = 0; s < n; ++s) {
+      HIPCK(hipSetDevice(mh->dev[s]));
+      for (int t = 0; t < n; ++t) {
+        if (t == s) continue;
+        mh->ev_chunk[s][t].assign((size_t)mh->x_chunks, nullptr);
+        for (int j = 0; j < mh->x_chunks; ++j) HIPCK(hipEventCreateWithFlags(&mh->ev_chunk[s][t][j], hipEventDisableTiming));
+      }
+    }
+  // link emulation (see the head of this file)
+  const char* eg = getenv("GLRM_EXCHANGE_EMULATE_GBPS");
+  const double gbps = (eg && *eg) ? atof(eg) : 0.0;
+  if (gbps > 0.0 && n > 1 && mh->exchange == 0) {
+    LinkEmu& e = mh->emu;
+    int share = 1;
+    for (int s = 0; s < n; ++s) {
+      int c = 0;
+      for (int t = 0; t < n; ++t) c += mh->dev[t] == mh->dev[s];
+      share = std::max(share, c);
+    }
+    e.dilate = std::max(1, env_int("GLRM_EXCHANGE_EMULATE_DILATE", share));
+    e.gbps = gbps;
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, mh->dev[0]) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+    e.mode = env_int("GLRM_EXCHANGE_EMULATE_MODE", can ? 1 : 2);
+    if (e.mode != 1 && e.mode != 2) return fail(GLRM_ERR_INVALID, "GLRM_EXCHANGE_EMULATE_MODE must be 1 (stream wait-value) or 2 (delay kernels)");
+    if (e.mode == 1 && !can) return fail(GLRM_ERR_UNSUPPORTED, "GLRM_EXCHANGE_EMULATE_MODE=1: the device does not support hipStreamWaitValue64");
+    if (e.mode == 1) {
+      e.mark.assign(n, nullptr); e.release.assign(n, nullptr); e.ticket.assign(n, 0);
+      for (int s = 0; s < n; ++s) {
+        HIPCK(hipSetDevice(mh->dev[s]));
+        HIPCK(hipExtMallocWithFlags((void**)&e.mark[s], 8, hipMallocSignalMemory));
+        HIPCK(hipExtMallocWithFlags((void**)&e.release[s], 8, hipMallocSignalMemory));
+        *e.mark[s] = 0; *e.release[s] = 0; // signal memory is host-visible
+      }
+      e.timer = std::thread([mh] { mh->emu.timer_loop(); });
+    } else {
+      e.t0.assign(n, nullptr);
+      int khz = 0;
+      if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, mh->dev[0]) == hipSuccess && khz > 0) e.wall_hz = khz * 1e3;
+      else (void)hipGetLastError();
+      for (int s = 0; s < n; ++s) {
+        HIPCK(hipSetDevice(mh->dev[s]));
+        HIPCK(hipMalloc((void**)&e.t0[s], 8));
+      }
+    }
+    e.bytes_per_s = gbps * 1e9 / e.dilate; // set last: the hooks are live from here
+  }
   return GLRM_OK;
 }
 
@@ -439,7 +628,7 @@ extern "C" int glrm_hip_multi_create(glrm_multi** out, const glrm_problem* p, co
   if (!out || !p || !mo) return fail(GLRM_ERR_INVALID, "NULL argument");
   *out = nullptr;
   if (mo->n_shards < 1 || mo->n_shards > 64) return fail(GLRM_ERR_INVALID, "n_shards must be in 1..64");
-  if (mo->reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_multi_options.reserved must be 0");
+  if (mo->arrival < 0 || mo->arrival > 2) return fail(GLRM_ERR_INVALID, "glrm_multi_options.arrival must be 0, 1 or 2");
   if (p->flags & GLRM_PROBLEM_DEVICE_ARRAYS) return fail(GLRM_ERR_UNSUPPORTED, "glrm_hip_multi_create takes host arrays (it slices them per device)");
   if (p->m <= 0 || p->n <= 0 || p->k <= 0) return fail(GLRM_ERR_INVALID, "m, n, k must be positive");
   if (!(p->row_begin == 0 && p->row_end == p->m && p->col_begin == 0 && p->col_end == p->n))
@@ -514,6 +703,42 @@ extern "C" int glrm_hip_multi_fit(glrm_multi* mh, const glrm_params* prm, double
     return rc;
   int64_t nnz_rows = 0;
   for (int s = 0; s < mh->n; ++s) nnz_rows += mh->sh[s]->nnz_r;
+  // arrival order: what shard t's Y half-step is told about the rows of X -- its own block is there, then chunk 0 of every peer (ring
+  // order from t: the order the peers push in), chunk 1 of every peer, ...; the events are re-recorded by every iteration's pushes
+  const int n = mh->n, C = mh->x_chunks;
+  const bool arr = mh->arrival != 0;
+  std::vector<std::vector<glrm_arrival>> arrv((size_t)n);
+  if (arr) {
+    for (int t = 0; t < n; ++t) {
+      arrv[t].push_back(glrm_arrival{mh->rbs[t], mh->rbs[t + 1], nullptr});
+      for (int j = 0; j < C; ++j)
+        for (int d = 1; d < n; ++d) {
+          const int s = (t + n - d) % n; // s pushes to (s + d) % n = t as its d-th destination
+          const int64_t blk = mh->rbs[s + 1] - mh->rbs[s];
+          const int64_t lo = mh->rbs[s] + blk * j / C, hi = mh->rbs[s] + blk * (j + 1) / C;
+          if (hi > lo) arrv[t].push_back(glrm_arrival{lo, hi, (void*)mh->ev_chunk[s][t][j]});
+        }
+    }
+    mh->wait_y0.assign((size_t)n, 0.0);
+    if (mh->profile)
+      for (int s = 0; s < n; ++s) {
+        glrm_kernel_stats ks{};
+        if ((rc = glrm_hip_kernel_stats(mh->sh[s], &ks, 0))) return rc;
+        mh->wait_y0[s] = ks.ms_wait_y;
+      }
+  }
+  // a shard may not overwrite its block of X (Y) while a push of the previous iteration's exchanges still reads it: at the start of an
+  // iteration its stream waits for its own outgoing copies (one copy stream per link keeps them in order, so the last event covers all;
+  // they have long finished in practice -- a whole half-step lies in between; with link emulation they "finish" late)
+  auto wait_outgoing = [&]() -> int {
+    if (n == 1 || mh->exchange == 1) return GLRM_OK;
+    for (int s = 0; s < n; ++s) {
+      COMMCK(hipSetDevice(mh->dev[s]));
+      for (int t = 0; t < n; ++t)
+        if (t != s) COMMCK(hipStreamWaitEvent(mh->st[s], mh->ev_arr[s][t], 0));
+    }
+    return GLRM_OK;
+  };
   const double scaled_abs_tol = prm->abs_tol * (double)nnz_rows;       // :72
   if ((rc = multi_objective(mh, &objective[0]))) return rc;           // :76
   seconds[0] = 0.0;
@@ -522,26 +747,34 @@ extern "C" int glrm_hip_multi_fit(glrm_multi* mh, const glrm_params* prm, double
   for (int64_t i = 1; i <= prm->max_iter; ++i) {                       // :107
     if (prm->inner_iter_X > 1 || prm->inner_iter_Y > 1)
       if ((rc = run_all(mh, [&](int s) { return glrm_hip_reset_stepsizes(mh->sh[s], prm->stepsize); }))) return rc; // :112-115
+    if ((rc = wait_outgoing())) return rc;
     for (int64_t in = 0; in + 1 < prm->inner_iter_X; ++in)              // inner sweeps touch own rows only: exchange once
       if ((rc = run_all(mh, [&](int s) { return glrm_hip_step_x(mh->sh[s], prm->min_stepsize); }))) return rc;
-    if (mh->x_chunks > 1) { // last inner sweep in row chunks: the push of chunk j overlaps the sweep of chunk j+1
-      for (int j = 0; j < mh->x_chunks; ++j) {
+    if (C > 1 || arr) { // last inner sweep in row chunks: the push of chunk j overlaps the sweep of chunk j+1
+      for (int j = 0; j < C; ++j) {
         if ((rc = run_all(mh, [&](int s) {
+               if (C == 1) return glrm_hip_step_x(mh->sh[s], prm->min_stepsize);
                const int64_t ml = mh->rbs[s + 1] - mh->rbs[s];
-               return glrm_hip_step_x_range(mh->sh[s], ml * j / mh->x_chunks, ml * (j + 1) / mh->x_chunks, prm->min_stepsize);
+               return glrm_hip_step_x_range(mh->sh[s], ml * j / C, ml * (j + 1) / C, prm->min_stepsize);
              })))
           return rc;
-        if ((rc = exchange_push(mh, mh->dX, mh->rbs, mh->ld, -1, j, mh->x_chunks))) return rc;
+        if ((rc = exchange_push(mh, mh->dX, mh->rbs, mh->ld, -1, j, C, arr))) return rc;
       }
-      if ((rc = exchange_wait(mh, -1))) return rc;
-      account_exchange(mh);
+      if (!arr) { // the Y half-step needs all of X: wait here (with arrival order it waits block by block, inside step_y_arrival)
+        if ((rc = exchange_wait(mh, -1))) return rc;
+        account_exchange(mh);
+      }
     } else {
       if ((rc = run_all(mh, [&](int s) { return glrm_hip_step_x(mh->sh[s], prm->min_stepsize); }))) return rc; // :117-158
       if ((rc = exchange_all(mh, mh->dX, mh->rbs, mh->ld))) return rc;
       account_exchange(mh);
     }
-    for (int64_t in = 0; in < prm->inner_iter_Y; ++in)
-      if ((rc = run_all(mh, [&](int s) { return glrm_hip_step_y(mh->sh[s], prm->min_stepsize); }))) return rc; // :160-203
+    for (int64_t in = 0; in < prm->inner_iter_Y; ++in)                  // :160-203
+      if ((rc = run_all(mh, [&](int s) {
+             if (arr && in == 0) return glrm_hip_step_y_arrival(mh->sh[s], prm->min_stepsize, arrv[s].data(), (int32_t)arrv[s].size());
+             return glrm_hip_step_y(mh->sh[s], prm->min_stepsize);
+           })))
+        return rc;
     if ((rc = exchange_all(mh, mh->dY, mh->ybs, mh->ld))) return rc;
     account_exchange(mh);
     if ((rc = exchange_all(mh, mh->dObjCol, mh->cbs, 1, mh->exchange == 1 ? -1 : 0))) return rc;
@@ -557,6 +790,15 @@ extern "C" int glrm_hip_multi_fit(glrm_multi* mh, const glrm_params* prm, double
   }
   for (int s = 0; s < mh->n; ++s)
     if ((rc = glrm_hip_synchronize(mh->sh[s]))) return rc;
+  if (arr && mh->profile) { // what the Y half-steps spent in front of blocks of X that had not arrived yet
+    double worst = 0.0;
+    for (int s = 0; s < n; ++s) {
+      glrm_kernel_stats ks{};
+      if ((rc = glrm_hip_kernel_stats(mh->sh[s], &ks, 0))) return rc;
+      worst = std::max(worst, ks.ms_wait_y - mh->wait_y0[s]);
+    }
+    mh->exchange_ms += worst;
+  }
   if ((rc = glrm_hip_get_factors(mh->sh[0], X, Y))) return rc;
   *n_recorded = nrec;
   return GLRM_OK;

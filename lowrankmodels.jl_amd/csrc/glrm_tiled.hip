@@ -454,9 +454,11 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
   HIPCK(hipGetLastError());
   if (eval_only || a.fixed_alpha > 0.0) return GLRM_OK;
   const TiledArgs full = a;
-  // A segment leaves the search when a trial is accepted or its step size falls below min_stepsize: at most log(alpha / min_stepsize) /
-  // log(1 / 0.7) rounds (13 from alpha = 1 and the default 0.01; ~2 100 from any finite alpha down to 0).  The bound below is a guard
-  // against a loop that cannot end, never a silent cut: running into it is an error.
+  // A segment leaves the search when a trial is accepted or its step size is no longer above min_stepsize (`while alpha > min_stepsize`,
+  // proxgrad.jl:136,180): at most log(alpha / min_stepsize) / log(1 / 0.7) rounds (13 from alpha = 1 and the default 0.01).  With
+  // min_stepsize = 0 a search whose trials are all rejected never ends in the reference either: 0.7 x 4.9e-324 rounds back to 4.9e-324,
+  // alpha never reaches 0 (~2 090 rounds from alpha = 1 to the smallest denormal, then forever).  The bound below is a guard against
+  // exactly that loop, never a silent cut: running into it is an error where the reference would hang.
   constexpr int MAX_ROUNDS = 4096;
   for (int round = 0;; ++round) {
     if (round == MAX_ROUNDS) return fail(GLRM_ERR_INVALID, "line search still running after %d rounds (min_stepsize %g)", MAX_ROUNDS, min_stepsize);

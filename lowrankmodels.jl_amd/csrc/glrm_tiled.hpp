@@ -707,6 +707,8 @@ __global__ void __launch_bounds__(NW * 64, NW == 12 ? 3 : 4) tiled_sweep_kernel(
         if (alpha < a.min_stepsize) {
           alpha = a.min_stepsize * 1.1;
           searching = false;
+        } else if (!(alpha > a.min_stepsize)) {
+          searching = false; // `while alpha > min_stepsize` (proxgrad.jl:136): alpha == min_stepsize ends the search (min_stepsize = 0: alpha underflowed to 0)
         }
       }
     }
@@ -929,7 +931,7 @@ __global__ void __launch_bounds__(256) col_decide_kernel(const TiledArgs a) {
     alpha *= .7;
     if (alpha < a.min_stepsize) {
       alpha = a.min_stepsize * 1.1;
-    } else {
+    } else if (alpha > a.min_stepsize) { // `while alpha > min_stepsize` (proxgrad.jl:136,180): alpha == min_stepsize ends the search without the 1.1 reset
       still = 1;
       const double l = (double)(a.ptr ? a.ptr[seg + 1] - a.ptr[seg] : a.dense_len) + 1.0;
       const double s = alpha / l;

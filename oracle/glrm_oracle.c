@@ -681,7 +681,7 @@ static int eng_wave_count(const glrm_sum_order* o, int64_t len, int rows) {
 
 /* One pass over a segment in the engine's order: *J = sum of losses at xv, g (nullable) = sum of dL * opposing vector.
  * fac = the opposing factor (k contiguous doubles per vector), lossrow: rows take the loss of the entry's column, columns one loss.
- * `work` holds (T + 1) * (k + 4) doubles, T <= 128 lane groups. */
+ * `work` holds ENG_WORK_DOUBLES(k) doubles: T <= 128 lane groups (glrm_cpu_set_sum_order refuses STRIDED layouts beyond that). */
 static void eng_pass(const glrm_cpu_handle* h, const glrm_sum_order* o, int rows, int64_t gseg, const int32_t* idx, const double* vals, int64_t len,
                      const double* xv, const double* fac, const glrm_loss* segloss, double* J, double* g, double* work) {
   const int k = h->k, G = o->lanes, R = o->comps;
@@ -710,7 +710,7 @@ static void eng_pass(const glrm_cpu_handle* h, const glrm_sum_order* o, int rows
     }
     double Js = 0.0;
     if (g) for (int c = 0; c < k; ++c) g[c] = 0.0;
-    double col[16];
+    double col[64]; /* NG = 64 / G <= 64 groups of a wave */
     for (int w = 0; w < W; ++w) { /* across_groups_sum inside a wave, then the waves in order (block_combine / row_combine) */
       const double Jw = eng_butterfly(Jq + w * NG, NG);
       if (W == 1) Js = Jw; else Js += Jw;
@@ -857,6 +857,12 @@ int glrm_cpu_set_sum_order(glrm_cpu_handle* h, int32_t which, const glrm_sum_ord
       return fail(GLRM_ERR_INVALID, "sum order: bad wave count / batch");
     if (order->cached_maxlen >= 0 && !(order->cached_waves == 1 || order->cached_waves == 2 || order->cached_waves == 4))
       return fail(GLRM_ERR_INVALID, "sum order: bad cached wave count");
+    /* eng_pass keeps one partial (loss, gradient) per lane group in a buffer of 128 groups: T = (64 / lanes) x waves must fit (the
+     * engine's strided families use 4, 8 or 16 lanes; one- and two-lane strided layouts on 8 waves would be 512 / 256 groups) */
+    const int wmax = order->waves > 0 ? order->waves : 8, wc = order->cached_maxlen >= 0 ? order->cached_waves : 1;
+    if ((64 / G) * (wmax > wc ? wmax : wc) > 128)
+      return fail(GLRM_ERR_INVALID, "sum order: strided layout of %d lanes on %d waves is %d lane groups per segment (limit 128)", G, wmax > wc ? wmax : wc,
+                  (64 / G) * (wmax > wc ? wmax : wc));
   }
   *dst = *order;
   return GLRM_OK;
@@ -882,6 +888,31 @@ static int step_x_rows(glrm_cpu_handle* h, int64_t s0, int64_t s1, double min_st
 
 /* One inner X sweep over the local rows, src/algorithms/proxgrad.jl:118-156
  * (threaded exactly like proxgrad_multithread.jl:118: rows are independent). */
+/* Twin of glrm_hip_step_y_arrival (include/glrm_hip.h): the checker shares one address space with whoever filled X, there is nothing to
+ * wait for; the block list is validated like the engine validates it (the blocks tile [0, m)) and the half-step is glrm_cpu_step_y. */
+int glrm_cpu_step_y(glrm_cpu_handle* h, double min_stepsize);
+int glrm_cpu_step_y_arrival(glrm_cpu_handle* h, double min_stepsize, const glrm_arrival* blocks, int32_t n_blocks) {
+  if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
+  if (n_blocks < 0 || (n_blocks > 0 && !blocks)) return fail(GLRM_ERR_INVALID, "bad block list");
+  if (n_blocks > 0) {
+    int64_t at = 0;
+    for (int done = 0; done < n_blocks;) { /* O(n^2) walk in row order: the lists are short */
+      int found = 0;
+      for (int b = 0; b < n_blocks; ++b) {
+        if (blocks[b].begin < 0 || blocks[b].end > h->m || blocks[b].begin > blocks[b].end) return fail(GLRM_ERR_INVALID, "arrival block %d out of range", b);
+        if (blocks[b].begin == blocks[b].end && at == 0 && !found) continue;
+        if (blocks[b].begin == at && blocks[b].end > at) { at = blocks[b].end; found = 1; break; }
+      }
+      if (!found) break;
+      ++done;
+    }
+    int64_t covered = 0;
+    for (int b = 0; b < n_blocks; ++b) covered += blocks[b].end - blocks[b].begin;
+    if (at != h->m || covered != h->m) return fail(GLRM_ERR_INVALID, "arrival blocks must tile the rows [0, m) of X without gaps or overlaps");
+  }
+  return glrm_cpu_step_y(h, min_stepsize);
+}
+
 int glrm_cpu_step_x(glrm_cpu_handle* h, double min_stepsize) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
   return step_x_rows(h, 0, h->row_end - h->row_begin, min_stepsize);

@@ -115,6 +115,43 @@ def ill_conditioned(pa, X0, Y0, p, ref, seed, tries=8):
     return False, worst
 
 
+def engine_order_verdict(pa, X0, Y0, p, kw, got):
+    """Before a failing seed may be excused as ill-conditioned: where the oracle can ADD IN THE ENGINE'S ORDER (glrm_hip_sum_order ->
+    glrm_cpu_set_sum_order: the scalar-loss families on the caller's own lists), it must then reproduce the engine -- otherwise
+    something other than summation order separates the two and the seed is a FAILURE however unstable its trajectory is (the
+    probes of ill_conditioned ask about the oracle alone and would excuse a genuine engine bug on such a seed).
+    Returns "reproduced" | "not-reproduced" | "no-order" (general sweeps, a private re-ordered copy: the probes decide alone)."""
+    o_g, X_g, Y_g = got
+    api, capi = _capi.hip_api(), O.oracle_api()
+    h = api.create(pa, **kw)
+    try:
+        orders = [api.sum_order(h, 0), api.sum_order(h, 1)]
+    except _capi.GLRMError:
+        return "no-order", None
+    finally:
+        api.destroy(h)
+    if any(o.family not in (1, 2) or o.private_order for o in orders):
+        return "no-order", None
+    ho = capi.create(pa)
+    try:
+        try:
+            for w, o in enumerate(orders):
+                O.set_sum_order(ho, w, o)
+        except _capi.GLRMError:
+            return "no-order", None
+        X, Y = np.array(X0, order="F"), np.array(Y0, order="F")
+        o_e, _ = capi.fit(ho, p, X, Y)
+    finally:
+        capi.destroy(ho)
+    if len(o_e) != len(o_g):
+        return "not-reproduced", float("inf")
+    try:
+        e = max(cases.rel_err(o_g[1:], o_e[1:]), vec_err(X_g, X), vec_err(Y_g, Y))  # objective[0] is summed per shard block on both sides
+    except AssertionError:
+        return "not-reproduced", float("inf")
+    return ("reproduced" if e < TOL / 10 else "not-reproduced"), e
+
+
 def one(seed):
     g, p = fz.random_model(seed)
     pa = g.problem_arrays()
@@ -145,9 +182,13 @@ def one(seed):
             if not same:
                 return "SHARD-MISMATCH", fam, (stable, cases.rel_err(o_s, o_g[1:]), cases.fro_err(X_s, X_g), cases.fro_err(Y_s, Y_g))
         if not ok:
+            verdict, dev = engine_order_verdict(pa, X0, Y0, p, kw, (o_g, X_g, Y_g))
+            if verdict == "not-reproduced":
+                return "FAIL", fam, detail + (f"the oracle adding in the engine's reported order does not reproduce the engine: {dev:.2e}",)
             ill, worst = ill_conditioned(pa, X0, Y0, p, (o_c, X_c, Y_c), seed)
             if ill:
-                return "ill-conditioned", fam, detail + (f"oracle vs itself (accept test +- 4 ulps / reversed lists / 1e-13-perturbed starts): {worst:.2e}",)
+                return "ill-conditioned", fam, detail + (f"oracle vs itself (accept test +- 4 ulps / reversed lists / 1e-13-perturbed starts): {worst:.2e}; "
+                                                         f"oracle in the engine's order: {verdict}" + (f" ({dev:.1e})" if dev is not None else ""),)
         return ("ok" if ok else "FAIL"), fam, detail
     finally:
         for k_ in env:

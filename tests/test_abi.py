@@ -28,7 +28,7 @@ def ensure_built():
 def test_hip_library_exports_every_declared_symbol():
     ensure_built()
     names = declared("glrm_hip.h", "glrm_hip_")
-    assert len(names) == len(_capi.ABI_SYMBOLS) == 36
+    assert len(names) == len(_capi.ABI_SYMBOLS) == 37
     assert sorted("glrm_hip_" + s for s in _capi.ABI_SYMBOLS) == names
     lib = ctypes.CDLL(os.path.join(PKG, "libglrm_hip.so"))
     for n in names:
@@ -55,9 +55,9 @@ def test_oracle_exports_the_same_entry_points():
 
 def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_capi.CLoss) == 32 and ctypes.sizeof(_capi.CReg) == 16
-    assert ctypes.sizeof(_capi.CParams) == 56 and ctypes.sizeof(_capi.COptions) == 40
+    assert ctypes.sizeof(_capi.CParams) == 56 and ctypes.sizeof(_capi.COptions) == 48
     assert ctypes.sizeof(_capi.CProblem) == 8 * 2 + 4 * 2 + 8 * 4 + 8 * 6 + 8 * 6 + 8 * 2 + 4 * 2
-    assert ctypes.sizeof(_capi.CKernelStats) == 8 * 2 + 8 * 2 + 8 * 6 + 4 * 4
+    assert ctypes.sizeof(_capi.CKernelStats) == 8 * 2 + 8 * 2 + 8 * 6 + 4 * 4 + 8 and ctypes.sizeof(_capi.CArrival) == 24
     assert ctypes.sizeof(_capi.CSignature) == 40 and ctypes.sizeof(_capi.CMultiOptions) == 24
 
 

@@ -41,6 +41,24 @@ def test_c4_gather_column_sweep_is_priced_at_the_survey_bytes():
     assert r["best"]["frac"] == pytest.approx(0.812, abs=2e-3)  # profiles/r02_c4_bench.json
 
 
+def test_the_roofline_headline_is_one_kind_of_number_on_both_sides_of_one():
+    """the C4 Y half-step at 130.8 ms printed frac 0.876 (PMC) and at 131.7 ms frac 0.9946 (algorithmic).  Now `frac` is the
+    SURVEY 8(d) algorithmic fraction in both, `cache_served` flags it, `traffic_frac` stands beside it."""
+    fr = {}
+    for ms in (130.8, 131.7):
+        rl = bench.kernel_roofline("blocked", nnz=10**9, nseg=100_000, nopp=10_000_000, k=64, ld=64, ms=ms)
+        r = bench.roofline_block(rl, "col passes", ms, 10**9, 9.17e11, "pmc", {"hit_rate": 0.189})
+        assert r["bound"] == "hbm" and r["per_launch"] == 1048 * 10**9
+        assert r["frac"] == pytest.approx(1.048e12 / (ms * 1e-3) / 8e12) == r["algorithmic_frac"]
+        assert r["cache_served"] is True
+        assert r["traffic_frac"] == pytest.approx(9.17e11 / (ms * 1e-3) / 8e12) and r["traffic_frac"] < r["frac"]
+        fr[ms] = r["frac"]
+    assert fr[130.8] > 1.0 > fr[131.7] and abs(fr[130.8] - fr[131.7]) < 0.01   # 1 % apart in time, 1 % apart in the headline
+    slow = bench.roofline_block(bench.kernel_roofline("gather", nnz=10**9, nseg=100_000, nopp=10_000_000, k=64, ld=64, ms=161.3), "k", 161.3, 10**9, None, "off", None)
+    assert slow["cache_served"] is False and slow["traffic_frac"] is None and slow["frac"] == pytest.approx(0.812, abs=2e-3)
+    assert bench.side_summary(bench.kernel_roofline("blocked", nnz=10**9, nseg=100_000, nopp=10_000_000, k=64, ld=64, ms=120.0))["frac"] > 1.0
+
+
 def test_config_table():
     c4 = bench.CONFIGS["C4"]
     assert (c4["rows"], c4["cols"], c4["k"], c4["q"], c4["reg"][0]) == (10_000_000, 100_000, 64, 100, 3) and bench.nonneg_start(c4)

@@ -89,6 +89,95 @@ def test_subset_rejects_dense_parent():
         api.destroy(h)
 
 
+def test_subset_of_shard_parents_is_deferred_until_the_host_finalizes(monkeypatch):
+    """include/glrm_hip.h, glrm_hip_subset: the child of ONE SHARD is a shard of the subset problem and comes back in the
+    GLRM_PROBLEM_DEFER_SETUP state -- step calls fail until the host has combined the children's signatures and finalized every child.
+    Two shard parents -> subset -> combine -> finalize -> three outer iterations on shared buffers == the child of the single-shard
+    parent, bit for bit.  A finalize that fails half way latches: the retry is refused, the handle can only be destroyed."""
+    import torch
+    rng = np.random.default_rng(11)
+    g = model(rng, 2000, 96, 4, 0.4)
+    pa = g.problem_arrays()
+    rt = rng.integers(0, 3, len(g._colidx)).astype(np.uint8)
+    ct = rng.integers(0, 3, len(g._rowidx)).astype(np.uint8)
+    X0, Y0 = np.asfortranarray(g.X), np.asfortranarray(g.Y)
+    p = L.ProxGradParams(max_iter=3, abs_tol=0.0, rel_tol=-1.0)
+    api = hip()
+    # the single-shard parent's child is ready on return
+    h = api.create(pa)
+    hc = api.subset(h, rt, ct, 1, True)
+    api.destroy(h)
+    try:
+        X1, Y1 = X0.copy(order="F"), Y0.copy(order="F")
+        obj1, _ = api.fit(hc, p, X1, Y1)
+    finally:
+        api.destroy(hc)
+    rbs, cbs = [0, 900, 2000], [0, 40, 96]
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    parents, kids = [], []
+    try:
+        for s in range(2):
+            parents.append(api.create(cases.shard_of(pa, rbs[s], rbs[s + 1], cbs[s], cbs[s + 1]), stream=stream, defer=True))
+        whole = _capi.CSignature.combine([api.signature(q) for q in parents])
+        with pytest.raises(_capi.GLRMError):  # an un-finalized parent cannot be subset
+            api.subset(parents[0], rt[: int(pa.rowptr[rbs[1]])], ct[: int(pa.colptr[cbs[1]])], 1, True)
+        for q in parents:
+            api.finalize(q, whole)
+        for s in range(2):
+            r0, r1, c0, c1 = int(pa.rowptr[rbs[s]]), int(pa.rowptr[rbs[s + 1]]), int(pa.colptr[cbs[s]]), int(pa.colptr[cbs[s + 1]])
+            kids.append(api.subset(parents[s], rt[r0:r1], ct[c0:c1], 1, True))
+        for q in parents:
+            api.destroy(q)
+        parents = []
+        for c in kids:  # deferred: nothing steps before the combined finalize
+            with pytest.raises(_capi.GLRMError) as ei:
+                api.step_x(c, 0.01)
+            assert ei.value.code == _capi.ERR_INVALID
+        sub_whole = _capi.CSignature.combine([api.signature(c) for c in kids])
+        assert sub_whole.nnz_rows == int((rt != 1).sum()) and sub_whole.nnz_cols == int((ct != 1).sum())
+        for c in kids:
+            api.finalize(c, sub_whole)
+        with pytest.raises(_capi.GLRMError):  # once
+            api.finalize(kids[0], sub_whole)
+        ld = api.factor_ld(kids[0])
+        dX, dY = torch.zeros(pa.m * ld, dtype=torch.float64, device=dev), torch.zeros(pa.n * ld, dtype=torch.float64, device=dev)
+        dC, dR = torch.zeros(pa.n, dtype=torch.float64, device=dev), torch.zeros(pa.m, dtype=torch.float64, device=dev)
+        for c in kids:
+            api.bind_buffers(c, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())
+        api.set_factors(kids[0], X0, Y0)
+        objs = []
+        for c in kids:
+            api.reset_stepsizes(c, p.stepsize)
+        for _ in range(p.max_iter):
+            for c in kids:
+                api.step_x(c, p.min_stepsize)
+            for c in kids:
+                api.step_y(c, p.min_stepsize)
+            objs.append(api.sum(kids[0], dC.data_ptr(), pa.n))
+        X2, Y2 = np.zeros_like(X0), np.zeros_like(Y0)
+        api.get_factors(kids[0], X2, Y2)
+        assert np.array_equal(np.array(objs), obj1[1:]) and np.array_equal(X2, X1) and np.array_equal(Y2, Y1)
+    finally:
+        for q in parents + kids:
+            api.destroy(q)
+    # the latch: a set-up that failed half way refuses a second finalize
+    monkeypatch.setenv("GLRM_HIP_TEST_FAIL_FINALIZE", "1")
+    q = api.create(cases.shard_of(pa, 0, 900, 0, 40), defer=True)
+    try:
+        with pytest.raises(_capi.GLRMError) as ei:
+            api.finalize(q, whole)
+        assert "injected" in str(ei.value)
+        monkeypatch.delenv("GLRM_HIP_TEST_FAIL_FINALIZE")
+        with pytest.raises(_capi.GLRMError) as ei:
+            api.finalize(q, whole)
+        assert ei.value.code == _capi.ERR_INVALID and "earlier glrm_hip_finalize" in str(ei.value)
+        with pytest.raises(_capi.GLRMError):
+            api.step_x(q, 0.01)
+    finally:
+        api.destroy(q)
+
+
 @pytest.mark.parametrize("kind", ["quad", "categorical"])
 def test_cross_validate_hip_vs_oracle(kind):
     rng = np.random.default_rng(11)

@@ -400,3 +400,31 @@ def test_a_line_search_of_two_hundred_rounds_runs_to_its_end(monkeypatch, family
     for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
         assert abs(st_g[key] - st_c[key]) <= max(5, 1e-3 * st_c[key]), (key, st_g[key], st_c[key])
     assert cases.rel_err(o_g, o_c) < TOL and cases.fro_err(X_g, X_c) < TOL and cases.fro_err(Y_g, Y_c) < TOL
+
+
+@pytest.mark.parametrize("family", ["tiled", "blocked", "gather"])
+def test_a_step_size_that_lands_exactly_on_the_minimum_ends_the_search(monkeypatch, family):
+    """`while alpha > min_stepsize` (src/algorithms/proxgrad.jl:136,180): a rejected trial that shrinks alpha to EXACTLY min_stepsize
+    neither resets it to 1.1 min (that needs alpha < min) nor takes another trial.  stepsize 1.0, min_stepsize 0.7: 1.0 * 0.7 is the double
+    0.7.  A = 0, X0 = 0: every gradient is exactly 0, every trial point equals the current point, J' == J rejects -- in any summation
+    order.  Iteration 1: one trial per segment, alpha = 0.7; iteration 2: no trial at all.  (the round state machines of the
+    pass families went on while `!(alpha < min)` and took a second trial, ending at alpha = 0.77.)"""
+    if family == "blocked":
+        force_blocked(monkeypatch)
+    m, n, k, q = 3000, 1200, 32, 120
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, q, value_model=0)
+    rowvals[:] = 0.0
+    colvals[:] = 0.0
+    X0 = np.zeros_like(X0)
+    one = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(0, 0, 1.0)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, one, reg, reg)
+    params = L.ProxGradParams(stepsize=1.0, max_iter=2, abs_tol=0.0, rel_tol=-1.0, min_stepsize=0.7)
+    O.set_threads(4)
+    o_c, X_c, Y_c, st_c = cases.run_engine(O.oracle_api(), pa, X0, Y0, params)
+    assert (st_c["trials_x"], st_c["trials_y"], st_c["accepts_x"], st_c["accepts_y"]) == (m, n, 0, 0)
+    o_g, X_g, Y_g, st_g = cases.run_engine(hip(), pa, X0, Y0, params, tiled={"tiled": 2, "blocked": 1, "gather": 1}[family])
+    want = {"tiled": 3, "blocked": BLOCKED_ROWS | BLOCKED_COLS, "gather": 0}[family]
+    assert st_g["tiled"] & want == want
+    assert (st_g["trials_x"], st_g["trials_y"], st_g["accepts_x"], st_g["accepts_y"]) == (m, n, 0, 0)
+    assert np.array_equal(o_g, o_c) and np.array_equal(X_g, X_c) and np.array_equal(Y_g, Y_c)

@@ -61,6 +61,10 @@ def test_jref_trajectory_and_factor_samples(config, capsys):
     assert ref["trajectory"]["max_rel"] < max(1e-5 if own["max_rel_over_trajectory"] < 1e-6 else 0.0, lim), (ref["trajectory"], own)
     assert ref["X_sample_rel_fro"] < max(1e-5 if own["X_sample_rel_fro"] < 1e-6 else 0.0, 1.5 * own["X_sample_rel_fro"] + 1e-6), (ref, own)
     assert ref["Y_sample_rel_fro"] < max(1e-5 if own["Y_sample_rel_fro"] < 1e-6 else 0.0, 1.5 * own["Y_sample_rel_fro"] + 1e-6), (ref, own)
+    # ... and absolute caps, so that the relative-to-oracle bound above cannot drift with the oracle: the north star's 1e-5 on the
+    # objective trajectory holds on both recipes as measured (C4: 7.9e-6); the factor samples of the chaotic NNMF recipe stay below 1e-2
+    assert ref["trajectory"]["max_rel"] < 1e-5, ref["trajectory"]
+    assert ref["X_sample_rel_fro"] < 1e-2 and ref["Y_sample_rel_fro"] < 1e-2, ref
     ls = ref["line_search_agreement"]
     for key, v in ls.items():  # accept / reject agreement rate
         assert abs(v["gpu"] - v["cpu"]) <= 0.01 * v["cpu"] + 5, (key, v)

@@ -213,6 +213,18 @@ def test_sum_order_is_refused_where_the_oracle_cannot_follow():
         with pytest.raises(_capi.GLRMError):
             O.set_sum_order(h, 0, o)
         O.set_sum_order(h, 0, O.make_sum_order("strided", 4, 2))
+        # (64 / lanes) x waves lane groups per segment must fit the oracle's 128-group buffers (two lanes on eight waves
+        # smashed the stack); the same layouts pinned to few enough waves are fine
+        for lanes, comps in ((2, 4), (1, 8)):
+            with pytest.raises(_capi.GLRMError):
+                O.set_sum_order(h, 0, O.make_sum_order("strided", lanes, comps))
+            with pytest.raises(_capi.GLRMError):
+                O.set_sum_order(h, 0, O.make_sum_order("strided", lanes, comps, waves=8))
+        O.set_sum_order(h, 0, O.make_sum_order("strided", 2, 4, waves=4))
+        O.set_sum_order(h, 0, O.make_sum_order("strided", 1, 8, waves=2))
+        O.set_sum_order(h, 0, O.make_sum_order("strided", 2, 4, waves=2, cached_maxlen=10, cached_waves=4))
+        with pytest.raises(_capi.GLRMError):
+            O.set_sum_order(h, 0, O.make_sum_order("strided", 1, 8, waves=2, cached_maxlen=10, cached_waves=4))
         assert api.sum_order(h, 0).asdict()["family_name"] == "strided" and api.sum_order(h, 1).asdict()["family_name"] == "reference"
         O.set_sum_order(h, 0, None)
         assert api.sum_order(h, 0).asdict()["family_name"] == "reference"
