@@ -728,6 +728,10 @@ def inlib_host(args):
     library's own per-iteration clock (the `seconds` array = ch.times, src/convergence.jl:22-26: every iteration ends with a device
     synchronisation on every shard), so the factors' trip over PCIe at the start and end of the call is outside the timed region like
     in the other host.  --shared-device: all N shards on device 0 (a box with one GPU: the code path, not the speed)."""
+    if args.shared_device:
+        # N compute streams + N link streams (+ the engine's side streams) on ONE device: the runtime maps streams onto GPU_MAX_HW_QUEUES
+        # hardware queues (default 4) and a queue standing in an emulated link wait would hold up every stream that shares it
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", str(min(32, 2 * args.gpus + 8)))
     import numpy as np
     import torch
     from lowrankmodels.jl_amd import _capi
@@ -750,40 +754,72 @@ def inlib_host(args):
     pa, X0, Y0 = host_problem(args, cfg, m, n, k, q, device)
     t_gen = time.time() - t0
     torch.cuda.empty_cache()
-    t0 = time.time()
     ids = [0] * N if args.shared_device else list(range(N))
-    mh = api.multi_create(pa, N, device_ids=ids, exchange=args.inlib_exchange, x_chunks=args.x_chunks if N > 1 else 0, profile=1,
-                          waves_row=args.waves_row, waves_col=args.waves_col, tiled=args.tiled)
-    t_create = time.time() - t0
-    try:
-        prm = ProxGradParams(max_iter=args.warmup + args.steps, abs_tol=-1e300, rel_tol=-1e300)
-        X, Y = X0, Y0
-        t0 = time.perf_counter()
-        obj, sec = api.multi_fit(mh, prm, X, Y)
-        wall = time.perf_counter() - t0
-        info = api.multi_info(mh, N)
-    finally:
-        api.multi_destroy(mh)
-    assert len(sec) == args.warmup + args.steps + 1, len(sec)
-    elapsed = float(sec[-1] - sec[args.warmup])
+    prm = ProxGradParams(max_iter=args.warmup + args.steps, abs_tol=-1e300, rel_tol=-1e300)
     nnz = int(pa.rowptr[-1])
+
+    def one_fit(link_gbps):
+        """ONE create + multi_fit with the link emulator at link_gbps GB/s per direction (0 = off: copies take what they take)."""
+        if link_gbps > 0:
+            os.environ["GLRM_EXCHANGE_EMULATE_GBPS"] = repr(float(link_gbps))
+        else:
+            os.environ.pop("GLRM_EXCHANGE_EMULATE_GBPS", None)
+        t0 = time.time()
+        mh = api.multi_create(pa, N, device_ids=ids, exchange=args.inlib_exchange, x_chunks=args.x_chunks if N > 1 else 0, profile=1,
+                              waves_row=args.waves_row, waves_col=args.waves_col, tiled=args.tiled, arrival=args.arrival)
+        t_create = time.time() - t0
+        try:
+            X, Y = np.array(X0, order="F"), np.array(Y0, order="F")
+            t0 = time.perf_counter()
+            obj, sec = api.multi_fit(mh, prm, X, Y)
+            wall = time.perf_counter() - t0
+            info = api.multi_info(mh, N)
+        finally:
+            api.multi_destroy(mh)
+            os.environ.pop("GLRM_EXCHANGE_EMULATE_GBPS", None)
+        assert len(sec) == args.warmup + args.steps + 1, len(sec)
+        return {"ms_per_step": 1e3 * float(sec[-1] - sec[args.warmup]) / args.steps, "obj": obj, "info": info, "wall": wall, "create_s": t_create}
+
+    run = one_fit(args.emulate_link_gbps)
+    base = one_fit(0.0) if args.emulate_link_gbps > 0 else None  # the same fit with free copies: what the link adds is the difference
+    obj, info, elapsed = run["obj"], run["info"], run["ms_per_step"] * 1e-3 * args.steps
+    host = {"kind": "in-library (glrm_hip_multi_create / glrm_hip_multi_fit): what julia/HipGLRM.jl ccalls for HipProxGradParams(ngpus = N)",
+            "exchange_used": {0: "direct peer pushes (hipMemcpyPeerAsync, one copy stream per (source, destination) pair)", 1: "RCCL ncclAllGather / grouped broadcasts"}.get(info["exchange"], info["exchange"]),
+            "arrival_order": {0: "on (default)", 1: "on", 2: "off: the Y half-step waits for the whole X exchange"}[args.arrival] + (
+                "" if args.arrival == 2 else ": the Y half-step consumes the peers' row chunks of X as their copy events fire (glrm_hip_step_y_arrival)"),
+            "exchange_ms_per_step_exposed": info["exchange_ms"] / max(args.warmup + args.steps, 1),
+            "exchange_ms_is": "time the compute streams stood waiting for blocks that had not arrived (Y-block exchange: end of the sweeps to the last "
+                              "arrival; X: the waits inside the arrival-ordered Y half-step), max over shards, summed over the call, per iteration",
+            "row_bounds": info["row_bounds"], "col_bounds": info["col_bounds"], "x_chunks": args.x_chunks if N > 1 else 0,
+            "shared_device": bool(args.shared_device),
+            "timed_region": "iterations warmup+1 .. warmup+steps of ONE glrm_hip_multi_fit call on the library's per-iteration clock (ch.times)",
+            "whole_call_wall_s_incl_factor_transfers_and_prologue": run["wall"],
+            "model_ms": {"X_block": exchange_model_ms((m // N) * k * 8, N), "Y_block": exchange_model_ms((n // N) * k * 8, N)}}
+    if base is not None:
+        share = max(ids.count(d) for d in set(ids))
+        dil = int(os.environ.get("GLRM_EXCHANGE_EMULATE_DILATE", share))
+        host["link_emulation"] = {
+            "GBps_per_direction_and_link": args.emulate_link_gbps, "dilation": dil,
+            "is": "every direct push occupies its link for bytes / (rate / dilation) from the moment its source rows were complete "
+                  "(csrc/glrm_multigpu.hip: LinkEmu); dilation = shards per device: they time-share one GPU, so compute is that many times "
+                  "slower than on as many GPUs and a transfer is slowed alike to keep its proportion to the compute",
+            "ms_per_step_with_link": run["ms_per_step"], "ms_per_step_with_free_copies": base["ms_per_step"],
+            "exchange_exposed_ms_per_step": run["ms_per_step"] - base["ms_per_step"],
+            "exchange_exposed_frac_of_step": (run["ms_per_step"] - base["ms_per_step"]) / run["ms_per_step"],
+            "same_objective_bits_both_runs": bool(np.array_equal(run["obj"], base["obj"])),
+            "X_block_link_ms_undilated": exchange_model_ms((m // N) * k * 8, N, args.emulate_link_gbps)["direct"],
+            "what_it_cannot_show": "N shards on ONE device do not run in lockstep like N devices do (the hardware interleaves their kernels), and "
+                                   "their copies share one HBM: the figure is the exchange the schedule leaves exposed, not a prediction of an "
+                                   "8-GPU iteration time"}
     out = {"metric": "observed-entry updates/sec", "value": args.steps * 2.0 * nnz / elapsed, "unit": "updates/s", "n_gpus": N, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
            "dtype": "f64", "data": "synthetic",
            "config": {"workload": cfg["text"].format(m=m, n=n, k=k, pct=100.0 * q / n) + f" ({nnz} observations), ProxGradParams defaults, stop rule off",
                       "name": args.config, "m": m, "n": n, "k": k, "observed": nnz, "host": "inlib",
                       "parallelism": f"glrm_hip_multi_fit: ONE host process, rows/cols in {N} nnz-balanced blocks on devices {ids}, X,Y replicated"},
-           "host": {"kind": "in-library (glrm_hip_multi_create / glrm_hip_multi_fit): what julia/HipGLRM.jl ccalls for HipProxGradParams(ngpus = N)",
-                    "exchange_used": {0: "direct peer pushes (hipMemcpyPeerAsync, one copy stream per (source, destination) pair)", 1: "RCCL ncclAllGather / grouped broadcasts"}.get(info["exchange"], info["exchange"]),
-                    "exchange_ms_per_step_exposed": info["exchange_ms"] / max(args.warmup + args.steps, 1),
-                    "exchange_ms_is": "wall time between the end of a half-step's sweeps and the arrival of the last block, summed over the call, per iteration",
-                    "row_bounds": info["row_bounds"], "col_bounds": info["col_bounds"], "x_chunks": args.x_chunks if N > 1 else 0,
-                    "shared_device": bool(args.shared_device),
-                    "timed_region": "iterations warmup+1 .. warmup+steps of ONE glrm_hip_multi_fit call on the library's per-iteration clock (ch.times)",
-                    "whole_call_wall_s_incl_factor_transfers_and_prologue": wall,
-                    "model_ms": {"X_block": exchange_model_ms((m // N) * k * 8, N), "Y_block": exchange_model_ms((n // N) * k * 8, N)}},
+           "host": host,
            "objective": {"initial": float(obj[0]), "after_warmup_and_steps": float(obj[-1])},
-           "setup_s": {"generate_and_copy_to_host": t_gen, "multi_create": t_create}}
+           "setup_s": {"generate_and_copy_to_host": t_gen, "multi_create": run["create_s"]}}
     print(json.dumps(out), flush=True)
     return out
 
@@ -793,7 +829,8 @@ def inlib_child(args, n_gpus, timeout_s=420, shared_device=False):
     with its shards on one device must not take the job's line with it): returns the child's JSON line, or what went wrong."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--host", "inlib", "--gpus", str(n_gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--config", args.config, "--rows", str(args.rows), "--cols", str(args.cols), "--obs-per-row", str(args.obs_per_row), "--rank", str(args.k),
-           "--seed", str(args.seed), "--tiled", str(args.tiled), "--x-chunks", str(args.x_chunks), "--waves-row", str(args.waves_row), "--waves-col", str(args.waves_col)]
+           "--seed", str(args.seed), "--tiled", str(args.tiled), "--x-chunks", str(args.x_chunks), "--waves-row", str(args.waves_row), "--waves-col", str(args.waves_col),
+           "--arrival", str(args.arrival), "--emulate-link-gbps", str(args.emulate_link_gbps)]
     if shared_device:
         cmd.append("--shared-device")
     env = {k_: v for k_, v in os.environ.items() if k_ not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK",
@@ -898,6 +935,10 @@ def main():
                     "process drives --gpus N devices through glrm_hip_multi_create / glrm_hip_multi_fit (what the Julia shim ccalls)")
     ap.add_argument("--shared-device", action="store_true", help="--host inlib: every shard on device 0 (one-GPU box: the code path, not the speed)")
     ap.add_argument("--inlib-exchange", type=int, default=0, choices=[0, 1], help="--host inlib: 0 direct peer pushes, 1 RCCL")
+    ap.add_argument("--arrival", type=int, default=0, choices=[0, 1, 2], help="--host inlib: glrm_multi_options.arrival (0 / 1: the Y half-step consumes "
+                    "the X chunks in arrival order; 2: it waits for the whole exchange, the round-4 schedule)")
+    ap.add_argument("--emulate-link-gbps", type=float, default=0.0, help="--host inlib: emulate an xGMI link of this many GB/s per direction on the "
+                    "direct pushes (GLRM_EXCHANGE_EMULATE_GBPS) and run the same fit once more with free copies: the difference is the exposed exchange")
     ap.add_argument("--no-inlib-leg", action="store_true", help="N > 1 under torch.distributed.run: skip the in-library host's run that rank 0 adds to the line")
     ap.add_argument("--cpu-full", action="store_true", help="one warm-up + one timed iteration of the CPU oracle on the FULL lists of the config (minutes, tens of GB of host memory)")
     args = ap.parse_args()
@@ -1011,6 +1052,8 @@ def main():
     # what the exchanges added to the iterations of the timed region (events on the rank's stream around every exchange; with row
     # chunks: the wait for the chunks the pipeline did not hide), and the set-up probe that picked the exchange (N > 2 on RCCL)
     exch = sf.exchange_times() if world > 1 else None
+    if exch is not None:  # arrival order: the X exchange is waited for block by block inside the Y half-step (glrm_hip_step_y_arrival)
+        exch["x"] += st.get("ms_wait_y", 0.0)
 
     # The reference's own run at full size -- default ProxGradParams(), stop rule of src/algorithms/proxgrad.jl:210-213, from the same
     # X0, Y0 -- timed end to end on the GPU (the CPU-derived J_ref leg is `to_ref_objective`).

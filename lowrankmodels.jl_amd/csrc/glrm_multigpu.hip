@@ -64,7 +64,9 @@ struct Rccl {
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
   Rccl() {
-    void* lib = dlopen("librccl.so", RTLD_LAZY | RTLD_LOCAL);
+    const char* path = getenv("GLRM_HIP_RCCL_LIB"); // another build of the library -- or the test suite's stand-in (tests/stubs/rccl_stub.cpp)
+    void* lib = (path && *path) ? dlopen(path, RTLD_LAZY | RTLD_LOCAL) : nullptr;
+    if (!lib) lib = dlopen("librccl.so", RTLD_LAZY | RTLD_LOCAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_LAZY | RTLD_LOCAL);
     if (!lib) return;
     CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
@@ -562,7 +564,8 @@ static int multi_create_impl(glrm_multi* mh, const glrm_problem* p, const glrm_o
   const int want = env_int("GLRM_HIP_EXCHANGE_RCCL", mo->exchange);
   if (want == 1 && n > 1) {
     Rccl& R = Rccl::get();
-    if (R.ok && distinct) {
+    // RCCL wants one device per rank; GLRM_HIP_RCCL_ALLOW_SHARED=1 lifts that for the test suite's stand-in library
+    if (R.ok && (distinct || env_int("GLRM_HIP_RCCL_ALLOW_SHARED", 0))) {
       mh->comms.assign(n, nullptr);
       const int e = R.CommInitAll(mh->comms.data(), n, mh->dev.data());
       if (e) return fail(GLRM_ERR_COMM, "ncclCommInitAll failed: %s", R.GetErrorString ? R.GetErrorString(e) : "?");

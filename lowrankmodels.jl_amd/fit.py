@@ -245,6 +245,11 @@ class ShardedFit:
         # proceeds on a side stream while the next chunk is swept (rows are independent).  Needs equal row blocks.
         nrows = [row_bounds[r + 1] - row_bounds[r] for r in range(self.world)]
         self.x_chunks = int(x_chunks) if (self.world > 1 and x_chunks > 1 and len(set(nrows)) == 1 and nrows[0] % x_chunks == 0) else 1
+        # Arrival order (include/glrm_hip.h: glrm_hip_step_y_arrival): the Y half-step is told which rows of X each chunk exchange
+        # fills and the event behind it, instead of waiting for the whole pipelined exchange between the half-steps; GLRM_ARRIVAL=0
+        # restores the wait
+        self._arrival = self.x_chunks > 1 and os.environ.get("GLRM_ARRIVAL", "1") != "0"
+        self._arrival_blocks, self._arrival_events = None, []
         if self.x_chunks > 1:
             c = nrows[0] // self.x_chunks
             self._stage = [torch.empty(self.world * c * self.ld, dtype=torch.float64, device=self.device) for _ in range(self.x_chunks)]
@@ -390,6 +395,7 @@ class ShardedFit:
         S, ld, rb = self.x_chunks, self.ld, self.row_bounds
         c = (rb[self.rank + 1] - rb[self.rank]) // S
         cuda = self.device.type == "cuda"
+        blocks, events = [(rb[self.rank], rb[self.rank + 1], None)], []
         for j in range(S):
             api.step_x_range(h, j * c, (j + 1) * c, params.min_stepsize)
             own = self.dX[(rb[self.rank] + j * c) * ld: (rb[self.rank] + (j + 1) * c) * ld]
@@ -405,6 +411,10 @@ class ShardedFit:
                         for q in range(self.world):
                             if q != self.rank:
                                 self.dX[(rb[q] + j * c) * ld: (rb[q] + (j + 1) * c) * ld].copy_(self._stage[j][q * c * ld: (q + 1) * c * ld], non_blocking=True)
+                    if self._arrival:  # chunk j of every peer is in place once this event has fired
+                        done = torch.cuda.Event()
+                        done.record(self._comm_stream)
+                        events.append(done)
             elif self._p2p:
                 self._p2p_ranges(self.dX, [((rb[q] + j * c) * ld, (rb[q] + (j + 1) * c) * ld) for q in range(self.world)])
             else:
@@ -412,6 +422,14 @@ class ShardedFit:
                 for q in range(self.world):
                     if q != self.rank:
                         self.dX[(rb[q] + j * c) * ld: (rb[q] + (j + 1) * c) * ld].copy_(self._stage[j][q * c * ld: (q + 1) * c * ld])
+            if self._arrival:
+                ev = events[-1].cuda_event if cuda else None
+                # peers in ring order from this rank (the order a direct exchange delivers in; with one event per chunk it only
+                # matters as the order in which the super-tiles are launched)
+                blocks += [(rb[q] + j * c, rb[q] + (j + 1) * c, ev) for q in ((self.rank + d) % self.world for d in range(1, self.world))]
+        if self._arrival:  # the first inner Y sweep waits block by block (iteration: step_y_arrival); nothing to wait for here
+            self._arrival_blocks, self._arrival_events = blocks, events
+            return
         if cuda:
             if self._profile:  # what the pipeline did NOT hide: the wait for the last chunks
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -447,8 +465,12 @@ class ShardedFit:
         else:
             api.step_x(h, params.min_stepsize)
             self._timed_gather("x", self.dX, self.row_bounds, self.ld)  # inner X sweeps only touch own rows: gather once
-        for _ in range(params.inner_iter_Y):
-            api.step_y(h, params.min_stepsize)
+        for it in range(params.inner_iter_Y):
+            if it == 0 and self._arrival_blocks is not None:
+                api.step_y_arrival(h, params.min_stepsize, self._arrival_blocks)  # returns with every event waited for on the stream
+                self._arrival_blocks = None
+            else:
+                api.step_y(h, params.min_stepsize)
         self._timed_gather("y", self.dY, self.y_bounds, self.ld)
         self._timed_gather("objective", self.dObjCol, self.col_bounds, 1)
         return api.sum(h, self.dObjCol.data_ptr(), self.n)

@@ -428,3 +428,97 @@ def test_a_step_size_that_lands_exactly_on_the_minimum_ends_the_search(monkeypat
     assert st_g["tiled"] & want == want
     assert (st_g["trials_x"], st_g["trials_y"], st_g["accepts_x"], st_g["accepts_y"]) == (m, n, 0, 0)
     assert np.array_equal(o_g, o_c) and np.array_equal(X_g, X_c) and np.array_equal(Y_g, Y_c)
+
+
+# ------------------------------------------------------------------------------------------------ the Y half-step while X is arriving
+
+def test_arrival_order_y_half_step_gives_the_bits_of_step_y(monkeypatch):
+    """glrm_hip_step_y_arrival (include/glrm_hip.h): the phase-aligned column passes launch each super-tile of X behind the events of the
+    blocks it touches, in the order the host announces them -- own rows first, then the peers' chunks.  Partial sums are per (column,
+    super-tile) and col_reduce adds them in super-tile order, so the result is glrm_hip_step_y's bit for bit whatever the order.  The
+    events here fire late (a side stream that sleeps before each record): the launches really stand behind them.  Profile: the waits are
+    accounted in kernel_stats.ms_wait_y.  Bad block lists are refused."""
+    import torch
+    force_blocked(monkeypatch)           # one tile unit per super-tile: 6000 rows of X = dozens of super-tiles
+    pa, X0, Y0, _, _ = c4_problem(6000, 600, 100)
+    api = hip()
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.current_stream().cuda_stream
+    side = torch.cuda.Stream(device=dev)
+
+    def run(arrival):
+        h = api.create(pa, stream=stream, profile=1)
+        try:
+            assert api.kernel_stats(h)["tiled"] & BLOCKED_COLS
+            api.set_factors(h, X0, Y0)
+            api.reset_stepsizes(h, 1.0)
+            objs = []
+            for it in range(3):
+                api.step_x(h, 0.01)
+                if arrival:
+                    # "own" rows 1500..3000 are there; the rest is announced in chunks of 750 rows, peers interleaved, by events the
+                    # side stream records one after the other with a pause in front of each
+                    chunks = [(lo, lo + 750) for lo in (0, 3000, 750, 3750, 4500, 5250)]
+                    blocks, keep = [(1500, 3000, None)], []
+                    with torch.cuda.stream(side):
+                        side.wait_stream(torch.cuda.current_stream())
+                        for lo, hi in chunks:
+                            torch.cuda._sleep(400_000)         # a pause in front of every arrival (0.2 - 4 ms: the counter's rate differs between devices)
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                            keep.append(ev)
+                            blocks.append((lo, hi, ev.cuda_event))
+                    if it == 1:
+                        blocks = blocks[::-1]                    # any order the host likes
+                    api.step_y_arrival(h, 0.01, blocks)
+                else:
+                    api.step_y(h, 0.01)
+                ld = api.factor_ld(h)
+                X, Y = np.zeros_like(X0), np.zeros_like(Y0)
+                api.get_factors(h, X, Y)
+                objs.append((X.copy(), Y.copy()))
+            st = api.kernel_stats(h)
+            if arrival:  # refusals: a gap, an overlap, rows out of range
+                for bad in ([(0, 3000, None), (3500, 6000, None)], [(0, 3500, None), (3000, 6000, None)], [(0, 7000, None)], [(0, 3000, None)]):
+                    with pytest.raises(_capi.GLRMError) as ei:
+                        api.step_y_arrival(h, 0.01, bad)
+                    assert ei.value.code == _capi.ERR_INVALID
+        finally:
+            api.destroy(h)
+        return objs, st
+
+    plain, st0 = run(False)
+    arr, st1 = run(True)
+    for (Xa, Ya), (Xp, Yp) in zip(arr, plain):
+        assert np.array_equal(Xa, Xp) and np.array_equal(Ya, Yp)
+    for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
+        assert st1[key] == st0[key]
+    assert st0["ms_wait_y"] == 0.0 and st1["ms_wait_y"] > 0.0      # the launch stream did stand in front of late blocks (most of the pauses hide behind the super-tiles already there)
+
+
+def test_arrival_order_on_a_family_that_needs_all_of_x_waits_for_everything(monkeypatch):
+    """Every family but the phase-aligned column passes walks X in one kernel: step_y_arrival then waits for all events and runs step_y."""
+    import torch
+    pa, X0, Y0, _, _ = c4_problem(3000, 300, 100)
+    api = hip()
+    res = {}
+    for arrival in (False, True):
+        h = api.create(pa, stream=torch.cuda.current_stream().cuda_stream, tiled=1)
+        try:
+            assert not api.kernel_stats(h)["tiled"] & BLOCKED_COLS
+            api.set_factors(h, X0, Y0)
+            api.reset_stepsizes(h, 1.0)
+            for _ in range(2):
+                api.step_x(h, 0.01)
+                if arrival:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    api.step_y_arrival(h, 0.01, [(2000, 3000, ev.cuda_event), (0, 2000, None)])
+                else:
+                    api.step_y(h, 0.01)
+            X, Y = np.zeros_like(X0), np.zeros_like(Y0)
+            api.get_factors(h, X, Y)
+            res[arrival] = (X, Y)
+        finally:
+            api.destroy(h)
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])

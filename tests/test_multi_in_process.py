@@ -131,3 +131,81 @@ def test_hip_multi_rccl_single_device_falls_back_or_runs():
         o, X, Y, info = run_multi(api, pa, kwargs["X"], kwargs["Y"], params, n, device_ids=[0] * n, exchange=1)
         assert np.array_equal(o[1:], o1[1:]) and np.array_equal(X, X1)
         assert info["exchange"] == 0
+
+
+def test_oracle_step_y_arrival_is_step_y_and_validates_the_block_list():
+    """The checker's twin of glrm_hip_step_y_arrival: nothing to wait for in one address space; the block list is validated like the
+    engine validates it (the blocks tile the rows [0, m) of X) and the half-step is glrm_cpu_step_y."""
+    kwargs, params = cases.build_golden_case("nnmf")
+    pa = L.GLRM(**kwargs).problem_arrays()
+    api = O.oracle_api()
+    res = {}
+    for arrival in (False, True):
+        h = api.create(pa)
+        try:
+            api.set_factors(h, np.asfortranarray(kwargs["X"]), np.asfortranarray(kwargs["Y"]))
+            api.reset_stepsizes(h, params.stepsize)
+            for _ in range(3):
+                api.step_x(h, params.min_stepsize)
+                if arrival:
+                    api.step_y_arrival(h, params.min_stepsize, [(20, 45, None), (0, 20, None), (45, pa.m, None), (7, 7, None)])
+                else:
+                    api.step_y(h, params.min_stepsize)
+            X, Y = np.zeros_like(kwargs["X"], order="F"), np.zeros_like(kwargs["Y"], order="F")
+            api.get_factors(h, X, Y)
+            res[arrival] = (X, Y)
+            if arrival:
+                for bad in ([(0, 20, None), (25, pa.m, None)], [(0, 30, None), (20, pa.m, None)], [(0, pa.m + 1, None)], [(0, 20, None)]):
+                    with pytest.raises(_capi.GLRMError):
+                        api.step_y_arrival(h, params.min_stepsize, bad)
+        finally:
+            api.destroy(h)
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("emulate", ["off", "wait-value", "delay-kernel"])
+def test_hip_multi_arrival_order_and_link_emulation(monkeypatch, emulate):
+    """The in-library host on 4 shards of one device, phase-aligned passes forced (many super-tiles per block of X): arrival order on
+    (glrm_multi_options.arrival = 0 / 1) and off (2), 1 / 4 row chunks -- every combination gives the single-device bits.  With the
+    link emulator (GLRM_EXCHANGE_EMULATE_GBPS; both mechanisms) the bits stay and an iteration cannot be faster than its X block needs
+    on the emulated link."""
+    import time
+    monkeypatch.setenv("GLRM_HIP_BLOCKED", "3")
+    monkeypatch.setenv("GLRM_HIP_BLOCKED_TPS", "1")
+    monkeypatch.setenv("GLRM_HIP_BLOCKED_FILL", "3")
+    monkeypatch.setenv("GLRM_HIP_CACHED", "0")
+    m, n, k = 8000, 800, 64
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, 100, value_model=1)
+    one = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(3, 0, 1.0)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, one, reg, reg)
+    X0, Y0 = np.asfortranarray(np.abs(X0) / 8.0), np.asfortranarray(np.abs(Y0) / 8.0)
+    iters = 5
+    params = L.ProxGradParams(max_iter=iters, abs_tol=0.0, rel_tol=-1.0)
+    api = _capi.hip_api()
+    o1, X1, Y1, st1 = cases.run_engine(api, pa, X0, Y0, params)
+    assert st1["tiled"] & 32
+    gbps, dilate = 0.5, 4                       # X block: 2000 rows x 64 x 8 B = 1.02 MB -> 8.2 ms per iteration at 0.5 / 4 GB/s
+    if emulate != "off":
+        monkeypatch.setenv("GLRM_EXCHANGE_EMULATE_GBPS", str(gbps))
+        monkeypatch.setenv("GLRM_EXCHANGE_EMULATE_MODE", {"wait-value": "1", "delay-kernel": "2"}[emulate])
+    for arrival, chunks in ((1, 4), (2, 4), (0, 1), (2, 1)):
+        t0 = time.perf_counter()
+        try:
+            mh = api.multi_create(pa, 4, device_ids=[0] * 4, x_chunks=chunks, arrival=arrival, profile=1)
+        except _capi.GLRMError as e:
+            if emulate == "wait-value" and e.code == _capi.ERR_UNSUPPORTED:
+                pytest.skip("hipStreamWaitValue64 is not supported on this device")
+            raise
+        try:
+            X, Y = np.array(X0, order="F"), np.array(Y0, order="F")
+            o, sec = api.multi_fit(mh, params, X, Y)
+            info = api.multi_info(mh, 4)
+        finally:
+            api.multi_destroy(mh)
+        assert np.array_equal(o[1:], o1[1:]) and np.array_equal(X, X1) and np.array_equal(Y, Y1), (arrival, chunks)
+        assert info["exchange"] == 0 and info["exchange_ms"] >= 0.0
+        if emulate != "off":
+            link_s = (m // 4) * k * 8 / (gbps * 1e9 / dilate)
+            assert sec[-1] >= 0.9 * iters * link_s, (emulate, arrival, chunks, sec[-1], iters * link_s)
