@@ -459,7 +459,7 @@ int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int reset);
  * order (with `rotate`: over the chunks i ^ ((global segment id & 7) >> 1)); the lanes' partials are added by an xor butterfly
  * (pairs at distance 1, then 2, 4, 8).  The regularizer's sum of squares / absolute values is formed the same way.
  */
-#define GLRM_ORDER_REFERENCE 0 /* list order, one accumulator per sum (the oracle's default; no engine family reports it) */
+#define GLRM_ORDER_REFERENCE 0 /* list order, one accumulator per sum: the oracle's default, and the engine's with glrm_options.sum_order = 1 */
 #define GLRM_ORDER_STRIDED 1   /* gather sweeps / cached row sweep: a segment is shared by W waves of 64 / lanes lane groups; group q
                                   of the T = W x 64 / lanes groups takes the observations q, q + T, q + 2T, ... in ascending order into
                                   its own loss and gradient accumulators; the groups of a wave are added by an xor butterfly (distance

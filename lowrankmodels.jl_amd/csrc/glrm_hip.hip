@@ -778,7 +778,12 @@ static int finalize_impl(glrm_handle* h, const glrm_signature* whole) {
       h->sig.cols_unordered < h->sig_local.cols_unordered)
     return fail(GLRM_ERR_INVALID, "the signature of the whole problem cannot be smaller than this shard's (sum the counts, max the rest)");
   int rc;
-  if (!h->multi && !h->dense) {
+  if ((rc = glrm_setup_reforder(h))) return rc; // glrm_options.sum_order = 1: refuses models the validation sweeps do not cover
+  if (h->sum_order_opt) {
+    // reference-order validation sweeps: one lane per segment in list order, no family to choose and no view to re-order
+    h->tiled_row = h->tiled_col = h->blocked_row = h->blocked_col = h->cached_row = h->cached_want = 0;
+    h->waves_row = h->waves_col = 1;
+  } else if (!h->multi && !h->dense) {
     // a failure from here on leaves re-ordered private views and partial buffers behind: the handle can then only be destroyed
     h->finalize_failed = true;
     if (env_int("GLRM_HIP_TEST_FAIL_FINALIZE", 0))  // test hook (tests/test_gpu_crossval.py): the latch below cannot be reached on purpose otherwise
@@ -1106,7 +1111,10 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
     HIPCK(hipEventRecord(ev.a, h->stream));
   }
   const bool tiled = rows ? (h->tiled_row && !eval_only) : h->tiled_col;
-  if (h->multi) {
+  if (h->sum_order_opt) {
+    rc = glrm_run_reforder(h, rows, min_stepsize, eval_only);
+    if (rc) return rc;
+  } else if (h->multi) {
     rc = glrm_run_multi(h, rows, min_stepsize, eval_only);
     if (rc) return rc;
   } else if (h->dense) {
@@ -1303,6 +1311,7 @@ extern "C" int glrm_hip_col_penalties(glrm_handle* h) {
 extern "C" int glrm_hip_sum(glrm_handle* h, const void* dvec, int64_t n, double* out) {
   if (!h || !out || (n > 0 && !dvec)) return fail(GLRM_ERR_INVALID, "NULL argument");
   DeviceGuard dg(h->device);
+  if (h->sum_order_opt) return glrm_reforder_sum(h, dvec, n, out); // sum(::Vector{Float64}) as Julia adds it (proxgrad.jl:205)
   hipLaunchKernelGGL(sum_stage1, dim3(SUM_BLOCKS), dim3(SUM_THREADS), 0, h->stream, (const double*)dvec, n, h->partials);
   hipLaunchKernelGGL(sum_stage2, dim3(1), dim3(SUM_THREADS), 0, h->stream, h->partials, h->dscalar);
   HIPCK(hipGetLastError());
@@ -1339,7 +1348,7 @@ extern "C" int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int
   out->nnz_rows = h->nnz_r; out->nnz_cols = h->nnz_c;
   out->waves_row = h->waves_row; out->waves_col = h->waves_col; out->ld = h->kp;
   out->tiled = h->multi ? 8 : (h->tiled_row ? 1 : 0) | (h->tiled_col ? 2 : 0) | (h->dense ? 4 : 0) | (h->cached_row ? 64 : 0) | (h->blocked_row ? 16 : 0) |
-               (h->blocked_col ? 32 : 0); // bit0 / bit1: LDS-tiled row / column sweep, bit4 / bit5: phase-aligned gather passes
+               (h->blocked_col ? 32 : 0) | (h->sum_order_opt ? 128 : 0); // bit0 / bit1: LDS-tiled row / column sweep, bit4 / bit5: phase-aligned gather passes, bit7: reference order
   if (reset) {
     h->launches_x = h->launches_y = 0;
     h->ms_x = h->ms_y = h->ms_wait = 0;
@@ -1367,7 +1376,10 @@ extern "C" int glrm_hip_sum_order(glrm_handle* h, int32_t which, glrm_sum_order*
   const bool quad = h->loss_quad_uniform, per_obs = !quad && h->n_losses > 1 && rows;
   const bool tiled = rows ? h->tiled_row != 0 : h->tiled_col != 0;
   const bool blocked = rows ? h->blocked_row != 0 : h->blocked_col != 0;
-  if (h->multi || h->dense || (blocked && !rows && h->lockstep)) {
+  if (h->sum_order_opt) {
+    o.family = GLRM_ORDER_REFERENCE; // glrm_reforder.hip: one lane per segment, list order, one accumulator per sum
+    o.lanes = 1; o.comps = h->kp;
+  } else if (h->multi || h->dense || (blocked && !rows && h->lockstep)) {
     o.family = GLRM_ORDER_OTHER;
   } else if (tiled) {
     const int T = h->order_unit; // vectors per staged tile (half a tile with loader waves)
@@ -1446,7 +1458,7 @@ extern "C" int glrm_hip_objective(glrm_handle* h, const double* X, const double*
 // One outer iteration as a hipGraph.  Eligible: gather sweeps (fixed launch sequence, no host round trips inside a half-step) on
 // the handle's private stream (the legacy default stream cannot be captured), no per-launch event timing.
 static bool graph_eligible(const glrm_handle* h) {
-  return h->own_stream && !h->profile && !h->multi && !h->dense && !h->tiled_row && !h->tiled_col && !h->blocked_row && !h->blocked_col && !h->cached_row &&
+  return h->own_stream && !h->profile && !h->multi && !h->dense && !h->sum_order_opt && !h->tiled_row && !h->tiled_col && !h->blocked_row && !h->blocked_col && !h->cached_row &&
          env_int("GLRM_HIP_GRAPH", 1) != 0;
 }
 
