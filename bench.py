@@ -432,8 +432,8 @@ def pmc_traffic(args, kernel_re, per_halfstep=False, child_env=None, eval_pass=F
         d = tempfile.mkdtemp(prefix="glrm_pmc_", dir="/tmp")
         cmd = [rp, "--pmc", *ctr.split(), "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "bench.py"),
                "--config", args.config, "--rows", str(args.rows), "--steps", "2", "--warmup", str(max(args.warmup, 1)), "--tiled", str(args.tiled), *(["--quad-gram"] if args.quad_gram else []),
-               "--no-cpu-baseline", "--no-convergence-run", "--no-jref", "--pmc", "off", "--seed", str(args.seed), "--borrow", args.borrow,
-               "--cols", str(args.cols), "--obs-per-row", str(args.obs_per_row), "--rank", str(args.k)]
+               "--no-cpu-baseline", "--no-convergence-run", "--no-jref", "--no-other-configs", "--no-create-from-host", "--pmc", "off", "--seed", str(args.seed), "--borrow", args.borrow,
+               "--cols", str(args.cols), "--obs-per-row", str(args.obs_per_row), "--rank", str(args.k), "--degree", args.degree, "--zipf-s", str(args.zipf_s)]
         env = dict(os.environ, TMPDIR="/tmp", **(child_env or {}))
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, start_new_session=True)
@@ -741,6 +741,75 @@ def inlib_child(args, n_gpus, timeout_s=420, shared_device=False):
     return r
 
 
+def other_config_line(args, name, extra=(), timeout_s=600):
+    """One of the other BASELINE configs under the same clock as the default line (C2 / C3 / C5 were builder-run
+    profiles only): `bench.py --config <name>` as a child process (its own device memory: C5 at its stated size needs ~200 GB), compacted
+    to what the tables quote -- ms per iteration, updates/s, kernel families, the roofline of its dominant kernel with PMC traffic."""
+    steps = min(args.steps, 10)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", name, "--steps", str(steps), "--warmup", str(args.warmup), "--seed", str(args.seed),
+           "--no-cpu-baseline", "--no-jref", "--no-convergence-run", "--no-other-configs", "--pmc", args.pmc, "--pmc-timeout", str(args.pmc_timeout), *extra]
+    t0 = time.time()
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout_s} s", "command": " ".join(cmd[1:])}
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return {"error": f"exit {p.returncode}", "stderr_tail": p.stderr[-800:], "command": " ".join(cmd[1:])}
+    r = json.loads(lines[-1])
+    rf, kn = r.get("roofline") or {}, r.get("kernels") or {}
+    return {"workload": r["config"]["workload"], "full_size": r["config"].get("full_size"), "ms_per_step": r["ms_per_step"], "updates_per_s": r["value"],
+            "steps": r["steps"], "warmup": r["warmup"], "families": {"row_sweep": r["config"].get("row_sweep"), "col_sweep": r["config"].get("col_sweep")},
+            "row_sweep_ms": kn.get("row_sweep_ms"), "col_sweep_ms": kn.get("col_sweep_ms"),
+            "mean_trials": {"per_row": kn.get("mean_trials_per_row"), "per_col": kn.get("mean_trials_per_col")},
+            "roofline": {kk: rf.get(kk) for kk in ("bound", "kernel", "achieved", "peak", "unit", "frac", "cache_served", "traffic", "traffic_frac", "per_launch",
+                                                   "avg_launch_ms", "algorithmic_frac")} | {"l2_hit_rate": (rf.get("l2") or {}).get("hit_rate")},
+            "objective": r.get("objective"), "setup_s": r.get("setup_s"), "child_wall_s": time.time() - t0,
+            "command": "bench.py " + " ".join(cmd[2:])}
+
+
+def create_from_host_leg(args, cfg, api, m, n, k, q, device):
+    """The boundary at north-star scale from HOST memory (`setup_s.create` times a device-to-device hand-over of generator
+    output).  What a host binding pays before the first iteration when Omega lives in host memory as a sparse matrix:
+      csr_from_csc_s  the row view from the CSC arrays by ONE counting transpose (scipy's csc -> csr, the twin of julia/HipGLRM.jl:
+                      views_from_csc; the column view IS colptr / rowval / nzval after an index shift) -- no lookup per entry
+      create_s        glrm_hip_create on pageable host arrays: the lists' trip over PCIe + set-up (family choice, buffers)
+    The lists are generated on the device and copied to the host first (d2h_s: not part of what a host would pay)."""
+    import numpy as np
+    import scipy.sparse as sp
+    import torch
+    from lowrankmodels.jl_amd import _capi, synth
+    reg = cfg["reg"]
+    t0 = time.time()
+    w = synth.DeviceWorkload(m, n, k, q, seed=args.seed, value_model=cfg["value_model"], loss_mix=cfg["loss_mix"], rx=reg, ry=reg, device=device)
+    colptr = w.colptr.cpu().numpy().astype(np.int64, copy=False)
+    rowidx = w.rowidx[: w.nnz_cols].cpu().numpy()
+    colvals = w.colvals[: w.nnz_cols].cpu().numpy()
+    ref_rowptr = w.rowptr.cpu().numpy()
+    ref_colidx_head = w.colidx[: 1 << 20].cpu().numpy()
+    w.free_sources()
+    del w
+    torch.cuda.empty_cache()
+    t_d2h = time.time() - t0
+    t0 = time.time()
+    A = sp.csc_matrix((colvals, rowidx, colptr), shape=(m, n)).tocsr()   # counting transpose, O(nnz); columns ascending inside every row
+    rowptr, colidx, rowvals = A.indptr.astype(np.int64, copy=False), A.indices.astype(np.int32, copy=False), A.data
+    t_csr = time.time() - t0
+    same = bool(np.array_equal(rowptr, ref_rowptr) and np.array_equal(colidx[: 1 << 20], ref_colidx_head))  # = the generator's own row view
+    r = np.array([reg], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, synth.loss_table(n, cfg["loss_mix"]), r, r)
+    nbytes = int(rowptr.nbytes + colidx.nbytes + rowvals.nbytes + colptr.nbytes + rowidx.nbytes + colvals.nbytes)
+    t0 = time.time()
+    h = api.create(pa, device_id=device.index or 0)
+    t_create = time.time() - t0
+    st = api.kernel_stats(h)
+    api.destroy(h)
+    return {"observations": int(rowptr[-1]), "list_bytes": nbytes, "csr_from_csc_s": t_csr, "csr_equals_the_generators_row_view": same,
+            "create_s": t_create, "create_GBps": nbytes / t_create / 1e9, "kernel_flags": st["tiled"], "d2h_s_not_a_host_cost": t_d2h,
+            "is": "host-resident Omega as CSC arrays -> row view by one counting transpose (scipy csc -> csr; julia/HipGLRM.jl: views_from_csc) -> "
+                  "glrm_hip_create from pageable host memory (PCIe upload + set-up); the PCIe-inclusive figures are never part of `value`"}
+
+
 def cpu_full_leg(args):
     """bench.py --cpu-full: ONE warm-up + ONE timed outer iteration of the CPU oracle on the FULL lists of the config (C4: 1e9 observations,
     24 GB of lists + 5 GB of factors on the host, twice while the handle copies them) on every core this box grants -- the check of the
@@ -833,6 +902,11 @@ def main():
     ap.add_argument("--emulate-link-gbps", type=float, default=0.0, help="--host inlib: emulate an xGMI link of this many GB/s per direction on the "
                     "direct pushes (GLRM_EXCHANGE_EMULATE_GBPS) and run the same fit once more with free copies: the difference is the exposed exchange")
     ap.add_argument("--no-inlib-leg", action="store_true", help="N > 1 under torch.distributed.run: skip the in-library host's run that rank 0 adds to the line")
+    ap.add_argument("--degree", default="uniform", choices=["uniform", "zipf"], help="uniform: exactly q observations per row (SURVEY 8(d) recipe); zipf: "
+                    "power-law row degrees and column popularities with about the same |Omega| (lowrankmodels.jl_amd/synth.py: ZipfWorkload; N = 1, list configs)")
+    ap.add_argument("--zipf-s", type=float, default=0.5, help="--degree zipf: the exponent of both laws, w(rank) = (rank + 1)^-s")
+    ap.add_argument("--no-create-from-host", action="store_true", help="default C4 line: skip the create-from-host-arrays leg (24 GB over PCIe, ~1 minute)")
+    ap.add_argument("--no-other-configs", action="store_true", help="default C4 line at N = 1: skip the compact C2 / C3 / C5 lines (child runs, ~5 minutes)")
     ap.add_argument("--cpu-full", action="store_true", help="one warm-up + one timed iteration of the CPU oracle on the FULL lists of the config (minutes, tens of GB of host memory)")
     args = ap.parse_args()
     if args.emulate_rank >= 0:
@@ -883,7 +957,14 @@ def main():
 
     api = _capi.hip_api()
     t_gen = time.time()
-    if args.config == "C3":
+    zipf = args.degree == "zipf"
+    if zipf:
+        if world != 1 or args.config == "C3" or cfg["loss_mix"]:
+            raise SystemExit("--degree zipf covers the single-loss list configs (C2, C4) on one GPU")
+        w = synth.ZipfWorkload(m, n, k, m * q, s_rows=args.zipf_s, s_cols=args.zipf_s, seed=args.seed, value_model=cfg["value_model"], rx=reg, ry=reg, device=device)
+        args.no_cpu_baseline = args.no_jref = args.no_other_configs = True  # those legs are defined on the uniform recipe
+        cfg["text"] = ("POWER-LAW Omega (Zipf s = %g on row degrees and column popularities) of " % args.zipf_s) + cfg["text"]
+    elif args.config == "C3":
         w = synth.DenseDeviceWorkload(m, n, k, seed=args.seed, rx=reg, ry=reg, device=device)
     else:
         w = synth.DeviceWorkload(m, n, k, q, rows=(rbs[rank], rbs[rank + 1]), cols=(cbs[rank], cbs[rank + 1]), seed=args.seed,
@@ -897,6 +978,7 @@ def main():
                     opts=dict(profile=1, waves_row=args.waves_row, waves_col=args.waves_col, tiled=args.tiled, quad_gram=1 if args.quad_gram else 0),
                     x_chunks=args.x_chunks if args.config != "C3" else 1)
     nnz_r, nnz_c = w.nnz_rows, w.nnz_cols
+    degrees = w.degree_summary() if zipf else None
     if not borrow:
         w.free_sources()
     t_create = time.time() - t_create
@@ -1030,7 +1112,8 @@ def main():
                        "name": args.config, "m": m, "n": n, "k": k, "observed": tot_r,
                        "full_size": m == CONFIGS[args.config]["rows"] and n == CONFIGS[args.config]["cols"] and k == CONFIGS[args.config]["k"], "start": INIT_NOTE[nonneg_start(cfg)], "regularizer": REG_NAME.get(reg[0], str(reg)),
                        "parallelism": f"rows/cols sharded over {world} GPU(s) ({args.scaling} scaling), X,Y replicated",
-                       "waves_row": st["waves_row"], "waves_col": st["waves_col"], "row_sweep": fam_r, "col_sweep": fam_c},
+                       "waves_row": st["waves_row"], "waves_col": st["waves_col"], "row_sweep": fam_r, "col_sweep": fam_c,
+                       **({"degree": "zipf", "zipf_s": args.zipf_s, "degrees": degrees} if zipf else {})},
             "roofline": roof,
             "kernels": {"row_sweep_ms": ms_x, "col_sweep_ms": ms_y,
                         "row_sweep": side_summary(rl_r), "col_sweep": side_summary(rl_c),
@@ -1062,6 +1145,19 @@ def main():
         # the same problem once more through the host the reference would bind (one process, N devices); every rank of this job has
         # released its shard, and waits at the barrier below while rank 0's child runs.  GLRM_BENCH_INLIB=shared: all shards on device 0
         # (the gloo plumbing mode of a box with fewer GPUs than ranks: tests/test_gpu_multirank.py drives this very code path)
+        # the other BASELINE configs under the same clock (the default line is C4 at full size on one GPU; scaled-down / sharded runs skip them)
+        full = m == CONFIGS[args.config]["rows"] and n == CONFIGS[args.config]["cols"] and k == CONFIGS[args.config]["k"]
+        if world == 1 and args.config == "C4" and full and not args.no_other_configs and args.tiled == 0:
+            out["other_configs"] = {"C2": other_config_line(args, "C2"), "C3": other_config_line(args, "C3"),
+                                    "C3_quad_gram": other_config_line(args, "C3", extra=("--quad-gram",)),
+                                    "C5": other_config_line(args, "C5", timeout_s=900),
+                                    "note": "each a child run of this script (`command`), this box, this session; C5 at its stated size (5e9 observations, lists "
+                                            "borrowed in place); roofline as in the main line: frac = achieved / peak of the best-priced limiter, traffic = PMC"}
+        if world == 1 and args.config == "C4" and full and not args.no_create_from_host and not zipf:
+            try:
+                out["setup_s"]["create_from_host"] = create_from_host_leg(args, cfg, api, m, n, k, q, device)
+            except Exception as e:  # the line must survive (host memory, scipy)
+                out["setup_s"]["create_from_host"] = {"error": repr(e)}
         inlib_shared = os.environ.get("GLRM_BENCH_INLIB") == "shared"
         if world > 1 and (backend == "nccl" or inlib_shared) and not args.no_inlib_leg and args.config != "C3" and args.scaling == "strong":
             out["inlib_host"] = inlib_child(args, world, shared_device=inlib_shared)

@@ -11,7 +11,6 @@ from .fit import ShardedFit, fit, fit_b, objective, partition
 from .crossval import (cross_validate, cv_by_iter, flatten_observations, get_train_and_test, getfolds, loss_fn,
                              regularization_path)
 from .initialize import init_svd_
-from .scaling import M_estimator, avgerror, equilibrate_variance_
 from .domains import (BoolDomain, CategoricalDomain, CountDomain, Domain, OrdinalDomain, PeriodicDomain, RealDomain, default_domain,
                       error_metric, error_metric_entry, impute, impute_entry, impute_missing)
 from .glrm import GLRM, add_offset_, copy_estimate, parameter_estimate, scale_regularizer_, sort_observations

@@ -6,8 +6,10 @@ Differences from the Julia type that a user can see:
   * the losses and regularizers of include/glrm_hip.h are accepted (nine scalar losses, five multi-dimensional ones,
     five base regularizers and their offset / ordinal wrappers); everything else is outside the accelerated path
     (SURVEY.md section 2);
-  * ``scale=True`` (equilibrate_variance!) runs for scalar losses; the reference's M-estimators of the multi-dimensional
-    losses do not execute, so that combination raises NotImplementedError.
+  * ``scale=true`` (equilibrate_variance!, src/modify_glrm.jl:31-58) is a constructor convenience outside this build's scope (SURVEY.md
+    section 2): ``scale`` takes a CALLABLE that rewrites the model's loss / regularizer scales at the point where the reference
+    runs equilibrate_variance! (before add_offset!, src/glrm.jl:73-78); the replayed reference scripts pass
+    tests/extras/scaling.py: equilibrate_variance_.  ``scale=True`` raises.
 """
 from __future__ import annotations
 
@@ -105,6 +107,9 @@ class GLRM:
         Y = np.asarray(Y, dtype=np.float64)
         if Y.shape != (k, d):
             raise ValueError("Y must be of size (k,d) where d is the sum of the embedding dimensions of all the losses.")
+        if scale is True:
+            raise NotImplementedError("scale=true (equilibrate_variance!) is outside this build's scope (SURVEY.md section 2): pass a callable "
+                                      "that rewrites the scales, e.g. tests/extras/scaling.py: equilibrate_variance_")
         if scale and d != n:
             raise NotImplementedError("scale=true with multi-dimensional losses: their M-estimators do not run in the reference either")
 
@@ -145,9 +150,8 @@ class GLRM:
         self._colvals = self._gather(rowidx.astype(np.int64), np.repeat(np.arange(n, dtype=np.int64), np.diff(colptr)), False)
         self._handle_cache = None
         self._split_cache = None
-        if scale:   # equilibrate_variance!(glrm) BEFORE add_offset!, src/glrm.jl:73-78
-            from .scaling import equilibrate_variance_
-            equilibrate_variance_(self)
+        if scale:   # where the reference runs equilibrate_variance!(glrm): BEFORE add_offset!, src/glrm.jl:73-78
+            scale(self)
         if offset:  # add_offset!(glrm), src/glrm.jl:76-78, src/modify_glrm.jl:21-24
             add_offset_(self)
 

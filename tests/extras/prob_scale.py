@@ -2,7 +2,7 @@
 import numpy as np
 
 import lowrankmodels.jl_amd.losses as _l
-from lowrankmodels.jl_amd.scaling import _observed_values, avgerror
+from .scaling import _observed_values, avgerror
 
 
 def prob_scale_(glrm, columns_to_scale=None, TOL=1e-12):

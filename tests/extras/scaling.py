@@ -1,4 +1,5 @@
-"""M-estimators and the scale=true model rewrite (reference: src/losses.jl:116-352 M_estimator / avgerror,
+"""TEST-SIDE helper (out of scope for the product, SURVEY.md section 2: `add_offset!` / `equilibrate_variance!` are constructor conveniences of
+the reference, not part of the fit! path): M-estimators and the scale=true model rewrite (reference: src/losses.jl:116-352 M_estimator / avgerror,
 src/modify_glrm.jl:31-82 equilibrate_variance! / prob_scale!).  Host-side pre-processing of the loss and regularizer scales;
 the fit itself is unchanged.  Scalar losses only: the reference's M-estimators of the multi-dimensional losses do not run
 (`a==j` on an array, adjoint row vectors passed to grad(::Vector)), so `scale=true` cannot be reproduced for them."""
@@ -8,7 +9,7 @@ import math
 
 import numpy as np
 
-from . import losses as _l
+import lowrankmodels.jl_amd.losses as _l
 
 
 def M_estimator(l, a):

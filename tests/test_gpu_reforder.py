@@ -58,7 +58,7 @@ def test_c4_recipe_with_long_columns_walks_the_pairwise_tree(k):
     reg = np.array([(3, 0, 1.0)], dtype=_capi.REG_DTYPE)
     pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, one, reg, reg)
     X0, Y0 = np.asfortranarray(np.abs(X0) / k ** 0.5), np.asfortranarray(np.abs(Y0) / k ** 0.5)
-    c, g = both(pa, X0, Y0, L.ProxGradParams(max_iter=25))
+    c, g = both(pa, X0, Y0, L.ProxGradParams(8.0, max_iter=25))       # stepsize 8: first trials are rejected, the trial passes walk the tree too
     identical(c, g)
     assert c[3]["trials_y"] > c[3]["accepts_y"]          # some column rejected a trial: the trial passes ran too
 

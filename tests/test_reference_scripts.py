@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import cases
+import extras as E
 import lowrankmodels.jl_amd as L
 import oracle as O
 
@@ -53,7 +54,7 @@ def poisson_script(engine, rng, max_iter=150):
     X_real, Y_real, ch = L.fit_b(g_pre, p, verbose=False, engine=engine)
     A_real = L.impute(g_pre, engine=engine)  # impute(losses, X_real'*Y_real)
     assert np.all(A_real >= 0) and np.all(A_real == np.round(A_real))  # counts
-    g = L.GLRM(A_real, losses, rx, ry, k, scale=True, offset=True, rng=np.random.default_rng(11))
+    g = L.GLRM(A_real, losses, rx, ry, k, scale=E.equilibrate_variance_, offset=True, rng=np.random.default_rng(11))
     X, Y, ch2 = L.fit_b(g, p, verbose=False, engine=engine)
     err = L.error_metric(g, engine=engine)
     out = np.array(ch.objective), np.array(ch2.objective), err

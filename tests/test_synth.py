@@ -47,3 +47,29 @@ def test_column_view_by_transposition_equals_the_generated_one():
         b = O.synth_cpu(700, 90, 5, 9, seed=3, loss_mix=mix, transpose=True)
         for u, v in zip(a, b):
             assert np.array_equal(u, v)
+
+
+def test_zipf_workload_is_a_consistent_power_law_omega():
+    """lowrankmodels.jl_amd/synth.py: ZipfWorkload (pure torch, so it runs here): both views list the same entries, sorted and without
+    duplicates (the findall order of src/glrm.jl:46-48), row degrees and column popularities are heavy-tailed, the values carry a rank-k
+    signal."""
+    import scipy.sparse as sp
+    from lowrankmodels.jl_amd import synth
+    m, n, k = 6000, 800, 8
+    w = synth.ZipfWorkload(m, n, k, 400_000, s_rows=0.7, s_cols=0.7, seed=3, chunk=1 << 17)
+    pa = w.host_problem()
+    assert pa.rowptr[-1] == pa.colptr[-1] == w.nnz_rows and 0.85 * 400_000 < w.nnz_rows < 1.1 * 400_000
+    for ptr, idx in ((pa.rowptr, pa.colidx), (pa.colptr, pa.rowidx)):
+        d = np.diff(idx.astype(np.int64))
+        inner = np.ones(len(idx) - 1, dtype=bool)
+        inner[ptr[1:-1][(ptr[1:-1] > 0) & (ptr[1:-1] < len(idx))] - 1] = False   # differences across a segment boundary
+        assert (d[inner] > 0).all()
+    A = sp.csr_matrix((pa.rowvals, pa.colidx, pa.rowptr), shape=(m, n))
+    B = sp.csc_matrix((pa.colvals, pa.rowidx, pa.colptr), shape=(m, n))
+    assert abs(A - B.tocsr()).max() == 0.0
+    s = w.degree_summary()
+    assert s["rows"]["max"] > 2.5 * s["rows"]["median"] and s["cols"]["max"] > 10 * s["cols"]["median"], s   # (800 columns cap the heaviest rows)
+    sig = w.whole_signature()
+    assert sig.nnz_rows == w.nnz_rows and sig.max_col_len == s["cols"]["max"]
+    X0, Y0 = w.init_factors(8)
+    assert X0.numel() == m * 8 and Y0.numel() == n * 8
