@@ -487,7 +487,8 @@ typedef struct glrm_sum_order {
   int64_t windows_per_sup; /* WINDOWED: windows per super-tile; 0 = the whole list is one super-tile and nothing is re-added */
   int32_t private_order;   /* 1 = the engine walks a private copy of the list in another order than the caller's (tile sort, grouping by
                               loss kind): the order above applies to THAT copy and cannot be reproduced from the caller's lists */
-  int32_t reserved;
+  int32_t long_from;       /* WINDOWED (phase-aligned column passes): > 0 = segments of at least this many observations are swept by the
+                              8-wave gather sweep instead and add in the STRIDED order (same lanes / comps, 8 waves, batch 1); 0 = none */
 } glrm_sum_order; /* 80 bytes */
 
 /* which: 0 = the row view (X half-step), 1 = the column view (Y half-step).  Needs a finalized handle. */

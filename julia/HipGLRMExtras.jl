@@ -19,7 +19,7 @@ struct CSumOrder
     waves4_from::Int64; waves8_from::Int64; cached_maxlen::Int64
     cached_waves::Int32; batch::Int32; batch_one_wave_only::Int32; rotate::Int32
     window::Int64; windows_per_sup::Int64
-    private_order::Int32; reserved::Int32
+    private_order::Int32; long_from::Int32
 end
 struct CDomain; kind::Int32; reserved::Int32; lo::Float64; hi::Float64; end
 cdomain(d::LowRankModels.RealDomain) = CDomain(0, 0, 0, 0)

@@ -124,11 +124,11 @@ class CSumOrder(C.Structure):
     _fields_ = [("family", C.c_int32), ("lanes", C.c_int32), ("comps", C.c_int32), ("waves", C.c_int32),
                 ("waves4_from", C.c_int64), ("waves8_from", C.c_int64), ("cached_maxlen", C.c_int64),
                 ("cached_waves", C.c_int32), ("batch", C.c_int32), ("batch_one_wave_only", C.c_int32), ("rotate", C.c_int32),
-                ("window", C.c_int64), ("windows_per_sup", C.c_int64), ("private_order", C.c_int32), ("reserved", C.c_int32)]
+                ("window", C.c_int64), ("windows_per_sup", C.c_int64), ("private_order", C.c_int32), ("long_from", C.c_int32)]
     FAMILIES = {0: "reference", 1: "strided", 2: "windowed", 3: "other"}
 
     def asdict(self):
-        d = {f: int(getattr(self, f)) for f, _ in self._fields_ if f != "reserved"}
+        d = {f: int(getattr(self, f)) for f, _ in self._fields_}
         d["family_name"] = self.FAMILIES.get(d["family"], "?")
         return d
 

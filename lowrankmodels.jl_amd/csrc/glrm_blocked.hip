@@ -95,7 +95,42 @@ int glrm_setup_blocked(glrm_handle* h) {
     HIPCK(hipMalloc((void**)&h->joldbuf, (size_t)nl1 * 8));
     HIPCK(hipMalloc((void**)&h->activebuf, (size_t)nl1 * 4));
     HIPCK(hipMalloc((void**)&h->ntrialbuf, (size_t)nl1 * 4));
+    HIPCK(hipMemsetAsync(h->activebuf, 0, (size_t)nl1 * 4, h->stream)); // diverted columns are never touched by col_reduce: they must read "not searching"
     h->blocked_col = 1;
+    // Skewed column lengths (power-law Omega; round 5).  A launch covers one super-tile x a slice of the columns, one lane group per column:
+    // a column 100 x the mean keeps its group walking 100 x longer than the others of its launch, alone and latency bound (C4 recipe with
+    // Zipf degrees: Y half-step 2.6 s against 0.13 s).  (i) The passes hand the columns out LONGEST FIRST, so the groups of a slice walk
+    // lists of like length (and of like density: they also advance through the super-tile at the same rate).  (ii) Columns of at least
+    // long_from = max(98 304, 16 x the whole problem's mean column length) observations leave the passes for the 8-wave gather sweep, which
+    // spreads one column over 64 lane groups; it runs beside the passes on the side stream.  Both are functions of the column's own
+    // length and of the whole problem's signature: shard-invariant.  Which slot a column sits in changes no sum; the diverted columns
+    // add in the gather sweep's order (reported: glrm_sum_order.long_from).
+    const int64_t mean_len = h->sig.nnz_cols / (h->n > 0 ? h->n : 1);
+    h->blk_long_from = env_int("GLRM_HIP_BLOCKED_LONG_FROM", 0) > 0 ? env_int("GLRM_HIP_BLOCKED_LONG_FROM", 0)
+                                                                     : std::max<int64_t>(GLRM_WAVES8_FROM, 16 * mean_len);
+    if (h->lockstep) h->blk_long_from = 0;
+    if (h->nl > 0 && h->blk_long_from > 0) {
+      std::vector<int64_t> ptr((size_t)h->nl + 1);
+      HIPCK(hipMemcpyAsync(ptr.data(), h->colptr, ((size_t)h->nl + 1) * 8, hipMemcpyDeviceToHost, h->stream));
+      HIPCK(hipStreamSynchronize(h->stream));
+      std::vector<int32_t> shortl, longl;
+      for (int64_t s = 0; s < h->nl; ++s) (ptr[s + 1] - ptr[s] >= h->blk_long_from ? longl : shortl).push_back((int32_t)s);
+      std::stable_sort(shortl.begin(), shortl.end(), [&](int32_t x, int32_t y) { return ptr[x + 1] - ptr[x] > ptr[y + 1] - ptr[y]; });
+      h->blk_nshort_c = (int64_t)shortl.size();
+      h->blk_nlong_c = (int64_t)longl.size();
+      HIPCK(hipMalloc((void**)&h->blk_perm_c, std::max<size_t>(1, shortl.size()) * 4));
+      HIPCK(hipMemcpyAsync(h->blk_perm_c, shortl.data(), shortl.size() * 4, hipMemcpyHostToDevice, h->stream));
+      if (!longl.empty()) {
+        HIPCK(hipMalloc((void**)&h->blk_long_c, longl.size() * 4));
+        HIPCK(hipMemcpyAsync(h->blk_long_c, longl.data(), longl.size() * 4, hipMemcpyHostToDevice, h->stream));
+        if (!h->side_stream) {
+          HIPCK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+          HIPCK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+          HIPCK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+      }
+      HIPCK(hipStreamSynchronize(h->stream)); // the lists are locals
+    }
   }
   if ((br || bc) && !h->nactive) HIPCK(hipMalloc((void**)&h->nactive, 4));
   if (h->lockstep && !h->lock_ctr) HIPCK(hipMalloc((void**)&h->lock_ctr, LOCK_CTR_WORDS * 4));
@@ -130,7 +165,7 @@ static int launch_blocked_inst(glrm_handle* h, TiledArgs a, bool rows) {
   int64_t& cap_slot = h->blocked_cap[rows ? 0 : 1][GRAD ? 0 : 1];
   if (cap_slot == 0) cap_slot = slice_capacity(kernel, h->device, SPB);
   const int64_t cap = cap_slot;
-  const int64_t nseg = a.nseg;
+  const int64_t nseg = a.npass > 0 ? a.npass : a.nseg;
   // equal slices: ceil(nseg / cap) launches per super-tile, all of the same size (a last slice of a few percent of the others is a launch
   // that cannot fill the chip)
   const int64_t nslices = (nseg + cap - 1) / cap;
@@ -349,6 +384,15 @@ int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, d
   a.active = rows ? h->active_r : h->activebuf;
   a.ntrial = rows ? h->ntrial_r : h->ntrialbuf;
   a.nactive = h->nactive;
+  if (!rows && h->blk_perm_c) { // length-sorted slots; the columns at or above long_from run on the gather sweep (run_sweep, glrm_hip.hip)
+    a.segperm = h->blk_perm_c;
+    a.npass = h->blk_nshort_c;
+    a.long_from = h->blk_long_from;
+    if (a.npass == 0) { // every local column is diverted: nothing for the passes (npass = 0 would mean "all")
+      HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
+      return GLRM_OK;
+    }
+  }
   if (rows && h->rng_e >= 0) { // glrm_hip_step_x_range: local rows [rng_b, rng_e)
     const int64_t s0 = h->rng_b;
     a.nseg = h->rng_e - s0;

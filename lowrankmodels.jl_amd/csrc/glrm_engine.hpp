@@ -136,6 +136,10 @@ int glrm_reforder_sum(glrm_handle* h, const void* dvec, int64_t n, double* out);
   bool finalize_failed = false;       // glrm_hip_finalize ran and failed half way: the handle can only be destroyed
   // launch geometry of the persistent / sliced kernels, per handle (device and fill percentage at finalize; a process may drive devices
   // with different CU counts, and the knobs are read per handle): 0 = not computed yet
+  // phase-aligned column passes on skewed data: slot -> column for the passes (columns below blk_long_from observations, longest
+  // first), the columns at or above it (8-wave gather sweep on the side stream), and the threshold (from the WHOLE problem's mean)
+  int32_t *blk_perm_c = nullptr, *blk_long_c = nullptr;
+  int64_t blk_nshort_c = 0, blk_nlong_c = 0, blk_long_from = 0;
   int64_t blocked_cap[2][2] = {{0, 0}, {0, 0}}; // phase-aligned passes: segments per launch slice, [row / column view][gradient / trial instantiation]
   int cached_grid[2] = {0, 0};        // persistent cached row sweep: resident workgroups, MAXT = 7 / 4 instantiation
   glrm_signature sig_local{}, sig{};  // this shard's contribution / the whole problem's

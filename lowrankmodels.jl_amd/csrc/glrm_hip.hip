@@ -585,7 +585,7 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
                   h->activebuf, h->ntrialbuf, h->nactive, h->dflag, h->Arow, h->Acol, h->part_r, h->gsum_r, h->trial_r,
                   h->jold_r, h->active_r, h->ntrial_r, h->ystart, h->mtrial, h->mpart_loss, h->mpart_G, h->mgtot,
                   h->mobjold, h->mactive, h->mnactive, h->colperm, h->rowperm, h->seglist_r, h->seglist_c, h->rowdescid, h->udesc,
-                  h->gramH, h->gram_part, h->jloss_r, h->jloss_c, h->lock_ctr, h->actlist};
+                  h->gramH, h->gram_part, h->jloss_r, h->jloss_c, h->lock_ctr, h->actlist, h->blk_perm_c, h->blk_long_c};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->iter_exec) (void)hipGraphExecDestroy(h->iter_exec);
@@ -1124,7 +1124,27 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
     rc = glrm_run_tiled(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
     if (rc) return rc;
   } else if (rows ? (h->blocked_row && !eval_only) : h->blocked_col) {
+    const bool divert = !rows && h->blk_nlong_c > 0; // the very long columns: 8-wave gather sweep on the side stream, beside the passes
+    if (divert) {
+      // the gather sweep reads all of X: behind the sweeps already queued (fork) and, while X is still arriving
+      // (glrm_hip_step_y_arrival), behind every block -- without holding up the passes on the main stream
+      HIPCK(hipEventRecord(h->ev_fork, h->stream));
+      HIPCK(hipStreamWaitEvent(h->side_stream, h->ev_fork, 0));
+      for (int b = 0; b < h->n_arrival; ++b)
+        if (h->arrival[b].event) HIPCK(hipStreamWaitEvent(h->side_stream, (hipEvent_t)h->arrival[b].event, 0));
+      SweepArgs b = a;
+      b.seglist = h->blk_long_c;
+      b.nseg = h->blk_nlong_c;
+      launch_sweep(h->G, h->R, 8, loss, 1, b, h->side_stream);
+    }
     rc = glrm_run_blocked(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
+    if (divert) { // join before anything else (also before reporting an error: later work on the stream stays ordered)
+      char keep[sizeof g_err];
+      memcpy(keep, g_err, sizeof keep);
+      (void)hipEventRecord(h->ev_join, h->side_stream);
+      (void)hipStreamWaitEvent(h->stream, h->ev_join, 0);
+      memcpy(g_err, keep, sizeof keep);
+    }
     if (rc) return rc;
   } else {
     // gather sweeps (and the cached row sweep), class by class -- see build_class_plan
@@ -1376,6 +1396,7 @@ extern "C" int glrm_hip_sum_order(glrm_handle* h, int32_t which, glrm_sum_order*
   const bool quad = h->loss_quad_uniform, per_obs = !quad && h->n_losses > 1 && rows;
   const bool tiled = rows ? h->tiled_row != 0 : h->tiled_col != 0;
   const bool blocked = rows ? h->blocked_row != 0 : h->blocked_col != 0;
+  if (!rows && h->blocked_col && !h->sum_order_opt && !h->multi && !h->dense) o.long_from = (int32_t)std::min<int64_t>(h->blk_long_from, INT32_MAX);
   if (h->sum_order_opt) {
     o.family = GLRM_ORDER_REFERENCE; // glrm_reforder.hip: one lane per segment, list order, one accumulator per sum
     o.lanes = 1; o.comps = h->kp;

@@ -77,6 +77,11 @@ struct TiledArgs {
   // appends it to `actlist_out` (slot = the old value of *nactive); the next trial pass runs over that list (`segperm` = the list,
   // nseg = its length: ceil(count / 256) workgroups) and the decide kernel reads it as `actlist_in`.  Which slot a segment sits in
   // changes no sum (see segperm), so the bits are those of the uncompacted rounds.
+  // Phase-aligned column passes on skewed data (round 5): the pass launches cover the first `npass` slots of `segperm` (the segments
+  // below `long_from` observations, longest first, so that the groups of a launch slice walk lists of like length); segments of at
+  // least `long_from` observations are swept by the 8-wave gather sweep beside the passes and are skipped by col_reduce / col_decide.
+  int64_t npass;              // 0 = every segment
+  int64_t long_from;          // 0 = no segment is diverted
   int stagger;                // > 0: workgroup i of the 32 an XCD holds at a time starts i x stagger x ~0.2 us late (tile_stagger below)
   int32_t* actlist_out;       // nullable
   const int32_t* actlist_in;  // col_decide_kernel: nullable; the segments to decide (nact_in of them) instead of all nseg
@@ -825,6 +830,7 @@ __global__ void __launch_bounds__(256) col_reduce_kernel(const TiledArgs a) {
   const int j = lane % G, gi = lane / G;
   const int64_t seg = ((int64_t)blockIdx.x * 4 + wave) * NGW + gi;
   if (seg >= a.nseg) return; // group-uniform
+  if (a.long_from > 0 && a.ptr && a.ptr[seg + 1] - a.ptr[seg] >= a.long_from) return; // swept by the gather sweep beside the passes
   const int64_t gseg = a.own_offset + seg;
   Vec<G, R> g, y, yn;
   double J = 0.0;

@@ -685,10 +685,12 @@ static int eng_wave_count(const glrm_sum_order* o, int64_t len, int rows) {
 static void eng_pass(const glrm_cpu_handle* h, const glrm_sum_order* o, int rows, int64_t gseg, const int32_t* idx, const double* vals, int64_t len,
                      const double* xv, const double* fac, const glrm_loss* segloss, double* J, double* g, double* work) {
   const int k = h->k, G = o->lanes, R = o->comps;
-  if (o->family == GLRM_ORDER_STRIDED) {
-    const int NG = 64 / G, W = eng_wave_count(o, len, rows), T = NG * W;
-    const int cached = rows && o->cached_maxlen >= 0 && len <= o->cached_maxlen;
-    const int batch = (!cached && o->batch == 4 && (!o->batch_one_wave_only || W == 1)) ? 4 : 1;
+  /* WINDOWED with long_from: the phase-aligned column passes hand segments of at least that many observations to the 8-wave gather sweep */
+  const int diverted = o->family == GLRM_ORDER_WINDOWED && o->long_from > 0 && len >= o->long_from;
+  if (o->family == GLRM_ORDER_STRIDED || diverted) {
+    const int NG = 64 / G, W = diverted ? 8 : eng_wave_count(o, len, rows), T = NG * W;
+    const int cached = !diverted && rows && o->cached_maxlen >= 0 && len <= o->cached_maxlen;
+    const int batch = (!diverted && !cached && o->batch == 4 && (!o->batch_one_wave_only || W == 1)) ? 4 : 1;
     double* Jq = work;               /* T */
     double* gq = work + 128;         /* T x k */
     for (int q = 0; q < T; ++q) {
@@ -845,6 +847,8 @@ int glrm_cpu_set_sum_order(glrm_cpu_handle* h, int32_t which, const glrm_sum_ord
   if (order->family == GLRM_ORDER_WINDOWED) {
     if (order->window <= 0 || order->windows_per_sup < 0 || !(order->batch == 2 || order->batch == G))
       return fail(GLRM_ERR_INVALID, "sum order: bad window geometry");
+    if (order->long_from < 0 || (order->long_from > 0 && (64 / G) * 8 > 128))
+      return fail(GLRM_ERR_INVALID, "sum order: long_from needs a lane layout of at least 4 lanes (8 waves x 64 / lanes groups)");
     /* the walk needs the lists ordered by window, like the engine's own check (glrm_tiled.hpp: check_sorted_kernel) */
     const int64_t ns = which == 0 ? h->row_end - h->row_begin : h->col_end - h->col_begin;
     const int64_t* ptr = which == 0 ? h->rowptr : h->colptr;
