@@ -101,13 +101,15 @@ int glrm_setup_blocked(glrm_handle* h) {
     // a column 100 x the mean keeps its group walking 100 x longer than the others of its launch, alone and latency bound (C4 recipe with
     // Zipf degrees: Y half-step 2.6 s against 0.13 s).  (i) The passes hand the columns out LONGEST FIRST, so the groups of a slice walk
     // lists of like length (and of like density: they also advance through the super-tile at the same rate).  (ii) Columns of at least
-    // long_from = max(98 304, 16 x the whole problem's mean column length) observations leave the passes for the 8-wave gather sweep, which
+    // long_from = max(4 096, 2 x the whole problem's mean column length) observations leave the passes for the 8-wave gather sweep, which
     // spreads one column over 64 lane groups; it runs beside the passes on the side stream.  Both are functions of the column's own
     // length and of the whole problem's signature: shard-invariant.  Which slot a column sits in changes no sum; the diverted columns
-    // add in the gather sweep's order (reported: glrm_sum_order.long_from).
+    // add in the gather sweep's order (reported: glrm_sum_order.long_from).  Measured, C4 recipe with Zipf(0.5) degrees (995e6
+    // observations, longest column 1.37e6 against a mean of 9 950; profiles/r05_c4_zipf_*): Y half-step 2 622 ms before, 207 ms with
+    // long_from = 16 x mean, 168 / 154 / 151 ms with 8 / 4 / 2 x mean; the uniform recipe (no column reaches 2 x mean) is untouched.
     const int64_t mean_len = h->sig.nnz_cols / (h->n > 0 ? h->n : 1);
     h->blk_long_from = env_int("GLRM_HIP_BLOCKED_LONG_FROM", 0) > 0 ? env_int("GLRM_HIP_BLOCKED_LONG_FROM", 0)
-                                                                     : std::max<int64_t>(GLRM_WAVES8_FROM, 16 * mean_len);
+                                                                     : std::max<int64_t>(4096, 2 * mean_len);
     if (h->lockstep) h->blk_long_from = 0;
     if (h->nl > 0 && h->blk_long_from > 0) {
       std::vector<int64_t> ptr((size_t)h->nl + 1);
