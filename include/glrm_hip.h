@@ -226,11 +226,10 @@ typedef struct glrm_options {
                         gather per observation and pass); exists so that a checker can hold the engine against the REFERENCE-order
                         oracle to rounding on trajectories that amplify summation order.  Scalar losses, list
                         problems. */
-  int32_t affine_trials; /* 1 = line-search trials after the first are evaluated from per-observation scalars when the prox of the
-                        segment's regularizer is linear (ZeroReg, QuadReg): x' = c(s) (x - s g) gives u'_f = c(s) (u_f - s w_f) with
-                        w_f = g.y_f formed once, so a later trial reads 16 bytes per observation instead of a k-vector.  Same algorithm
-                        (src/algorithms/proxgrad.jl:136-155); u'_f is rounded differently from the dot product <x', y_f> (<< 1e-5; a
-                        trial whose decrease is below that rounding may be decided differently -- like quad_gram).  Default 0. */
+  int32_t affine_trials; /* RESERVED in ABI 3 (0 or 1 accepted, no effect yet).  Specified so that hosts need not change when it lands: with a
+                        linear prox (ZeroReg, QuadReg) x' = c(s) (x - s g) gives u'_f = c(s) (u_f - s w_f), w_f = g.y_f, so line-search
+                        trials after the second could be evaluated from 16 bytes per observation instead of a k-vector
+                        (src/algorithms/proxgrad.jl:136-155).  DESIGN.md section 8 says why round 5 did not build it. */
   int32_t reserved;  /* must be 0 */
 } glrm_options; /* 48 bytes */
 

@@ -22,7 +22,7 @@
 // MI355X with register operands and nothing else going on (it issues every ~96 cycles at 2.38 GHz, not the 64 that the 78.6 TFLOP/s
 // rating implies); the gradient pass below runs at 50-52.  v_mfma_f64_4x4x4_4b_f64 sustains 70-73 TFLOP/s but needs four times the
 // operand words per flop: the same pass rebuilt on it (lane maps from tools/probe_mfma4.hip, operands in 16-byte LDS reads, conflict-
-// free row padding) was parity-green and no faster (82.3 vs 78.0 ms per C3 iteration) -- measured and dropped, DESIGN.md section 4.3.
+// free row padding) was parity-green and no faster (82.3 vs 78.0 ms per C3 iteration) -- measured and dropped, LABNOTES.md section 4.3.
 //
 // The line search (trial passes, accept / shrink) reuses col_reduce_kernel / col_decide_kernel of glrm_tiled.hpp.
 #pragma once

@@ -18,8 +18,10 @@ PLAIN_SEEDS, ROTATED_SEEDS = range(48), range(5000, 5044)
 TALLY = {"plain": {}, "rotated": {}}
 
 
-def random_loss(rng, allow_vector):
+def random_loss(rng, allow_vector, exact_only=False):
     kinds = ["quad", "l1", "huber", "quantile", "periodic", "poisson", "ordhinge", "logistic", "whinge"]
+    if exact_only:  # the losses the engine and the oracle evaluate with the same instructions (no exp / log / sin)
+        kinds = ["quad", "l1", "huber", "quantile", "ordhinge", "whinge"]
     if allow_vector:
         kinds += ["mnl", "ova", "ovah", "bvs", "bvsh", "ordistic", "mnlord"]
     kind = kinds[int(rng.integers(len(kinds)))]
@@ -54,14 +56,15 @@ def random_reg(rng):
             L.QuadReg(0.1)][int(rng.integers(5))]
 
 
-def random_model(seed):
+def random_model(seed, exact_scalar=False):
+    """exact_scalar: a scalar-loss model of the losses both sides evaluate with the same instructions, long run (the reference-order leg)."""
     rng = np.random.default_rng(seed)
     m, n = int(rng.integers(20, 400)), int(rng.integers(5, 60))
     k = int([1, 2, 3, 5, 8, 9, 16, 20, 33, 64][int(rng.integers(10))])
-    vector = bool(rng.random() < 0.6)
+    vector = bool(rng.random() < 0.6) and not exact_scalar
     if vector:
         k = min(k, 33)
-    losses = [random_loss(rng, vector) for _ in range(n)]
+    losses = [random_loss(rng, vector, exact_only=exact_scalar) for _ in range(n)]
     offset = vector and rng.random() < 0.5 and k >= 2
     if rng.random() < 0.3:
         rx = [random_reg(rng) for _ in range(m)]
@@ -89,7 +92,7 @@ def random_model(seed):
     # u = x'y ~ N(0, 1) at the start: keeps exp(u) of the Poisson / logistic columns in range
     g = L.GLRM(A, losses, rx, ry, k, X=rng.standard_normal((k, m)) / k ** 0.25, Y=rng.standard_normal((k, D)) / k ** 0.25, offset=offset, **kw)
     inner = int(rng.integers(1, 4)) if rng.random() < 0.3 else 1
-    p = L.ProxGradParams(float([1.0, 0.5, 2.0][int(rng.integers(3))]), max_iter=int(rng.integers(4, 14)), inner_iter=inner)
+    p = L.ProxGradParams(float([1.0, 0.5, 2.0][int(rng.integers(3))]), max_iter=int(rng.integers(40, 120) if exact_scalar else rng.integers(4, 14)), inner_iter=inner)
     return g, p
 
 
@@ -176,6 +179,63 @@ def test_random_models_with_the_sweep_family_rotated(seed):
     if res == "ill-conditioned":
         pytest.skip(f"[{fam}] ill-conditioned, nothing asserted: {detail}")
     assert res == "ok", (seed, fam, res, detail)
+
+
+EXACT_KINDS = {0, 1, 2, 3, 6, 8}   # Quad, L1, Huber, Quantile, OrdinalHinge, WeightedHinge: the same instructions on both sides (no exp / log / sin)
+REFORDER_SEEDS = range(48)
+REFORDER_TALLY = {}
+
+
+@pytest.mark.parametrize("seed", REFORDER_SEEDS)
+def test_random_models_over_their_whole_trajectory_in_the_reference_order_mode(seed):
+    """the randomized evidence compared only the stable prefix of each trajectory (median 7 iterations), because another
+    summation order forks an unstable trajectory.  In the reference-order mode (glrm_options.sum_order = 1) there is no other order: the
+    engine adds like the oracle, so the WHOLE run of every scalar-loss seed is compared -- every iteration the solver takes, unstable or
+    not, under the seed's own stop rule -- and must be IDENTICAL, bit for bit, when the model holds only losses both sides evaluate with
+    the same instructions; models with Logistic / Poisson / Periodic columns (in-kernel exp / log / sin vs libm) are held to 1e-9 on
+    their stable prefix.  Models outside the mode (multi-dimensional losses, offsets, k > 64) are counted, not compared."""
+    g, p = random_model(seed, exact_scalar=seed % 2 == 0)   # even seeds: exactly evaluated losses, 40-120 iterations; odd seeds: the plain table
+    pa = g.problem_arrays()
+    scalar = L.embedding_dim(g.losses) == g.n and not getattr(g, "offset", False) and all(int(r["wrap"]) == 0 for r in list(pa.rx) + list(pa.ry))
+    if not scalar or g.k > 64:
+        REFORDER_TALLY[seed] = ("outside the mode", 0)
+        pytest.skip("multi-dimensional losses / wrapped regularizers / k > 64: outside the reference-order mode")
+    X0, Y0 = np.asfortranarray(g.X), np.asfortranarray(g.Y)
+    exact = all(int(l["kind"]) in EXACT_KINDS for l in pa.losses)
+    O.set_threads(4)
+    if not exact:
+        stable = well_conditioned_prefix(pa, X0, Y0, p, seed)
+        if stable < 2:
+            REFORDER_TALLY[seed] = ("transcendental, unstable", 0)
+            pytest.skip("exp / log / sin based losses on a trajectory that amplifies 1e-13 within two iterations")
+        p = L.ProxGradParams(p.stepsize, max_iter=min(p.max_iter, stable), inner_iter=p.inner_iter_X, abs_tol=0.0, rel_tol=-1.0)
+    o_c, X_c, Y_c, st_c = cases.run_engine(O.oracle_api(), pa, X0, Y0, p)
+    o_g, X_g, Y_g, st_g = cases.run_engine(_capi.hip_api(), pa, X0, Y0, p, sum_order=1)
+    assert st_g["tiled"] == 128 and len(o_g) == len(o_c), (seed, st_g["tiled"], len(o_g), len(o_c))
+    if exact:
+        same_obj = np.array_equal(o_g[1:], o_c[1:]) or (np.isnan(o_g[1:]) == np.isnan(o_c[1:])).all() and np.array_equal(np.nan_to_num(o_g[1:]), np.nan_to_num(o_c[1:]))
+        assert same_obj and np.array_equal(X_g, X_c) and np.array_equal(Y_g, Y_c), (seed, cases.rel_err(o_g[1:], o_c[1:]), np.abs(X_g - X_c).max(), np.abs(Y_g - Y_c).max())
+        for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
+            assert st_g[key] == st_c[key], (seed, key)
+        REFORDER_TALLY[seed] = ("bit-identical, whole run", len(o_g) - 1)
+    else:
+        assert cases.rel_err(o_g, o_c) < 1e-9 and cases.fro_err(X_g, X_c) < 1e-9 and cases.fro_err(Y_g, Y_c) < 1e-9, seed
+        REFORDER_TALLY[seed] = ("1e-9, stable prefix", len(o_g) - 1)
+
+
+def test_accounting_reference_order_seeds(capsys):
+    t = REFORDER_TALLY
+    if len(t) < len(REFORDER_SEEDS):
+        pytest.skip("select the whole file for the accounting")
+    whole = [v[1] for v in t.values() if v[0].startswith("bit")]
+    line = (f"[fuzz accounting] reference-order mode: {len(t)} seeds, {len(whole)} bit-identical over their WHOLE run (iterations: min "
+            f"{min(whole, default=0)}, median {int(np.median(whole or [0]))}, max {max(whole, default=0)}), "
+            f"{sum(1 for v in t.values() if v[0].startswith('1e-9'))} with exp / log / sin losses at 1e-9 on the stable prefix, "
+            f"{sum(1 for v in t.values() if v[0].startswith('outside'))} outside the mode, "
+            f"{sum(1 for v in t.values() if v[0].startswith('transc'))} transcendental and unstable")
+    with capsys.disabled():
+        print("\n" + line)
+    assert len(whole) >= 20 and np.median(whole) >= 11, line
 
 
 def _account(kind, seeds, need):
