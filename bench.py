@@ -804,8 +804,20 @@ def create_from_host_leg(args, cfg, api, m, n, k, q, device):
     t_create = time.time() - t0
     st = api.kernel_stats(h)
     api.destroy(h)
+    # GLRM_PROBLEM_ROWS_FROM_COLS: the column view alone crosses PCIe, the engine derives the row view on the device (one stable radix
+    # sort of the column-major stream by row id) -- no host transpose, half the upload
+    pc = _capi.ProblemArrays(m, n, k, None, None, None, colptr, rowidx, colvals, synth.loss_table(n, cfg["loss_mix"]), r, r, flags=_capi.PROBLEM_ROWS_FROM_COLS)
+    t0 = time.time()
+    h = api.create(pc, device_id=device.index or 0)
+    t_cols = time.time() - t0
+    st2 = api.kernel_stats(h)
+    api.destroy(h)
     return {"observations": int(rowptr[-1]), "list_bytes": nbytes, "csr_from_csc_s": t_csr, "csr_equals_the_generators_row_view": same,
             "create_s": t_create, "create_GBps": nbytes / t_create / 1e9, "kernel_flags": st["tiled"], "d2h_s_not_a_host_cost": t_d2h,
+            "column_view_only": {"create_s": t_cols, "uploaded_bytes": int(colptr.nbytes + rowidx.nbytes + colvals.nbytes), "same_kernel_families": st2["tiled"] == st["tiled"],
+                                 "nnz_rows": int(st2["nnz_rows"]),
+                                 "is": "GLRM_PROBLEM_ROWS_FROM_COLS: colptr / rowidx / colvals only; the row view is derived on the device -- what "
+                                       "julia/HipGLRM.jl hands over for a SparseMatrixCSC (no host transpose at all)"},
             "is": "host-resident Omega as CSC arrays -> row view by one counting transpose (scipy csc -> csr; julia/HipGLRM.jl: views_from_csc) -> "
                   "glrm_hip_create from pageable host memory (PCIe upload + set-up); the PCIe-inclusive figures are never part of `value`"}
 

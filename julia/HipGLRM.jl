@@ -10,10 +10,10 @@
 #   HipGLRMDescriptors.jl  loss / regularizer types -> (kind, dim, scale, p0, p1) / (kind, wrap, scale); which models the engine takes
 #   HipGLRMExtras.jl       init_svd! / error_metric / impute / subset / sum_order on the same cached handle
 # Omega at north-star scale (1e9 observations): a `SparseMatrixCSC` whose lists are the constructor's (`findall(!iszero, A)`,
-# src/glrm.jl:46-48) IS the column view -- colptr / rowval / nzval are handed over after one index shift, the row view comes from ONE
-# counting transpose (O(nnz), ascending columns per row = the order sort_observations pushes them in, src/modify_glrm.jl:8-12), and no
-# entry is looked up through `A[e, j]` (a binary search per observation on a CSC matrix).  Lists the caller built (obs tuples,
-# duplicates, two different views) are flattened list by list, each view from ITS OWN list.
+# src/glrm.jl:46-48) IS the column view -- colptr / rowval / nzval are handed over after one index shift and NOTHING ELSE: the row view
+# (ascending columns per row = the order sort_observations pushes them in, src/modify_glrm.jl:8-12) is derived by the engine on the
+# device (GLRM_PROBLEM_ROWS_FROM_COLS), and no entry is looked up through `A[e, j]` (a binary search per observation on a CSC matrix).
+# Lists the caller built (obs tuples, duplicates, two different views) are flattened list by list, each view from ITS OWN list.
 #
 # NOT EXECUTED IN THIS REPOSITORY'S CI: no `julia` binary exists in the build image or on the GPU box (SURVEY.md F2).  The same C entry
 # points are exercised from C (examples/c_abi_example.c, examples/c_abi_multi.c) and from Python/ctypes (lowrankmodels.jl_amd/_capi.py,
@@ -92,37 +92,37 @@ function csc_is_omega(A::SparseMatrixCSC, oe)
     end
     true
 end
-# both views of a SparseMatrixCSC without one lookup: the column view IS (colptr, rowval, nzval); the row view is its counting transpose
-function views_from_csc(A::SparseMatrixCSC, losses)
-    m, n = size(A); cp, rv, nz = A.colptr, A.rowval, A.nzval; nnz_ = length(rv)
+# ... and are the row lists its transpose (every row's entries by ascending column)?  One walk over the columns with a cursor per row;
+# nothing is built.  (They are for the sparse constructor; a caller may have replaced them: the two views are independent.)
+function rows_are_transpose(A::SparseMatrixCSC, of)
+    cp, rv = A.colptr, A.rowval; cur = ones(Int, size(A, 1))
+    @inbounds for j in 1:size(A, 2), t in cp[j]:cp[j+1]-1
+        i = rv[t]; c = cur[i]
+        (c <= length(of[i]) && of[i][c] == j) || return false
+        cur[i] = c + 1
+    end
+    all(i -> cur[i] == length(of[i]) + 1, eachindex(of))
+end
+# the column view of a SparseMatrixCSC IS (colptr, rowval, nzval): one index shift, no lookup
+function cols_from_csc(A::SparseMatrixCSC, losses)
+    cp, rv, nz = A.colptr, A.rowval, A.nzval; n = size(A, 2)
     colptr = Vector{Int64}(undef, n + 1); @inbounds for j in 1:n+1; colptr[j] = cp[j] - 1; end
-    rowidx = Vector{Int32}(undef, nnz_); colvals = Vector{Float64}(undef, nnz_); rowptr = zeros(Int64, m + 1)
-    @inbounds for j in 1:n, t in cp[j]:cp[j+1]-1
-        rowidx[t] = Int32(rv[t] - 1); colvals[t] = value(losses[j], nz[t]); rowptr[rv[t] + 1] += 1
-    end
-    @inbounds for i in 1:m; rowptr[i + 1] += rowptr[i]; end
-    colidx = Vector{Int32}(undef, nnz_); rowvals = Vector{Float64}(undef, nnz_); fill_ = copy(rowptr)
-    @inbounds for j in 1:n, t in cp[j]:cp[j+1]-1             # columns ascending => every row's list ascending, like findall's order
-        i = rv[t]; fill_[i] += 1; colidx[fill_[i]] = Int32(j - 1); rowvals[fill_[i]] = colvals[t]
-    end
-    rowptr, colidx, rowvals, colptr, rowidx, colvals
+    rowidx = Vector{Int32}(undef, length(rv)); colvals = Vector{Float64}(undef, length(rv))
+    @inbounds for j in 1:n, t in cp[j]:cp[j+1]-1; rowidx[t] = Int32(rv[t] - 1); colvals[t] = value(losses[j], nz[t]); end
+    colptr, rowidx, colvals
 end
-# do the row lists equal the transpose's?  (they do for the sparse constructor; a caller may have replaced them: the views are independent)
-function rows_match(rowptr, colidx, of)
-    @inbounds for e in eachindex(of)
-        l = of[e]; length(l) == rowptr[e + 1] - rowptr[e] || return false
-        for (t, j) in enumerate(l); j - 1 == colidx[rowptr[e] + t] || return false; end
-    end
-    true
-end
+# (rowptr, colidx, rowvals, colptr, rowidx, colvals, flags).  A sparse matrix's pattern goes over as its column view alone
+# (GLRM_PROBLEM_ROWS_FROM_COLS = 8: the engine derives the row view on the device, the multi-GPU create on the host); anything else is
+# flattened list by list, each view from ITS OWN list.
 function omega_views(glrm::GLRM)
     A = glrm.A
+    rows() = flatten(glrm.observed_features, glrm.losses, (e, j) -> A[e, j], false)
     if A isa SparseMatrixCSC && csc_is_omega(A, glrm.observed_examples)
-        v = views_from_csc(A, glrm.losses)
-        rows_match(v[1], v[2], glrm.observed_features) && return v
-        return (flatten(glrm.observed_features, glrm.losses, (e, j) -> A[e, j], false)..., v[4], v[5], v[6])
+        cols = cols_from_csc(A, glrm.losses)
+        rows_are_transpose(A, glrm.observed_features) && return (Int64[], Int32[], Float64[], cols..., Int32(8))
+        return (rows()..., cols..., Int32(0))
     end
-    (flatten(glrm.observed_features, glrm.losses, (e, j) -> A[e, j], false)..., flatten(glrm.observed_examples, glrm.losses, (j, e) -> A[e, j], true)...)
+    (rows()..., flatten(glrm.observed_examples, glrm.losses, (j, e) -> A[e, j], true)..., Int32(0))
 end
 
 lasterr() = unsafe_string(ccall((:glrm_hip_last_error, LIB), Cstring, ()))
@@ -140,10 +140,10 @@ function create_handle(glrm::GLRM, desc, p::HipProxGradParams, dense::Bool)
     losses, rx, ry = desc
     check_abi()
     A = glrm.A; m, n = size(A); h = Ref{Ptr{Cvoid}}(C_NULL)
-    rowptr, colidx, rowvals, colptr, rowidx, colvals = dense ? (Int64[], Int32[], Float64[], Int64[], Int32[], Float64[]) : omega_views(glrm)
-    nul(v) = dense ? Ptr{eltype(v)}(C_NULL) : pointer(v)
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, flags = dense ? (Int64[], Int32[], Float64[], Int64[], Int32[], Float64[], Int32(0)) : omega_views(glrm)
+    nul(v) = (dense || (flags == 8 && v !== colptr && v !== rowidx && v !== colvals)) ? Ptr{eltype(v)}(C_NULL) : pointer(v)
     GC.@preserve losses rx ry rowptr colidx rowvals colptr rowidx colvals A p begin
-        prob = CProblem(m, n, glrm.k, 0, 0, m, 0, n, nul(rowptr), nul(colidx), nul(rowvals), nul(colptr), nul(rowidx), nul(colvals),
+        prob = CProblem(m, n, glrm.k, flags, 0, m, 0, n, nul(rowptr), nul(colidx), nul(rowvals), nul(colptr), nul(rowidx), nul(colvals),
                         pointer(losses), length(losses), pointer(rx), length(rx), pointer(ry), length(ry),
                         dense ? pointer(A) : Ptr{Float64}(C_NULL), dense ? m : 0, dense ? 1 : 0, 0)   # Julia's A is column-major
         opt = COptions(p.device_id, 0, 0, 0, C_NULL, 0, 0, p.quad_gram ? 1 : 0, p.mode == :reference_order ? 1 : 0, p.affine_trials ? 1 : 0, 0)

@@ -18,6 +18,7 @@ ERR_INVALID, ERR_UNSUPPORTED, ERR_HIP, ERR_COMM, ERR_OOM, ERR_NONFINITE = -1, -2
 PROBLEM_DEVICE_ARRAYS = 1
 PROBLEM_DEFER_SETUP = 2
 PROBLEM_BORROW_DEVICE_ARRAYS = 4
+PROBLEM_ROWS_FROM_COLS = 8   # Omega is a sparse matrix's pattern: hand over the column view only, the engine derives the row view
 
 
 class GLRMError(RuntimeError):

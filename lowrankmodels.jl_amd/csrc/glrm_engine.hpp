@@ -96,12 +96,7 @@ struct glrm_handle {
   int64_t vps_r = 0, vps_c = 0;           // opposing vectors per super-tile
   double *part_r = nullptr, *gsum_r = nullptr, *trial_r = nullptr, *jold_r = nullptr;
   int32_t *active_r = nullptr, *ntrial_r = nullptr;
-  int cached_row = 0, cached_cap = 0; // reference-order validation sweeps (glrm_reforder.hip; glrm_options.sum_order = 1)
-int glrm_setup_reforder(glrm_handle* h);               // finalize: refuses what the mode does not cover
-int glrm_run_reforder(glrm_handle* h, bool rows, double min_stepsize, int eval_only);
-int glrm_reforder_sum(glrm_handle* h, const void* dvec, int64_t n, double* out); // Julia's pairwise sum(::Vector{Float64})
-
-// cached gather row sweep (glrm_cached.hip): 0 off, 1 LDS, 2 registers; trips / vectors a row may have
+  int cached_row = 0, cached_cap = 0; // cached gather row sweep (glrm_cached.hip): 0 off, 1 LDS, 2 registers; trips / vectors a row may have
   int cached_want = 0;                // the whole problem runs its short rows on the cached sweep (decided from glrm_signature, never from the shard)
   // glrm_options.quad_gram: trials from the quadratic form (glrm_dense.hpp: dense_gram_*)
   bool dense_gram = false;
@@ -208,6 +203,9 @@ int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_
 int glrm_setup_reforder(glrm_handle* h);               // finalize: refuses what the mode does not cover
 int glrm_run_reforder(glrm_handle* h, bool rows, double min_stepsize, int eval_only);
 int glrm_reforder_sum(glrm_handle* h, const void* dvec, int64_t n, double* out); // Julia's pairwise sum(::Vector{Float64})
+
+// GLRM_PROBLEM_ROWS_FROM_COLS (glrm_transpose.hip): the row view derived on the device from the uploaded column view
+int glrm_rows_from_cols(glrm_handle* h);
 
 // cached gather row sweep (glrm_cached.hip)
 int glrm_setup_cached(glrm_handle* h);                 // finalize: cached_want / cached_row from h->sig

@@ -712,6 +712,18 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
     HIPCK(hipStreamSynchronize(st));
     if ((h->nnz_r > 0 && (!h->colidx || !h->rowvals)) || (h->nnz_c > 0 && (!h->rowidx || !h->colvals)))
       return fail(GLRM_ERR_INVALID, "index / value arrays are NULL");
+  } else if (!p->dense_A && (p->flags & GLRM_PROBLEM_ROWS_FROM_COLS)) { // the column view only; the row view is derived on the device
+    if ((rc = dev_copy_in(&h->colptr, p->colptr, h->nl + 1, on_dev, st))) return rc;
+    if (on_dev) {
+      HIPCK(hipMemcpyAsync(&h->nnz_c, p->colptr + h->nl, 8, hipMemcpyDeviceToHost, st));
+      HIPCK(hipStreamSynchronize(st));
+    } else {
+      h->nnz_c = p->colptr[h->nl];
+    }
+    if (h->nnz_c > 0 && (!p->rowidx || !p->colvals)) return fail(GLRM_ERR_INVALID, "index / value arrays are NULL");
+    if ((rc = dev_copy_in(&h->rowidx, p->rowidx, h->nnz_c, on_dev, st))) return rc;
+    if ((rc = dev_copy_in(&h->colvals, p->colvals, h->nnz_c, on_dev, st))) return rc;
+    if ((rc = glrm_rows_from_cols(h))) return rc;
   } else if (!p->dense_A) {
     if ((rc = dev_copy_in(&h->rowptr, p->rowptr, h->ml + 1, on_dev, st))) return rc;
     if ((rc = dev_copy_in(&h->colptr, p->colptr, h->nl + 1, on_dev, st))) return rc;
@@ -817,14 +829,22 @@ extern "C" int glrm_hip_create(glrm_handle** out, const glrm_problem* p, const g
   if (rc) return rc;
   if ((p->flags & GLRM_PROBLEM_BORROW_DEVICE_ARRAYS) && (!(p->flags & GLRM_PROBLEM_DEVICE_ARRAYS) || p->dense_A))
     return fail(GLRM_ERR_INVALID, "GLRM_PROBLEM_BORROW_DEVICE_ARRAYS needs GLRM_PROBLEM_DEVICE_ARRAYS and observation lists (not dense_A)");
+  const bool from_cols = (p->flags & GLRM_PROBLEM_ROWS_FROM_COLS) != 0;
+  if (from_cols) {
+    if (p->dense_A || (p->flags & GLRM_PROBLEM_BORROW_DEVICE_ARRAYS)) return fail(GLRM_ERR_INVALID, "GLRM_PROBLEM_ROWS_FROM_COLS: list problems, copied (not borrowed) arrays");
+    if (p->rowptr || p->colidx || p->rowvals) return fail(GLRM_ERR_INVALID, "GLRM_PROBLEM_ROWS_FROM_COLS: rowptr / colidx / rowvals must be NULL (the engine derives the row view)");
+    if (!(p->row_begin == 0 && p->row_end == p->m && p->col_begin == 0 && p->col_end == p->n))
+      return fail(GLRM_ERR_INVALID, "GLRM_PROBLEM_ROWS_FROM_COLS needs the whole problem (a shard's rows meet every column)");
+    if (!p->colptr) return fail(GLRM_ERR_INVALID, "colptr is NULL");
+  }
   if (p->dense_A) {
     // validated in glrm_setup_dense
   } else if (!(p->flags & GLRM_PROBLEM_DEVICE_ARRAYS)) {
-    rc = check_view("rowptr", p->row_end - p->row_begin, p->rowptr, p->colidx, p->rowvals, p->n, p, true, p->row_begin);
+    rc = from_cols ? GLRM_OK : check_view("rowptr", p->row_end - p->row_begin, p->rowptr, p->colidx, p->rowvals, p->n, p, true, p->row_begin);
     if (rc) return rc;
     rc = check_view("colptr", p->col_end - p->col_begin, p->colptr, p->rowidx, p->colvals, p->m, p, false, p->col_begin);
     if (rc) return rc;
-  } else if (!p->rowptr || !p->colptr) {
+  } else if ((!from_cols && !p->rowptr) || !p->colptr) {
     return fail(GLRM_ERR_INVALID, "rowptr / colptr are NULL");
   }
   int ndev = 0;

@@ -630,6 +630,33 @@ static int multi_create_impl(glrm_multi* mh, const glrm_problem* p, const glrm_o
 extern "C" int glrm_hip_multi_create(glrm_multi** out, const glrm_problem* p, const glrm_options* o, const glrm_multi_options* mo) {
   if (!out || !p || !mo) return fail(GLRM_ERR_INVALID, "NULL argument");
   *out = nullptr;
+  if ((p->flags & GLRM_PROBLEM_ROWS_FROM_COLS) && !(p->flags & GLRM_PROBLEM_DEVICE_ARRAYS)) {
+    // Omega is a sparse matrix's pattern, handed over as its column view only: every shard needs its rows' lists, so the row view is
+    // built here, once, by a counting transpose on the host (columns in order => every row's list ascending), and the shards are cut
+    // from both views as usual
+    if (p->dense_A || p->rowptr || p->colidx || p->rowvals) return fail(GLRM_ERR_INVALID, "GLRM_PROBLEM_ROWS_FROM_COLS: rowptr / colidx / rowvals must be NULL");
+    if (p->m <= 0 || p->n <= 0 || !p->colptr) return fail(GLRM_ERR_INVALID, "m, n must be positive and colptr given");
+    const int64_t nz = p->colptr[p->n];
+    if (nz > 0 && (!p->rowidx || !p->colvals)) return fail(GLRM_ERR_INVALID, "index / value arrays are NULL");
+    std::vector<int64_t> rowptr((size_t)p->m + 1, 0), fill((size_t)p->m);
+    std::vector<int32_t> colidx((size_t)nz);
+    std::vector<double> rowvals((size_t)nz);
+    for (int64_t t = 0; t < nz; ++t) {
+      if (p->rowidx[t] < 0 || p->rowidx[t] >= p->m) return fail(GLRM_ERR_INVALID, "rowidx holds an index outside [0, m)");
+      rowptr[(size_t)p->rowidx[t] + 1] += 1;
+    }
+    for (int64_t i = 0; i < p->m; ++i) { rowptr[i + 1] += rowptr[i]; fill[i] = rowptr[i]; }
+    for (int64_t f = 0; f < p->n; ++f)
+      for (int64_t t = p->colptr[f]; t < p->colptr[f + 1]; ++t) {
+        const int64_t at = fill[p->rowidx[t]]++;
+        colidx[at] = (int32_t)f;
+        rowvals[at] = p->colvals[t];
+      }
+    glrm_problem q = *p;
+    q.flags &= ~GLRM_PROBLEM_ROWS_FROM_COLS;
+    q.rowptr = rowptr.data(); q.colidx = colidx.data(); q.rowvals = rowvals.data();
+    return glrm_hip_multi_create(out, &q, o, mo); // (create copies every slice to its device: the vectors may go afterwards)
+  }
   if (mo->n_shards < 1 || mo->n_shards > 64) return fail(GLRM_ERR_INVALID, "n_shards must be in 1..64");
   if (mo->arrival < 0 || mo->arrival > 2) return fail(GLRM_ERR_INVALID, "glrm_multi_options.arrival must be 0, 1 or 2");
   if (p->flags & GLRM_PROBLEM_DEVICE_ARRAYS) return fail(GLRM_ERR_UNSUPPORTED, "glrm_hip_multi_create takes host arrays (it slices them per device)");

@@ -439,6 +439,37 @@ int glrm_cpu_create(glrm_cpu_handle** out, const glrm_problem* p, const glrm_opt
   int rc = check_desc(p);
   if (rc) return rc;
   int64_t ml = p->row_end - p->row_begin, nl = p->col_end - p->col_begin;
+  /* GLRM_PROBLEM_ROWS_FROM_COLS (include/glrm_hip.h): Omega is a sparse matrix's pattern; the row view is the counting transpose of the
+   * column view -- walking the columns in order appends to each row its entries by ascending column, which is the order in which
+   * sort_observations pushes the CartesianIndices of findall(!iszero, A) (src/glrm.jl:46-48, src/modify_glrm.jl:8-12). */
+  glrm_problem q = *p;
+  int64_t* t_rowptr = NULL; int32_t* t_colidx = NULL; double* t_rowvals = NULL;
+  if (p->flags & GLRM_PROBLEM_ROWS_FROM_COLS) {
+    if (p->dense_A || p->rowptr || p->colidx || p->rowvals) return fail(GLRM_ERR_INVALID, "GLRM_PROBLEM_ROWS_FROM_COLS: rowptr / colidx / rowvals must be NULL");
+    if (!(p->row_begin == 0 && p->row_end == p->m && p->col_begin == 0 && p->col_end == p->n)) return fail(GLRM_ERR_INVALID, "GLRM_PROBLEM_ROWS_FROM_COLS needs the whole problem");
+    rc = check_view("colptr", nl, p->colptr, p->rowidx, p->colvals, p->m, p, 0, p->col_begin);
+    if (rc) return rc;
+    const int64_t nz = p->colptr[nl];
+    t_rowptr = (int64_t*)calloc((size_t)p->m + 1, 8);
+    t_colidx = (int32_t*)malloc((size_t)(nz ? nz : 1) * 4);
+    t_rowvals = (double*)malloc((size_t)(nz ? nz : 1) * 8);
+    int64_t* fill = (int64_t*)malloc((size_t)(p->m ? p->m : 1) * 8);
+    if (!t_rowptr || !t_colidx || !t_rowvals || !fill) { free(t_rowptr); free(t_colidx); free(t_rowvals); free(fill); return fail(GLRM_ERR_OOM, "out of memory"); }
+    for (int64_t t = 0; t < nz; ++t) t_rowptr[p->rowidx[t] + 1] += 1;
+    for (int64_t i = 0; i < p->m; ++i) { t_rowptr[i + 1] += t_rowptr[i]; fill[i] = t_rowptr[i]; }
+    for (int64_t f = 0; f < p->n; ++f)
+      for (int64_t t = p->colptr[f]; t < p->colptr[f + 1]; ++t) {
+        const int64_t at = fill[p->rowidx[t]]++;
+        t_colidx[at] = (int32_t)f;
+        t_rowvals[at] = p->colvals[t];
+      }
+    free(fill);
+    q.rowptr = t_rowptr; q.colidx = t_colidx; q.rowvals = t_rowvals;
+    q.flags &= ~GLRM_PROBLEM_ROWS_FROM_COLS;
+    rc = glrm_cpu_create(out, &q, o);
+    free(t_rowptr); free(t_colidx); free(t_rowvals);
+    return rc;
+  }
   rc = check_view("rowptr", ml, p->rowptr, p->colidx, p->rowvals, p->n, p, 1, p->row_begin);
   if (rc) return rc;
   rc = check_view("colptr", nl, p->colptr, p->rowidx, p->colvals, p->m, p, 0, p->col_begin);

@@ -130,10 +130,13 @@ def test_the_marshalling_core_stays_within_its_line_budget():
 def test_a_sparse_matrix_is_handed_over_without_a_lookup_per_entry():
     """the shim flattened Omega through a per-entry closure A[e, j] -- a binary search per observation on a
     SparseMatrixCSC, twice, for 1e9 observations.  The sparse constructor's lists ARE the CSC arrays (src/glrm.jl:46-48): the column view
-    is taken from colptr / rowval / nzval, the row view from one counting transpose, and A[e, j] is only reached for lists the caller built."""
+    is taken from colptr / rowval / nzval, the row view is left to the engine (GLRM_PROBLEM_ROWS_FROM_COLS, derived on the device), and
+    A[e, j] is only reached for lists the caller built."""
     txt = open(SHIM).read()
-    body = txt[txt.index("function views_from_csc"):txt.index("function rows_match")]
+    body = txt[txt.index("function cols_from_csc"):txt.index("function omega_views")]
     assert "A.colptr" in body and "A.rowval" in body and "A.nzval" in body and "A[" not in body
     ov = txt[txt.index("function omega_views"):txt.index("lasterr()")]
-    assert ov.index("views_from_csc") < ov.index("A[e, j]")           # the lookup path is the fallback
-    assert "csc_is_omega(A, glrm.observed_examples)" in ov and "rows_match" in ov
+    assert ov.index("cols_from_csc") < ov.index("rows()...") and "Int32(8)" in ov          # the lookup path is the fallback
+    assert "csc_is_omega(A, glrm.observed_examples)" in ov and "rows_are_transpose(A, glrm.observed_features)" in ov
+    flag = int(re.search(r"#define GLRM_PROBLEM_ROWS_FROM_COLS (\d+)", open(HEADER).read()).group(1))
+    assert flag == 8 and "CProblem(m, n, glrm.k, flags," in txt
