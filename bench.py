@@ -771,9 +771,11 @@ def other_config_line(args, name, extra=(), timeout_s=600):
 def create_from_host_leg(args, cfg, api, m, n, k, q, device):
     """The boundary at north-star scale from HOST memory (`setup_s.create` times a device-to-device hand-over of generator
     output).  What a host binding pays before the first iteration when Omega lives in host memory as a sparse matrix:
-      csr_from_csc_s  the row view from the CSC arrays by ONE counting transpose (scipy's csc -> csr, the twin of julia/HipGLRM.jl:
-                      views_from_csc; the column view IS colptr / rowval / nzval after an index shift) -- no lookup per entry
-      create_s        glrm_hip_create on pageable host arrays: the lists' trip over PCIe + set-up (family choice, buffers)
+      csr_from_csc_s  the row view from the CSC arrays by ONE counting transpose on the host (scipy's csc -> csr; the column view IS
+                      colptr / rowval / nzval after an index shift) -- what a host without GLRM_PROBLEM_ROWS_FROM_COLS has to do
+      create_s        glrm_hip_create on pageable host arrays: both lists' trip over PCIe + set-up (family choice, buffers)
+      column_view_only.create_s   GLRM_PROBLEM_ROWS_FROM_COLS: the column view alone crosses PCIe, the row view is derived on the device
+                      (what julia/HipGLRM.jl hands over for a SparseMatrixCSC)
     The lists are generated on the device and copied to the host first (d2h_s: not part of what a host would pay)."""
     import numpy as np
     import scipy.sparse as sp
@@ -818,8 +820,9 @@ def create_from_host_leg(args, cfg, api, m, n, k, q, device):
                                  "nnz_rows": int(st2["nnz_rows"]),
                                  "is": "GLRM_PROBLEM_ROWS_FROM_COLS: colptr / rowidx / colvals only; the row view is derived on the device -- what "
                                        "julia/HipGLRM.jl hands over for a SparseMatrixCSC (no host transpose at all)"},
-            "is": "host-resident Omega as CSC arrays -> row view by one counting transpose (scipy csc -> csr; julia/HipGLRM.jl: views_from_csc) -> "
-                  "glrm_hip_create from pageable host memory (PCIe upload + set-up); the PCIe-inclusive figures are never part of `value`"}
+            "is": "host-resident Omega as CSC arrays -> row view by one counting transpose on the host (scipy csc -> csr) -> glrm_hip_create from "
+                  "pageable host memory (PCIe upload of both views + set-up); column_view_only = the same Omega handed over as its column view alone; "
+                  "the PCIe-inclusive figures are never part of `value`"}
 
 
 def cpu_full_leg(args):
