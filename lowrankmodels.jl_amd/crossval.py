@@ -84,6 +84,7 @@ class _Split:
         c._rowidx = np.ascontiguousarray(self.I[sel].astype(np.int32))
         c._colvals = np.ascontiguousarray(g._rowvals[sel])
         c._fully_observed = False
+        c._pattern_from_csc = False  # lists built here: both views go over
         return c
 
 

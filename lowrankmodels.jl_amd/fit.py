@@ -67,7 +67,8 @@ def _ensure_handle(glrm, api, params, allow_dense=True):
         glrm.close()
         cache = None
     if cache is None:
-        h = api.create(glrm.problem_arrays(dense=use_dense), **_engine_opts(params))
+        # a model built from a sparse matrix's pattern goes over as its column view alone (GLRM_PROBLEM_ROWS_FROM_COLS)
+        h = api.create(glrm.problem_arrays(dense=use_dense, cols_only=getattr(glrm, "_pattern_from_csc", False) and not use_dense), **_engine_opts(params))
         glrm._handle_cache = (api, h, key, soft, use_dense)
     elif cache[3] != soft:
         # only the regularizers changed: keep Omega / A on the device

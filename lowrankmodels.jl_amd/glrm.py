@@ -121,6 +121,9 @@ class GLRM:
 
         self._fully_observed = obs is None and observed_features is None and observed_examples is None and \
             not (sparse_na and _issparse(A))
+        # Omega is the pattern of a sparse matrix (src/glrm.jl:46-48): both views list the same entries, each ascending -- the fit hands the
+        # column view over alone and the engine derives the row view (GLRM_PROBLEM_ROWS_FROM_COLS, include/glrm_hip.h)
+        self._pattern_from_csc = obs is None and sparse_na and _issparse(A)
         # observed entries, src/glrm.jl:45-55
         if obs is None and sparse_na and _issparse(A):
             csc = A.tocsc()
@@ -201,9 +204,18 @@ class GLRM:
                 and len(pack_losses(self.losses)) == 1 and self.losses[0].kind == 0
                 and all(r.wrap == 0 for r in list(self.rx) + list(self.ry)))
 
-    def problem_arrays(self, rows=None, cols=None, dense=False) -> ProblemArrays:
+    def problem_arrays(self, rows=None, cols=None, dense=False, cols_only=False) -> ProblemArrays:
+        """cols_only (whole problem, sparse-matrix pattern): the column view alone with GLRM_PROBLEM_ROWS_FROM_COLS -- what the Julia shim
+        hands over for a SparseMatrixCSC; the library derives the row view."""
         rb, re = (0, self.m) if rows is None else rows
         cb, ce = (0, self.n) if cols is None else cols
+        if cols_only and not dense:
+            if not getattr(self, "_pattern_from_csc", False) or rows is not None or cols is not None:
+                raise ValueError("cols_only needs the whole problem of a model built from a sparse matrix's pattern")
+            from ._capi import PROBLEM_ROWS_FROM_COLS
+            return ProblemArrays(self.m, self.n, self.k, None, None, None, np.ascontiguousarray(self._colptr), np.ascontiguousarray(self._rowidx),
+                                 np.ascontiguousarray(self._colvals), pack_losses(self.losses), pack_regs(self.rx), pack_regs(self.ry),
+                                 flags=PROBLEM_ROWS_FROM_COLS)
         if dense:
             if not self.dense_eligible():
                 raise ValueError("this model is not eligible for the dense hand-over")
