@@ -49,7 +49,7 @@ extern "C" {
 /* 2: glrm_options grew by quad_gram / reserved (round 2), glrm_signature + glrm_hip_signature / glrm_hip_finalize and
  *    GLRM_PROBLEM_DEFER_SETUP were added (round 3).  A host built against ABI 1 fails the version check instead of handing over
  *    a 32-byte glrm_options. */
-/* 3: glrm_options grew by sum_order / affine_trials (48 bytes), glrm_kernel_stats by ms_wait_y, glrm_multi_options.reserved became
+/* 3: glrm_options grew by sum_order and one more reserved word (48 bytes), glrm_kernel_stats by ms_wait_y, glrm_multi_options.reserved became
  *    `arrival`; glrm_arrival + glrm_hip_step_y_arrival were added (round 5). */
 #define GLRM_HIP_ABI_VERSION 3
 
@@ -233,10 +233,7 @@ typedef struct glrm_options {
                         gather per observation and pass); exists so that a checker can hold the engine against the REFERENCE-order
                         oracle to rounding on trajectories that amplify summation order.  Scalar losses, list
                         problems. */
-  int32_t affine_trials; /* RESERVED in ABI 3 (0 or 1 accepted, no effect yet).  Specified so that hosts need not change when it lands: with a
-                        linear prox (ZeroReg, QuadReg) x' = c(s) (x - s g) gives u'_f = c(s) (u_f - s w_f), w_f = g.y_f, so line-search
-                        trials after the second could be evaluated from 16 bytes per observation instead of a k-vector
-                        (src/algorithms/proxgrad.jl:136-155).  DESIGN.md section 8 says why round 5 did not build it. */
+  int32_t reserved0; /* must be 0 */
   int32_t reserved;  /* must be 0 */
 } glrm_options; /* 48 bytes */
 

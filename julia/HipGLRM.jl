@@ -45,7 +45,7 @@ struct CParams
 end
 struct COptions
     device_id::Int32; profile::Int32; waves_row::Int32; waves_col::Int32; stream::Ptr{Cvoid}
-    caller_stream::Int32; tiled::Int32; quad_gram::Int32; sum_order::Int32; affine_trials::Int32; reserved::Int32
+    caller_stream::Int32; tiled::Int32; quad_gram::Int32; sum_order::Int32; reserved0::Int32; reserved::Int32
 end
 struct CMultiOptions; n_shards::Int32; exchange::Int32; device_ids::Ptr{Int32}; x_chunks::Int32; arrival::Int32; end
 
@@ -57,19 +57,18 @@ mutable struct HipProxGradParams <: AbstractParams
     abs_tol::Float64; rel_tol::Float64; min_stepsize::Float64
     device_id::Int; ngpus::Int; device_ids::Vector{Int32}; exchange::Symbol; x_chunks::Int; dense::Bool; quad_gram::Bool
     mode::Symbol                               # :fast (the engine's summation orders) | :reference_order (validation, glrm_options.sum_order = 1)
-    affine_trials::Bool
 end
 function HipProxGradParams(stepsize::Number=1.0; max_iter::Int=100, inner_iter_X::Int=1, inner_iter_Y::Int=1,
                            inner_iter::Int=1, abs_tol::Number=0.00001, rel_tol::Number=0.0001,
                            min_stepsize::Number=0.01*stepsize, device_id::Int=-1, ngpus::Int=1,
                            device_ids=Int32.(0:ngpus-1), exchange::Symbol=:direct, x_chunks::Int=4, dense::Bool=true,
-                           quad_gram::Bool=false, mode::Symbol=:fast, affine_trials::Bool=false)
+                           quad_gram::Bool=false, mode::Symbol=:fast)
     length(device_ids) == ngpus || error("device_ids must list one device per shard")
     exchange in (:direct, :rccl) || error("exchange must be :direct or :rccl")
     mode in (:fast, :reference_order) || error("mode must be :fast or :reference_order")
     HipProxGradParams(Float64(stepsize), max_iter, max(inner_iter_X, inner_iter), max(inner_iter_Y, inner_iter),
                       Float64(abs_tol), Float64(rel_tol), Float64(min_stepsize), device_id, ngpus, Vector{Int32}(device_ids),
-                      exchange, x_chunks, dense, quad_gram, mode, affine_trials)
+                      exchange, x_chunks, dense, quad_gram, mode)
 end
 
 # ---- Omega -> 0-based CSR / CSC (include/glrm_hip.h: glrm_problem) ------------------------------------------------------
@@ -146,7 +145,7 @@ function create_handle(glrm::GLRM, desc, p::HipProxGradParams, dense::Bool)
         prob = CProblem(m, n, glrm.k, flags, 0, m, 0, n, nul(rowptr), nul(colidx), nul(rowvals), nul(colptr), nul(rowidx), nul(colvals),
                         pointer(losses), length(losses), pointer(rx), length(rx), pointer(ry), length(ry),
                         dense ? pointer(A) : Ptr{Float64}(C_NULL), dense ? m : 0, dense ? 1 : 0, 0)   # Julia's A is column-major
-        opt = COptions(p.device_id, 0, 0, 0, C_NULL, 0, 0, p.quad_gram ? 1 : 0, p.mode == :reference_order ? 1 : 0, p.affine_trials ? 1 : 0, 0)
+        opt = COptions(p.device_id, 0, 0, 0, C_NULL, 0, 0, p.quad_gram ? 1 : 0, p.mode == :reference_order ? 1 : 0, 0, 0)
         if p.ngpus > 1
             mo = CMultiOptions(p.ngpus, p.exchange == :rccl ? 1 : 0, pointer(p.device_ids), p.x_chunks, 0)
             check(ccall((:glrm_hip_multi_create, LIB), Cint, (Ref{Ptr{Cvoid}}, Ref{CProblem}, Ref{COptions}, Ref{CMultiOptions}), h, prob, opt, mo))

@@ -9,7 +9,7 @@ hip_release!(glrm::GLRM) = (haskey(CACHE, glrm) && (destroy(CACHE[glrm]); delete
 # what the device copy depends on (data, Omega, losses, placement, options) / what set_regularizers can replace
 hardkey(glrm, desc, p, dense) = hash((objectid(glrm.A), size(glrm.A), glrm.k, objectid(glrm.observed_features), objectid(glrm.observed_examples),
                                       sum(length, glrm.observed_features), sum(length, glrm.observed_examples), desc[1], length(desc[2]), length(desc[3]),
-                                      p.device_id, p.ngpus, p.device_ids, p.exchange, p.x_chunks, dense, p.quad_gram, p.mode, p.affine_trials))
+                                      p.device_id, p.ngpus, p.device_ids, p.exchange, p.x_chunks, dense, p.quad_gram, p.mode))
 softkey(desc) = hash((desc[2], desc[3]))
 
 function handle(glrm::GLRM, desc, p)

@@ -72,7 +72,7 @@ class CSparseParams(C.Structure):
 class COptions(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("profile", C.c_int32), ("waves_row", C.c_int32), ("waves_col", C.c_int32),
                 ("stream", C.c_void_p), ("caller_stream", C.c_int32), ("tiled", C.c_int32), ("quad_gram", C.c_int32),
-                ("sum_order", C.c_int32), ("affine_trials", C.c_int32), ("reserved", C.c_int32)]
+                ("sum_order", C.c_int32), ("reserved0", C.c_int32), ("reserved", C.c_int32)]
 
 
 assert C.sizeof(COptions) == 48
@@ -264,21 +264,20 @@ class Api:
         return p
 
     def create(self, prob: "ProblemArrays", device_id=-1, profile=0, waves_row=0, waves_col=0, stream=None, tiled=0, quad_gram=0, defer=False,
-               sum_order=0, affine_trials=0):
+               sum_order=0):
         """``stream=None``: the handle creates a private stream.  ``stream=<int>``: launch on exactly that
         hipStream_t -- 0 is the legacy default stream (what torch.cuda.current_stream().cuda_stream returns
         for the default stream), so kernels stay ordered with the caller's other work on it.
         ``defer=True`` (one shard of a sharded fit): only upload; the host combines :meth:`signature` over the shards and
         calls :meth:`finalize` on every one of them (GLRM_PROBLEM_DEFER_SETUP).
-        ``sum_order=1``: the reference-order validation sweeps (glrm_options.sum_order); ``affine_trials=1``: later line-search
-        trials from per-observation scalars where the prox is linear (glrm_options.affine_trials)."""
+        ``sum_order=1``: the reference-order validation sweeps (glrm_options.sum_order)."""
         if prob.dense_A is not None and not self.dense_ok:
             raise GLRMError(ERR_UNSUPPORTED, "this engine takes observation lists only")
         p = self._cproblem(prob)
         if defer:
             p.flags |= PROBLEM_DEFER_SETUP
         o = COptions(device_id, profile, waves_row, waves_col, (stream or None), 0 if stream is None else 1, tiled, int(quad_gram), int(sum_order),
-                     int(affine_trials), 0)
+                     0, 0)
         h = C.c_void_p()
         self._ck(self._f["create"](C.byref(h), C.byref(p), C.byref(o)))
         return h
@@ -293,12 +292,12 @@ class Api:
 
     # -- one process, several devices (glrm_*_multi_*) -----------------------------------------
     def multi_create(self, prob: "ProblemArrays", n_shards, device_ids=None, exchange=0, x_chunks=0, profile=0, waves_row=0,
-                     waves_col=0, tiled=0, quad_gram=0, arrival=0, sum_order=0, affine_trials=0):
+                     waves_col=0, tiled=0, quad_gram=0, arrival=0, sum_order=0):
         """The whole problem (host arrays), sharded by the library over ``device_ids`` (default 0..n_shards-1; ids may repeat)."""
         if prob.dense_A is not None and not self.dense_ok:
             raise GLRMError(ERR_UNSUPPORTED, "this engine takes observation lists only")
         p = self._cproblem(prob)
-        o = COptions(-1, profile, waves_row, waves_col, None, 0, tiled, int(quad_gram), int(sum_order), int(affine_trials), 0)
+        o = COptions(-1, profile, waves_row, waves_col, None, 0, tiled, int(quad_gram), int(sum_order), 0, 0)
         ids = None if device_ids is None else np.ascontiguousarray(device_ids, dtype=np.int32)
         if ids is not None and len(ids) != n_shards:
             raise ValueError("device_ids must have n_shards entries")

@@ -150,7 +150,6 @@ struct glrm_handle {
   std::vector<int> sup_order;
   double ms_wait = 0;                 // profile: time the launch stream stood in those waits
   int sum_order_opt = 0;              // glrm_options.sum_order (1: reference-order validation sweeps, glrm_reforder.hip)
-  int affine_opt = 0;                 // glrm_options.affine_trials
   // hipGraph of one outer iteration (gather sweeps on a private stream): small fits are launch bound
   hipGraph_t iter_graph = nullptr;
   hipGraphExec_t iter_exec = nullptr;

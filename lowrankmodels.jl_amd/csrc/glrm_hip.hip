@@ -685,10 +685,8 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   h->profile = o ? o->profile : 0;
   h->tiled_opt = o ? o->tiled : 0;
   h->sum_order_opt = o ? o->sum_order : 0;
-  h->affine_opt = o ? o->affine_trials : 0;
-  if (o && o->reserved != 0) return fail(GLRM_ERR_INVALID, "glrm_options.reserved must be 0");
+  if (o && (o->reserved != 0 || o->reserved0 != 0)) return fail(GLRM_ERR_INVALID, "glrm_options.reserved0 / reserved must be 0");
   if (o && (o->sum_order < 0 || o->sum_order > 1)) return fail(GLRM_ERR_INVALID, "glrm_options.sum_order must be 0 (engine orders) or 1 (reference order)");
-  if (o && (o->affine_trials < 0 || o->affine_trials > 1)) return fail(GLRM_ERR_INVALID, "glrm_options.affine_trials must be 0 or 1");
   if (o) h->opts = *o; else { h->opts = glrm_options{}; h->opts.device_id = -1; }
   h->losses_h.assign(p->losses, p->losses + p->n_losses);
   h->rx_h.assign(p->rx, p->rx + p->n_rx);

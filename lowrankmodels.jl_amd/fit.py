@@ -25,7 +25,7 @@ def _engine_opts(params):
     g = lambda k, d: getattr(params, k, d)
     return dict(device_id=g("device_id", -1), profile=1 if g("profile", False) else 0,
                 waves_row=g("waves_row", 0), waves_col=g("waves_col", 0), tiled=g("tiled", 0), quad_gram=1 if g("quad_gram", False) else 0,
-                sum_order=1 if g("mode", "fast") == "reference_order" else 0, affine_trials=1 if g("affine_trials", False) else 0)
+                sum_order=1 if g("mode", "fast") == "reference_order" else 0)
 
 
 def _should_stop(i, prev, obj, scaled_abs_tol, rel_tol):
@@ -61,7 +61,7 @@ def _ensure_handle(glrm, api, params, allow_dense=True):
     (scale_regularizer!, regularization_path).  Returns (handle, hard key, soft key)."""
     use_dense = allow_dense and api.dense_ok and glrm.dense_eligible() and getattr(params, "dense", True)
     hard, soft = glrm._descriptor_key()
-    key = (id(api), _engine_opts(params)["device_id"], _engine_opts(params)["quad_gram"], _engine_opts(params)["sum_order"], _engine_opts(params)["affine_trials"], hard)
+    key = (id(api), _engine_opts(params)["device_id"], _engine_opts(params)["quad_gram"], _engine_opts(params)["sum_order"], hard)
     cache = glrm._handle_cache
     if cache is not None and (cache[2] != key or cache[4] != use_dense):
         glrm.close()
@@ -151,7 +151,7 @@ def _fit_multi_in_process(glrm, params, ch, verbose, api):
     from .regularizers import pack_regs
     use_dense = api.dense_ok and glrm.dense_eligible() and getattr(params, "dense", True)
     hard, soft = glrm._descriptor_key()
-    key = (id(api), "multi", params.ngpus, tuple(params.device_ids or ()), params.exchange, params.x_chunks, bool(getattr(params, "quad_gram", False)), getattr(params, "mode", "fast"), bool(getattr(params, "affine_trials", False)), hard)
+    key = (id(api), "multi", params.ngpus, tuple(params.device_ids or ()), params.exchange, params.x_chunks, bool(getattr(params, "quad_gram", False)), getattr(params, "mode", "fast"), hard)
     cache = glrm._handle_cache
     if cache is not None and (cache[2] != key or cache[4] != use_dense):
         glrm.close()
@@ -160,7 +160,7 @@ def _fit_multi_in_process(glrm, params, ch, verbose, api):
         o = _engine_opts(params)
         mh = api.multi_create(glrm.problem_arrays(dense=use_dense), params.ngpus, params.device_ids, 1 if params.exchange == "rccl" else 0,
                               params.x_chunks, profile=o["profile"], waves_row=o["waves_row"], waves_col=o["waves_col"], tiled=o["tiled"], quad_gram=o["quad_gram"],
-                              sum_order=o["sum_order"], affine_trials=o["affine_trials"])
+                              sum_order=o["sum_order"])
         glrm._handle_cache = (api, mh, key, soft, use_dense, "multi")
     elif cache[3] != soft:
         api.multi_set_regularizers(cache[1], pack_regs(glrm.rx), pack_regs(glrm.ry))

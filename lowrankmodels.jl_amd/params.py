@@ -31,15 +31,13 @@ class HipProxGradParams(ProxGradParams):
     dispatches on it exactly like on the built-in solvers (src/fit.jl:8-12)."""
 
     def __init__(self, stepsize=1.0, *, device_id=-1, profile=False, waves_row=0, waves_col=0, tiled=0, dense=True, ngpus=1,
-                 device_ids=None, exchange="direct", x_chunks=0, quad_gram=False, mode="fast", affine_trials=False, **kw):
+                 device_ids=None, exchange="direct", x_chunks=0, quad_gram=False, mode="fast", **kw):
         super().__init__(stepsize, **kw)
         # SURVEY.md 8(b) `mode` / `line_search_sum_order`: "fast" = the engine's summation orders; "reference_order" = the validation
         # sweeps that add every sum like the reference does (glrm_options.sum_order = 1: scalar losses, list problems, k <= 64; slow)
         if mode not in ("fast", "reference_order"):
             raise ValueError("mode must be 'fast' or 'reference_order'")
         self.mode = mode
-        # glrm_options.affine_trials: later line-search trials from per-observation scalars where the prox is linear (ZeroReg, QuadReg)
-        self.affine_trials = bool(affine_trials)
         # fully observed QuadLoss models only (glrm_options.quad_gram, SURVEY.md 7.2 K5): line-search trials from the quadratic form
         # J(x) + g.s + scale s'(YY')s instead of another pass over A; same iterates up to rounding.  Off by default.
         self.quad_gram = bool(quad_gram)
