@@ -1138,10 +1138,7 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
   } else if (h->dense) {
     rc = glrm_run_dense(h, rows, min_stepsize, eval_only);
     if (rc) return rc;
-  } else if (tiled) {
-    rc = glrm_run_tiled(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
-    if (rc) return rc;
-  } else if (rows ? (h->blocked_row && !eval_only) : h->blocked_col) {
+  } else if (tiled || (rows ? (h->blocked_row && !eval_only) : h->blocked_col)) {
     const bool divert = !rows && h->blk_nlong_c > 0; // the very long columns: 8-wave gather sweep on the side stream, beside the passes
     if (divert) {
       // the gather sweep reads all of X: behind the sweeps already queued (fork) and, while X is still arriving
@@ -1155,7 +1152,8 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
       b.nseg = h->blk_nlong_c;
       launch_sweep(h->G, h->R, 8, loss, 1, b, h->side_stream);
     }
-    rc = glrm_run_blocked(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
+    rc = tiled ? glrm_run_tiled(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only)
+               : glrm_run_blocked(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
     if (divert) { // join before anything else (also before reporting an error: later work on the stream stays ordered)
       char keep[sizeof g_err];
       memcpy(keep, g_err, sizeof keep);
@@ -1414,7 +1412,7 @@ extern "C" int glrm_hip_sum_order(glrm_handle* h, int32_t which, glrm_sum_order*
   const bool quad = h->loss_quad_uniform, per_obs = !quad && h->n_losses > 1 && rows;
   const bool tiled = rows ? h->tiled_row != 0 : h->tiled_col != 0;
   const bool blocked = rows ? h->blocked_row != 0 : h->blocked_col != 0;
-  if (!rows && h->blocked_col && !h->sum_order_opt && !h->multi && !h->dense) o.long_from = (int32_t)std::min<int64_t>(h->blk_long_from, INT32_MAX);
+  if (!rows && (h->blocked_col || h->tiled_col) && !h->sum_order_opt && !h->multi && !h->dense) o.long_from = (int32_t)std::min<int64_t>(h->blk_long_from, INT32_MAX);
   if (h->sum_order_opt) {
     o.family = GLRM_ORDER_REFERENCE; // glrm_reforder.hip: one lane per segment, list order, one accumulator per sum
     o.lanes = 1; o.comps = h->kp;

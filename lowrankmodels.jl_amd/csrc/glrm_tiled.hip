@@ -22,9 +22,12 @@ static bool tile_rot_rt(int G, int R) { return GLRM_TILE_ROT && (G == 4 || G == 
 // slot -> segment permutation of a tiled sweep: segments sorted by (loss kind of the column,) descending length, so that the 16
 // lane groups of a wave meet one loss formula and lists of similar length.  nullptr when the natural order is already that
 // (one loss kind and lengths within 25 % of each other: the synthetic BASELINE workloads).
-static int make_segperm(glrm_handle* h, bool rows, int32_t** out) {
+// long_from > 0 (columns): segments of at least that many observations are left out of the slots (they run on the 8-wave gather sweep
+// beside the passes, glrm_hip.hip: run_sweep) and listed in *longs; *nshort = slots handed out
+static int make_segperm(glrm_handle* h, bool rows, int32_t** out, int64_t long_from = 0, std::vector<int32_t>* longs = nullptr, int64_t* nshort = nullptr) {
   *out = nullptr;
   const int64_t nseg = rows ? h->ml : h->nl;
+  if (nshort) *nshort = nseg;
   if (nseg <= 1 || !env_int("GLRM_HIP_SEGPERM", 1)) return GLRM_OK;
   std::vector<int64_t> ptr((size_t)nseg + 1);
   HIPCK(hipMemcpyAsync(ptr.data(), rows ? h->rowptr : h->colptr, ((size_t)nseg + 1) * 8, hipMemcpyDeviceToHost, h->stream));
@@ -32,9 +35,16 @@ static int make_segperm(glrm_handle* h, bool rows, int32_t** out) {
   int64_t lmin = INT64_MAX, lmax = 0;
   for (int64_t s = 0; s < nseg; ++s) { const int64_t l = ptr[s + 1] - ptr[s]; lmin = l < lmin ? l : lmin; lmax = l > lmax ? l : lmax; }
   const bool kinds = !rows && h->n_losses > 1;
-  if (!kinds && lmax * 4 <= lmin * 5) return GLRM_OK;
-  std::vector<int32_t> perm((size_t)nseg);
-  for (int64_t s = 0; s < nseg; ++s) perm[s] = (int32_t)s;
+  const bool divert = long_from > 0 && longs && lmax >= long_from;
+  if (!kinds && !divert && lmax * 4 <= lmin * 5) return GLRM_OK;
+  std::vector<int32_t> perm;
+  perm.reserve((size_t)nseg);
+  for (int64_t s = 0; s < nseg; ++s) {
+    if (divert && ptr[s + 1] - ptr[s] >= long_from) longs->push_back((int32_t)s);
+    else perm.push_back((int32_t)s);
+  }
+  const int64_t nslots = (int64_t)perm.size();
+  if (nshort) *nshort = nslots;
   const glrm_loss* lt = kinds ? h->losses_h.data() + h->cb : nullptr;
   std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) {
     if (kinds && lt[x].kind != lt[y].kind) return lt[x].kind < lt[y].kind;
@@ -48,7 +58,7 @@ static int make_segperm(glrm_handle* h, bool rows, int32_t** out) {
     std::vector<int32_t> q[4];
     for (int32_t sgm : perm) q[tile_rot_of(h->cb + sgm)].push_back(sgm);
     size_t head[4] = {0, 0, 0, 0};
-    for (int64_t slot = 0; slot < nseg; ++slot) {
+    for (int64_t slot = 0; slot < nslots; ++slot) {
       int c = tile_rot_of(slot); // the class the slot's position wants
       if (head[c] >= q[c].size()) {
         size_t best = 0;
@@ -58,8 +68,8 @@ static int make_segperm(glrm_handle* h, bool rows, int32_t** out) {
       perm[(size_t)slot] = q[c][head[c]++];
     }
   }
-  HIPCK(hipMalloc((void**)out, (size_t)nseg * 4));
-  HIPCK(hipMemcpyAsync(*out, perm.data(), (size_t)nseg * 4, hipMemcpyHostToDevice, h->stream));
+  HIPCK(hipMalloc((void**)out, (size_t)(nslots > 0 ? nslots : 1) * 4));
+  HIPCK(hipMemcpyAsync(*out, perm.data(), (size_t)nslots * 4, hipMemcpyHostToDevice, h->stream));
   HIPCK(hipStreamSynchronize(h->stream)); // perm is a local
   return GLRM_OK;
 }
@@ -224,7 +234,28 @@ int glrm_setup_tiled(glrm_handle* h) {
     HIPCK(hipMalloc((void**)&h->activebuf, (size_t)nl1 * 4));
     HIPCK(hipMalloc((void**)&h->ntrialbuf, (size_t)nl1 * 4));
     HIPCK(hipMalloc((void**)&h->nactive, 4));
-    if ((rc0 = make_segperm(h, false, &h->colperm))) return rc0;
+    HIPCK(hipMemsetAsync(h->activebuf, 0, (size_t)nl1 * 4, st)); // diverted columns are never touched by col_reduce: "not searching"
+    // Skewed column lengths (round 5, like the phase-aligned passes: glrm_blocked.hip).  The columns are already handed out sorted by
+    // length; a workgroup's 256 columns walk a tile in lockstep (one barrier per tile), so ONE column many times the others keeps its
+    // workgroup on every tile for its own entries alone, and the few workgroups of the head of the sorted list are the makespan (C2
+    // recipe with Zipf(0.5) degrees: Y half-step 22.1 ms against 9.0).  Columns of at least long_from = max(4 096, 2 x the whole problem's
+    // mean column length) observations leave the passes for the 8-wave gather sweep on the side stream: a function of the column's own
+    // length and the whole problem's signature (shard-invariant), reported in glrm_sum_order.long_from.
+    const int64_t mean_len = h->sig.nnz_cols / (h->n > 0 ? h->n : 1);
+    h->blk_long_from = env_int("GLRM_HIP_TILED_LONG_FROM", -1) >= 0 ? env_int("GLRM_HIP_TILED_LONG_FROM", 0) : std::max<int64_t>(4096, 2 * mean_len);
+    std::vector<int32_t> longl;
+    if ((rc0 = make_segperm(h, false, &h->colperm, h->blk_long_from, &longl, &h->blk_nshort_c))) return rc0;
+    h->blk_nlong_c = (int64_t)longl.size();
+    if (!longl.empty()) {
+      HIPCK(hipMalloc((void**)&h->blk_long_c, longl.size() * 4));
+      HIPCK(hipMemcpyAsync(h->blk_long_c, longl.data(), longl.size() * 4, hipMemcpyHostToDevice, st));
+      if (!h->side_stream) {
+        HIPCK(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        HIPCK(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        HIPCK(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+      }
+      HIPCK(hipStreamSynchronize(st)); // longl is a local
+    }
   }
   if (h->tiled_row && (rc0 = make_segperm(h, true, &h->rowperm))) return rc0;
   // Line-search rounds over the still-searching segments only (glrm_tiled.hpp: TiledArgs::actlist_out).  Columns: the passes after the
@@ -293,7 +324,7 @@ template <int G, int R, int NW, int TILE, int LOSS, int LW = 0>
 static int launch_tiled_inst(int kind, const TiledArgs& a, hipStream_t st) {
   constexpr int SPB = (NW - LW) * (64 / G);
   const int lds = tile_lds_bytes<G, R, TILE, LW>() + (loss_mode(LOSS) == 2 && a.descid ? a.n_udesc * 32 : 0);
-  const unsigned gx = (unsigned)((a.nseg + SPB - 1) / SPB);
+  const unsigned gx = (unsigned)(((a.npass > 0 ? a.npass : a.nseg) + SPB - 1) / SPB);
   int rc = GLRM_OK;
   if (kind == 0 && a.fixed_alpha > 0.0) {
     if ((rc = set_lds(tiled_sweep_kernel<G, R, NW, TILE, LOSS, true, LW>, lds))) return rc;
@@ -438,6 +469,14 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
     a.part = h->part; a.gsum = h->gsum; a.trial = h->trialbuf; a.jold = h->joldbuf;
     a.active = h->activebuf; a.ntrial = h->ntrialbuf; a.nactive = h->nactive;
     a.segperm = h->colperm;
+    if (h->blk_nlong_c > 0) { // the columns at or above long_from run on the gather sweep beside the passes (run_sweep, glrm_hip.hip)
+      a.long_from = h->blk_long_from;
+      a.npass = h->blk_nshort_c;
+      if (a.npass == 0) { // every local column is diverted
+        HIPCK(hipMemsetAsync(h->nactive, 0, 4, h->stream));
+        return GLRM_OK;
+      }
+    }
   }
   int rc;
   const bool lists = h->actlist && (rows ? (h->tile_rounds & 1) != 0 : (h->tile_rounds & 2) != 0) && a.nseg <= h->actlist_cap;
@@ -474,6 +513,7 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
     if (compact) {
       t.segperm = list[cur];
       t.nseg = nact;
+      t.npass = 0;
     }
     if ((rc = launch_tiled(h, loss, rows && row_rounds ? 4 : 2, t))) return rc;
     TiledArgs d = full;

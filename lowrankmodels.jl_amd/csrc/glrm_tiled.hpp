@@ -787,7 +787,7 @@ __global__ void __launch_bounds__(NW * 64, L2 ? 1 : 4) tiled_col_pass_kernel(con
   const int j = lane % G, gi = lane / G;
   const int64_t slot = (L2 ? a.seg_begin : 0) + (int64_t)blockIdx.x * SPB + (wave - LW) * NGW + gi;
   const int sup = L2 ? a.sup_fixed : (int)blockIdx.y;
-  bool have = wave >= LW && slot < (L2 ? a.seg_begin + a.nseg_slice : a.nseg);
+  bool have = wave >= LW && slot < (L2 ? a.seg_begin + a.nseg_slice : (a.npass > 0 ? a.npass : a.nseg));
   const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[slot] : slot; // which column a group works on does not change any sum
   if (!GRAD && have) have = a.active[seg] != 0;
   if (!GRAD && !__syncthreads_or(have ? 1 : 0)) return; // nothing left to evaluate in this column group

@@ -75,22 +75,24 @@ def test_two_ragged_shards_of_a_power_law_omega_equal_one_handle(monkeypatch, fa
     assert np.array_equal(o2, o1[1:]) and np.array_equal(X2, X1) and np.array_equal(Y2, Y1)
 
 
-def test_phase_aligned_passes_on_skewed_columns_add_in_their_reported_order(monkeypatch):
-    """Round 5: the phase-aligned column passes hand their columns out longest first (which slot a column sits in changes no sum) and divert
-    the columns of at least glrm_sum_order.long_from observations to the 8-wave gather sweep beside the passes.  The engine reports that
-    rule, the oracle adds in the reported order -- windowed for the short columns, strided on 8 waves for the diverted ones -- and lands on
-    the engine's factors BIT FOR BIT; two ragged shards divert the same columns."""
+@pytest.mark.parametrize("family", ["blocked", "tiled"])
+def test_pass_families_on_skewed_columns_add_in_their_reported_order(monkeypatch, family):
+    """Round 5: the phase-aligned column passes hand their columns out longest first (which slot a column sits in changes no sum), and both
+    pass families -- phase-aligned and LDS-tiled -- divert the columns of at least glrm_sum_order.long_from observations to the 8-wave
+    gather sweep beside the passes.  The engine reports that rule, the oracle adds in the reported order -- windowed for the short columns,
+    strided on 8 waves for the diverted ones -- and lands on the engine's factors BIT FOR BIT; two ragged shards divert the same columns."""
     import test_gpu_sum_order as S
-    for k_, v in FAMILIES["blocked"][0].items():
+    env, kw, bits = FAMILIES[family]
+    for k_, v in env.items():
         monkeypatch.setenv(k_, v)
-    monkeypatch.setenv("GLRM_HIP_BLOCKED_LONG_FROM", "3000")
+    monkeypatch.setenv("GLRM_HIP_BLOCKED_LONG_FROM" if family == "blocked" else "GLRM_HIP_TILED_LONG_FROM", "3000")
     w, pa, X0, Y0 = problem(m=20000, n=1500, k=64, nnz=1_500_000, nonneg=True)
     lens = np.diff(pa.colptr)
     assert (lens >= 3000).sum() >= 5 and (lens < 3000).sum() > 1000          # both kinds of column exist
-    o = S.engine_and_oracle_in_its_order(pa, X0, Y0, 6, 32, ("windowed", "windowed"))
+    o = S.engine_and_oracle_in_its_order(pa, X0, Y0, 6, bits & 34, ("windowed", "windowed"), **kw)
     assert o[1].long_from == 3000 and o[0].long_from == 0
     api = _capi.hip_api()
     params = L.ProxGradParams(max_iter=4, abs_tol=0.0, rel_tol=-1.0)
-    o1, X1, Y1, _ = cases.run_engine(api, pa, X0, Y0, params)
-    o2, X2, Y2, _ = cases.run_shards_on_one_device(api, pa, X0, Y0, params, [0, 7000, pa.m], [0, 400, pa.n], x_chunks=2)
+    o1, X1, Y1, _ = cases.run_engine(api, pa, X0, Y0, params, **kw)
+    o2, X2, Y2, _ = cases.run_shards_on_one_device(api, pa, X0, Y0, params, [0, 7000, pa.m], [0, 400, pa.n], x_chunks=2, **kw)
     assert np.array_equal(o2, o1[1:]) and np.array_equal(X2, X1) and np.array_equal(Y2, Y1)
