@@ -238,11 +238,13 @@ int glrm_setup_tiled(glrm_handle* h) {
     // Skewed column lengths (round 5, like the phase-aligned passes: glrm_blocked.hip).  The columns are already handed out sorted by
     // length; a workgroup's 256 columns walk a tile in lockstep (one barrier per tile), so ONE column many times the others keeps its
     // workgroup on every tile for its own entries alone, and the few workgroups of the head of the sorted list are the makespan (C2
-    // recipe with Zipf(0.5) degrees: Y half-step 22.1 ms against 9.0).  Columns of at least long_from = max(4 096, 2 x the whole problem's
+    // recipe with Zipf(0.5) degrees: Y half-step 22.1 ms against 9.0).  Columns of at least long_from = max(4 096, 4 x the whole problem's
     // mean column length) observations leave the passes for the 8-wave gather sweep on the side stream: a function of the column's own
-    // length and the whole problem's signature (shard-invariant), reported in glrm_sum_order.long_from.
+    // length and the whole problem's signature (shard-invariant), reported in glrm_sum_order.long_from.  Measured at C2-Zipf (mean 50 266,
+    // longest 879 189): Y half-step 27.5 / 19.0 / 16.2 / 17.1 ms at 1 / 2 / 4 / 8 x mean (profiles/r05_c2_zipf_long_from_sweep.txt): the
+    // gather sweep pays 536 B per update where the tiles pay a fraction, so only the head of the distribution is worth diverting.
     const int64_t mean_len = h->sig.nnz_cols / (h->n > 0 ? h->n : 1);
-    h->blk_long_from = env_int("GLRM_HIP_TILED_LONG_FROM", -1) >= 0 ? env_int("GLRM_HIP_TILED_LONG_FROM", 0) : std::max<int64_t>(4096, 2 * mean_len);
+    h->blk_long_from = env_int("GLRM_HIP_TILED_LONG_FROM", -1) >= 0 ? env_int("GLRM_HIP_TILED_LONG_FROM", 0) : std::max<int64_t>(4096, 4 * mean_len);
     std::vector<int32_t> longl;
     if ((rc0 = make_segperm(h, false, &h->colperm, h->blk_long_from, &longl, &h->blk_nshort_c))) return rc0;
     h->blk_nlong_c = (int64_t)longl.size();
