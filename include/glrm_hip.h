@@ -143,8 +143,8 @@ typedef struct glrm_domain {
                                         (src/glrm.jl:46-48, src/modify_glrm.jl:8-12).  rowptr / colidx / rowvals must be NULL: the engine derives
                                         the row view from the column view on the device (one stable sort of the column-major stream by
                                         row id).  A host holding a CSC matrix hands over colptr / rowval / nzval after an index shift and
-                                        nothing else.  Whole-problem list handles (row and column range complete), <= 1.5e9 observations,
-                                        not with GLRM_PROBLEM_BORROW_DEVICE_ARRAYS. */
+                                        nothing else.  Whole-problem list handles (row and column range complete), any observation count
+                                        (beyond 1.5e9 the stream is sorted in row ranges), not with GLRM_PROBLEM_BORROW_DEVICE_ARRAYS. */
 #define GLRM_PROBLEM_DEFER_SETUP 2   /* flags bit 1: this is one shard of a sharded fit -- glrm_hip_create only uploads it; the host
                                         combines the shards' glrm_signature and calls glrm_hip_finalize on every shard before the
                                         first step (see glrm_signature below) */

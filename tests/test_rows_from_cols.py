@@ -1,7 +1,8 @@
 """GLRM_PROBLEM_ROWS_FROM_COLS (include/glrm_hip.h): Omega as a sparse matrix's pattern handed over as its column view only
 (colptr / rowval / nzval of a CSC matrix after an index shift) -- the row view, every row's entries by ascending column like
 `sort_observations` pushes the CartesianIndices of `findall(!iszero, A)` (src/glrm.jl:46-48, src/modify_glrm.jl:8-12), is derived by the
-library.  CPU: the oracle's twin.  -m gpu: the engine's device-side derivation (one stable radix sort of the column-major stream by row
+library.  An Omega beyond what one hipCUB sort takes (1.5e9 entries; C5 holds 5e9) is sorted in row ranges: GLRM_HIP_TRANSPOSE_CHUNK lowers that
+bound so the ranged path runs here on small patterns.  CPU: the oracle's twin.  -m gpu: the engine's device-side derivation (one stable radix sort of the column-major stream by row
 id) gives exactly the handle built from both views -- same factors bit for bit -- on sorted patterns, patterns with duplicates, empty
 rows and columns, through the in-library multi-GPU create (host-side transpose there), and refuses what the flag does not cover."""
 import numpy as np
@@ -79,6 +80,25 @@ def test_device_side_row_view_gives_the_handle_built_from_both_views(shape):
     o_c = cases.run_engine(O.oracle_api(), cols_only, X0, Y0, L.ProxGradParams(max_iter=8))
     o_g = cases.run_engine(api, cols_only, X0, Y0, L.ProxGradParams(max_iter=8))
     assert cases.rel_err(o_g[0], o_c[0]) < 1e-5 and cases.fro_err(o_g[1], o_c[1]) < 1e-5 and cases.fro_err(o_g[2], o_c[2]) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [1, 97, 5000, 60000])
+@pytest.mark.parametrize("shape", [(3000, 250, 8, 0.08, False), (700, 300, 5, 0.15, True), (40, 900, 8, 0.02, False)])
+def test_row_ranges_give_the_same_row_view(shape, chunk, monkeypatch):
+    """Row ranges of at most `chunk` entries (one row at least: chunk = 1 sorts row by row, 60000 = one or two ranges): the same handle."""
+    m, n, k, dens, dup = shape
+    rng = np.random.default_rng(m + n + 1)
+    both, cols_only, X0, Y0 = pattern(rng, m, n, k, dens, dup=dup)
+    if chunk == 1 and m > 1000:
+        pytest.skip("row-by-row on the small patterns only")
+    api = _capi.hip_api()
+    p = L.ProxGradParams(max_iter=5)
+    a = cases.run_engine(api, both, X0, Y0, p)
+    monkeypatch.setenv("GLRM_HIP_TRANSPOSE_CHUNK", str(chunk))
+    b = cases.run_engine(api, cols_only, X0, Y0, p)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert a[3]["nnz_rows"] == b[3]["nnz_rows"]
 
 
 @pytest.mark.gpu
