@@ -166,8 +166,10 @@ function fit!(glrm::GLRM, p::HipProxGradParams; ch::ConvergenceHistory=Convergen
     h = handle(glrm, desc, p)
     prm = CParams(p.stepsize, p.max_iter, p.inner_iter_X, p.inner_iter_Y, p.abs_tol, p.rel_tol, p.min_stepsize)
     verbose && println("Fitting GLRM")
-    check(ccall(p.ngpus > 1 ? (:glrm_hip_multi_fit, LIB) : (:glrm_hip_fit, LIB), Cint,
-                (Ptr{Cvoid}, Ref{CParams}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}),
+    check(p.ngpus > 1 ?                      # (a `ccall` target is a constant expression: one literal call per entry point)
+          ccall((:glrm_hip_multi_fit, LIB), Cint, (Ptr{Cvoid}, Ref{CParams}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}),
+                h, prm, X, Y, obj, sec, cap, nrec) :
+          ccall((:glrm_hip_fit, LIB), Cint, (Ptr{Cvoid}, Ref{CParams}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64, Ref{Int64}),
                 h, prm, X, Y, obj, sec, cap, nrec))
     X === glrm.X || copyto!(glrm.X, X)
     scaled_abs_tol = p.abs_tol * sum(length, glrm.observed_features)                  # src/algorithms/proxgrad.jl:72

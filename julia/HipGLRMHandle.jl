@@ -3,7 +3,12 @@
 # regularizers only replace descriptors (glrm_hip_set_regularizers).
 mutable struct Entry; h::Ptr{Cvoid}; multi::Bool; hard::UInt64; soft::UInt64; end
 const CACHE = IdDict{Any,Entry}()
-destroy(e::Entry) = (e.h == C_NULL || ccall(e.multi ? (:glrm_hip_multi_destroy, LIB) : (:glrm_hip_destroy, LIB), Cvoid, (Ptr{Cvoid},), e.h); e.h = C_NULL)
+# (a `ccall` target is a constant expression: one literal call per entry point, the choice is made around it)
+function destroy(e::Entry)
+    e.h == C_NULL && return
+    e.multi ? ccall((:glrm_hip_multi_destroy, LIB), Cvoid, (Ptr{Cvoid},), e.h) : ccall((:glrm_hip_destroy, LIB), Cvoid, (Ptr{Cvoid},), e.h)
+    e.h = C_NULL
+end
 "Drop the device copy of a model's data (also done by the model's finalizer).  Call it after mutating `glrm.A` in place."
 hip_release!(glrm::GLRM) = (haskey(CACHE, glrm) && (destroy(CACHE[glrm]); delete!(CACHE, glrm)); glrm)
 # what the device copy depends on (data, Omega, losses, placement, options) / what set_regularizers can replace
@@ -19,8 +24,8 @@ function handle(glrm::GLRM, desc, p)
     if e !== nothing && e.hard == hard
         if e.soft != soft                   # scale_regularizer! / regularization_path: Omega and A stay on the device
             rx, ry = desc[2], desc[3]
-            check(ccall(multi ? (:glrm_hip_multi_set_regularizers, LIB) : (:glrm_hip_set_regularizers, LIB), Cint,
-                        (Ptr{Cvoid}, Ptr{CReg}, Int64, Ptr{CReg}, Int64), e.h, rx, length(rx), ry, length(ry)))
+            check(multi ? ccall((:glrm_hip_multi_set_regularizers, LIB), Cint, (Ptr{Cvoid}, Ptr{CReg}, Int64, Ptr{CReg}, Int64), e.h, rx, length(rx), ry, length(ry)) :
+                          ccall((:glrm_hip_set_regularizers, LIB), Cint, (Ptr{Cvoid}, Ptr{CReg}, Int64, Ptr{CReg}, Int64), e.h, rx, length(rx), ry, length(ry)))
             e.soft = soft
         end
         return e.h

@@ -117,6 +117,17 @@ def test_every_ccall_names_a_declared_symbol():
         assert used or f == "HipGLRMDescriptors.jl", f
 
 
+def test_every_ccall_target_is_a_literal():
+    """Julia resolves a `ccall` target at compile time: `(:symbol, LIB)` must be written out in the call (LIB is a `const`), a target
+    chosen by an expression -- `ccall(multi ? (:a, LIB) : (:b, LIB), ...)` -- is a TypeError at run time.  Nothing here can run Julia, so
+    the shape is checked textually."""
+    for f in JULIA_FILES:
+        txt = re.sub(r"#.*", "", open(os.path.join(ROOT, "julia", f)).read())
+        calls = len(re.findall(r"\bccall\(", txt))
+        literal = len(re.findall(r"\bccall\(\s*\(:glrm_hip_\w+, LIB\)\s*,", txt))
+        assert calls == literal, (f, calls, literal)
+
+
 def test_the_marshalling_core_stays_within_its_line_budget():
     """the Julia side is <= 150 lines of pure marshalling.  Counted: the code lines (not blank, not comment) of
     julia/HipGLRM.jl -- struct mirrors, the params type, Omega -> CSR / CSC, create, fit!; the type -> descriptor tables, the handle cache
