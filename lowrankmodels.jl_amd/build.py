@@ -38,14 +38,17 @@ def build_all(force=False, verbose=True):
         if force or _stale(out, deps):
             # one hipcc -c per source, in parallel, then link
             objs, procs = [], []
+            hdr_paths = deps[len(src_paths):]
             for sp in src_paths:
                 obj = os.path.join(PKG, "build", os.path.basename(sp) + ".o")
                 os.makedirs(os.path.dirname(obj), exist_ok=True)
+                objs.append(obj)
+                if not force and not _stale(obj, [sp] + hdr_paths):  # this object is newer than its source and every header
+                    continue
                 cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", sp, "-o", obj]
                 if verbose:
                     print("[build]", " ".join(cmd), flush=True)
                 procs.append((cmd, subprocess.Popen(cmd)))
-                objs.append(obj)
             for cmd, pr in procs:
                 if pr.wait() != 0:
                     raise subprocess.CalledProcessError(pr.returncode, cmd)
