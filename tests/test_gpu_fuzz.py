@@ -109,6 +109,12 @@ def well_conditioned_prefix(pa, X0, Y0, p, seed):
         q = L.ProxGradParams(p.stepsize, max_iter=T, inner_iter=p.inner_iter_X, abs_tol=0.0, rel_tol=-1.0)
         o_a, X_a, Y_a, _ = cases.run_engine(api, pa, X0, Y0, q)
         o_b, X_b, Y_b, _ = cases.run_engine(api, pa, Xp, Y0, q)
+        if len(o_a) != len(o_b):
+            # one of the two runs stopped early (with these tolerances: the recorded objective ROSE after iteration 10,
+            # src/algorithms/proxgrad.jl:210-213) and the other did not -- the stop decision at that iteration hangs on the perturbation:
+            # the stable prefix ends before it (soak seed 30301: 13 vs 14 recorded objectives)
+            T = min(len(o_a), len(o_b)) - 2
+            continue
         with np.errstate(all="ignore"):
             rel = np.abs(o_a - o_b) / np.abs(o_a)
         ok = (rel < 1e-9) | (o_a == o_b)
