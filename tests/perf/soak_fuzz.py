@@ -5,6 +5,10 @@ oracle's own trajectory is stable (well_conditioned_prefix); scalar-loss models 
 third seed, through a three-shard set-up on one device that must reproduce the single-shard fit bit for bit.  A deviation above the
 tolerance is a FAIL only if the oracle reproduces itself from eight 1e-13-perturbed starts (otherwise: "ill-conditioned").
     python tests/perf/soak_fuzz.py FIRST LAST      # seeds FIRST .. LAST-1; prints one line per failure and a summary
+    python tests/perf/soak_fuzz.py FIRST LAST --reference-order
+        the engine's reference-order mode (glrm_options.sum_order = 1) on random_model(seed, exact_scalar=True): scalar losses both sides
+        evaluate with the same instructions, 40-120 iterations under the seed's own stop rule, the WHOLE run -- stable or not -- must equal
+        the oracle's bit for bit (objectives after the initial one, factors, line-search totals)
 """
 import importlib.util
 import os
@@ -196,13 +200,32 @@ def one(seed):
             os.environ.pop(k_, None)
 
 
+def one_reference_order(seed):
+    g, p = fz.random_model(seed, exact_scalar=True)
+    pa = g.problem_arrays()
+    scalar = L.embedding_dim(g.losses) == g.n and not getattr(g, "offset", False) and all(int(r["wrap"]) == 0 for r in list(pa.rx) + list(pa.ry))
+    if not scalar or g.k > 64 or not all(int(l["kind"]) in fz.EXACT_KINDS for l in pa.losses):
+        return "skip", "reference-order", None
+    X0, Y0 = np.asfortranarray(g.X), np.asfortranarray(g.Y)
+    o_c, X_c, Y_c, st_c = cases.run_engine(O.oracle_api(), pa, X0, Y0, p)
+    o_g, X_g, Y_g, st_g = cases.run_engine(_capi.hip_api(), pa, X0, Y0, p, sum_order=1)
+    LAST["iterations"] = len(o_g) - 1
+    same = (st_g["tiled"] == 128 and len(o_g) == len(o_c) and np.array_equal(np.nan_to_num(o_g[1:]), np.nan_to_num(o_c[1:]))
+            and (np.isnan(o_g[1:]) == np.isnan(o_c[1:])).all() and np.array_equal(X_g, X_c) and np.array_equal(Y_g, Y_c)
+            and all(st_g[key] == st_c[key] for key in ("trials_x", "trials_y", "accepts_x", "accepts_y")))
+    return ("ok" if same else "FAIL"), "reference-order", (len(o_g) - 1, len(o_c) - 1)
+
+
 def main():
     first, last = int(sys.argv[1]), int(sys.argv[2])
+    ref_mode = "--reference-order" in sys.argv[3:]
     O.set_threads(4)
-    tally, t0 = {}, time.time()
+    tally, t0, iters = {}, time.time(), []
     for seed in range(first, last):
         try:
-            res, fam, detail = one(seed)
+            res, fam, detail = one_reference_order(seed) if ref_mode else one(seed)
+            if res == "ok":
+                iters.append(LAST["iterations"])
         except AssertionError as ex:  # finite / non-finite pattern differs
             res, fam, detail = "FAIL", "?", ("assert", str(ex)[:200])
             try:
@@ -220,7 +243,12 @@ def main():
         tally[(res, fam)] = tally.get((res, fam), 0) + 1
         if res not in ("ok", "skip", "ill-conditioned"):
             print(f"seed {seed} [{fam}]: {res} {detail}", flush=True)
-    print(f"seeds {first}..{last - 1} in {time.time() - t0:.0f} s:", flush=True)
+        if (seed - first + 1) % 250 == 0:  # a run cut short by its time limit still says how far it got
+            print(f"  ... {seed - first + 1} seeds in {time.time() - t0:.0f} s: " + ", ".join(f"{r} {c}" for r, c in sorted(
+                {r: sum(c for (r2, _), c in tally.items() if r2 == r) for r in {k_[0] for k_ in tally}}.items())), flush=True)
+    print(f"seeds {first}..{last - 1} in {time.time() - t0:.0f} s" + (" (reference-order mode, whole runs, bit for bit)" if ref_mode else "") + ":", flush=True)
+    if iters:
+        print(f"  iterations compared per ok seed: min {min(iters)}, median {int(np.median(iters))}, max {max(iters)}, total {sum(iters)}")
     for (res, fam), c in sorted(tally.items()):
         print(f"  {res:15s} {fam:18s} {c}")
     bad = sum(c for (res, _), c in tally.items() if res not in ("ok", "skip", "ill-conditioned"))
