@@ -87,10 +87,12 @@ def test_three_ranks_ragged_blocks(tmp_path, mode):
         assert np.array_equal(z["nnmf_obj"][1:], np.array(ch.objective[1:]))
 
 
-def test_pipelined_x_exchange_equals_one_rank(tmp_path):
+@pytest.mark.parametrize("arrival", ["1", "0"])
+def test_pipelined_x_exchange_equals_one_rank(tmp_path, arrival):
     """GLRM_X_CHUNKS=2: the X half-step runs in two row chunks whose all-gather is pipelined behind the next chunk
-    (glrm_*_step_x_range); rows are independent, so the result is still the single-process bits."""
-    ranks = run_world(tmp_path, ["c1", "kmeans"], 2, {"GLRM_X_CHUNKS": "2"})
+    (glrm_*_step_x_range); rows are independent, so the result is still the single-process bits.  GLRM_ARRIVAL=1 (default): the first inner
+    Y sweep is told which rows every chunk exchange fills (glrm_*_step_y_arrival) instead of waiting for the pipeline; 0: the wait."""
+    ranks = run_world(tmp_path, ["c1", "kmeans"], 2, {"GLRM_X_CHUNKS": "2", "GLRM_ARRIVAL": arrival})
     O.set_threads(1)
     for name in ["c1", "kmeans"]:
         kwargs, params = cases.build_golden_case(name)
