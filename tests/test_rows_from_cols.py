@@ -54,6 +54,13 @@ def test_oracle_twin(dup):
     same_fit(O.oracle_api(), *pattern(rng, 300, 70, 5, 0.2, dup=dup))
 
 
+def test_oracle_twin_on_an_empty_pattern_and_a_single_entry():
+    api = O.oracle_api()
+    same_fit(api, *pattern(np.random.default_rng(1), 30, 12, 3, 0.0))       # no observation at all: the line searches run on the regularizers alone
+    both, cols_only, X0, Y0 = pattern(np.random.default_rng(2), 1, 1, 2, 1.0)
+    same_fit(api, both, cols_only, X0, Y0)
+
+
 def test_oracle_twin_refuses_misuse():
     rng = np.random.default_rng(5)
     both, cols_only, X0, Y0 = pattern(rng, 60, 20, 3, 0.3)
@@ -99,6 +106,18 @@ def test_row_ranges_give_the_same_row_view(shape, chunk, monkeypatch):
     b = cases.run_engine(api, cols_only, X0, Y0, p)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert a[3]["nnz_rows"] == b[3]["nnz_rows"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("chunk", [None, 7])
+def test_device_side_row_view_of_an_empty_pattern_and_a_single_entry(chunk, monkeypatch):
+    if chunk:
+        monkeypatch.setenv("GLRM_HIP_TRANSPOSE_CHUNK", str(chunk))
+    api = _capi.hip_api()
+    same_fit(api, *pattern(np.random.default_rng(1), 30, 12, 3, 0.0))
+    same_fit(api, *pattern(np.random.default_rng(2), 1, 1, 2, 1.0))
+    same_fit(api, *pattern(np.random.default_rng(3), 1, 40, 2, 0.5))         # one row holding everything: a range of one row
+    same_fit(api, *pattern(np.random.default_rng(4), 40, 1, 2, 0.5))
 
 
 @pytest.mark.gpu
