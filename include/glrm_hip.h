@@ -321,7 +321,12 @@ int glrm_hip_step_y(glrm_handle* h, double min_stepsize);                   /* o
  * super-tile) that col_reduce adds in super-tile order whatever order the launches ran in: they launch each super-tile behind the events
  * of the blocks it touches, own rows first, so the exchange overlaps the half-step that consumes it.  Every other family waits for all
  * events and then runs glrm_hip_step_y.  Results are those of glrm_hip_step_y bit for bit.  With glrm_options.profile the time the
- * launch stream spent in those waits is accounted in glrm_kernel_stats.ms_wait_y. */
+ * launch stream spent in those waits is accounted in glrm_kernel_stats.ms_wait_y.
+ * TRUE arrival order (default; GLRM_HIP_ARRIVAL_DYNAMIC=0 restores the announced order): a super-tile is enqueued once the events of all
+ * its blocks have fired (hipEventQuery), the ready ones in the announced order, and the calling thread polls for the rest -- behind a
+ * lagging peer the launch stream no longer stands in front of its block while other super-tiles are ready.  The call therefore returns
+ * only when every block has arrived (the line search that follows reads its counters back anyway).  An event that cannot be queried, or
+ * 5 s without progress, hands the remaining super-tiles to in-stream waits in the announced order. */
 typedef struct glrm_arrival {
   int64_t begin, end; /* rows [begin, end) of X */
   void* event;        /* hipEvent_t or NULL */

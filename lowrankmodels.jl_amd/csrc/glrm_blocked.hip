@@ -24,6 +24,9 @@
 #include <utility>
 #include <vector>
 
+#include <chrono>
+#include <thread>
+
 #include "glrm_engine.hpp"
 #include "glrm_tiled.hpp"
 
@@ -176,10 +179,9 @@ static int launch_blocked_inst(glrm_handle* h, TiledArgs a, bool rows) {
   // the events of the blocks it touches (h->sup_order, glrm_run_blocked); the partial sums are per (segment, super-tile) and col_reduce
   // adds them in super-tile order, so the launch order changes no bit
   const bool ordered = GRAD && !rows && h->n_arrival > 0 && (int)h->sup_order.size() == a.nsup;
-  for (int si = 0; si < a.nsup; ++si) {
-    const int sup = ordered ? h->sup_order[si] : si;
+  const int64_t rows_per_sup = (int64_t)a.tiles_per_sup * T;
+  auto launch_sup = [&](int sup) -> int { // one super-tile: behind the events of the blocks it touches (ordered), slice by slice
     if (ordered) {
-      const int64_t rows_per_sup = (int64_t)a.tiles_per_sup * T;
       const int rcw = glrm_arrival_wait(h, sup * rows_per_sup, std::min<int64_t>((sup + 1) * rows_per_sup, a.n_other));
       if (rcw) return rcw;
     }
@@ -189,6 +191,51 @@ static int launch_blocked_inst(glrm_handle* h, TiledArgs a, bool rows) {
       a.nseg_slice = std::min(per, nseg - s0);
       hipLaunchKernelGGL(kernel, dim3((unsigned)((a.nseg_slice + SPB - 1) / SPB)), dim3(BNW * 64), 0, h->stream, a);
     }
+    return GLRM_OK;
+  };
+  std::vector<int> pend;
+  if (ordered) pend = h->sup_order;
+  else for (int si = 0; si < a.nsup; ++si) pend.push_back(si);
+  if (ordered && env_int("GLRM_HIP_ARRIVAL_DYNAMIC", 1)) {
+    // TRUE arrival order.  The fixed order above is the order blocks arrive in when every peer keeps pace; behind a lagging peer the
+    // in-order stream would stand in front of its block while super-tiles further down the list are ready.  So the host enqueues a
+    // super-tile only once the events of ALL its blocks have fired (hipEventQuery), the ready ones in list order, and polls for the
+    // rest: the stream never stands in a wait while work is ready.  An event that cannot be queried (or 5 s without any progress) hands
+    // the remaining super-tiles to the in-stream waits below.  Which order the super-tiles run in changes no bit.
+    std::vector<char> fired((size_t)h->n_arrival, 0);
+    bool unknown = false;
+    auto ready = [&](int sup) {
+      const int64_t lo = sup * rows_per_sup, hi = std::min<int64_t>((sup + 1) * rows_per_sup, a.n_other);
+      for (int b = 0; b < h->n_arrival; ++b) {
+        const glrm_arrival& blk = h->arrival[b];
+        if (fired[b] || !blk.event || blk.end <= lo || blk.begin >= hi) continue;
+        const hipError_t q = hipEventQuery((hipEvent_t)blk.event);
+        if (q == hipSuccess) { fired[b] = 1; continue; }
+        (void)hipGetLastError();
+        if (q != hipErrorNotReady) unknown = true;
+        return false;
+      }
+      return true;
+    };
+    auto t_progress = std::chrono::steady_clock::now();
+    while (!pend.empty() && !unknown) {
+      bool progressed = false;
+      for (size_t i = 0; i < pend.size() && !unknown;) {
+        if (!ready(pend[i])) { ++i; continue; }
+        const int rcl = launch_sup(pend[i]);
+        if (rcl) return rcl;
+        pend.erase(pend.begin() + (long)i);
+        progressed = true;
+      }
+      const auto now = std::chrono::steady_clock::now();
+      if (progressed) t_progress = now;
+      else if (std::chrono::duration<double>(now - t_progress).count() > 5.0) break;
+      else std::this_thread::sleep_for(std::chrono::microseconds(20));
+    }
+  }
+  for (int sup : pend) {
+    const int rcl = launch_sup(sup);
+    if (rcl) return rcl;
   }
   HIPCK(hipGetLastError());
   return GLRM_OK;

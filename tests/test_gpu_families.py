@@ -432,13 +432,18 @@ def test_a_step_size_that_lands_exactly_on_the_minimum_ends_the_search(monkeypat
 
 # ------------------------------------------------------------------------------------------------ the Y half-step while X is arriving
 
-def test_arrival_order_y_half_step_gives_the_bits_of_step_y(monkeypatch):
+@pytest.mark.parametrize("dynamic", ["1", "0"])
+def test_arrival_order_y_half_step_gives_the_bits_of_step_y(monkeypatch, dynamic):
     """glrm_hip_step_y_arrival (include/glrm_hip.h): the phase-aligned column passes launch each super-tile of X behind the events of the
     blocks it touches, in the order the host announces them -- own rows first, then the peers' chunks.  Partial sums are per (column,
     super-tile) and col_reduce adds them in super-tile order, so the result is glrm_hip_step_y's bit for bit whatever the order.  The
     events here fire late (a side stream that sleeps before each record): the launches really stand behind them.  Profile: the waits are
-    accounted in kernel_stats.ms_wait_y.  Bad block lists are refused."""
+    accounted in kernel_stats.ms_wait_y.  Bad block lists are refused.
+    dynamic = 1 (default): the host enqueues a super-tile once the events of all its blocks have FIRED (hipEventQuery) and polls for the
+    rest -- true arrival order, the stream never stands behind a lagging block while other super-tiles are ready; 0: every super-tile is
+    enqueued at once in the announced order behind in-stream waits."""
     import torch
+    monkeypatch.setenv("GLRM_HIP_ARRIVAL_DYNAMIC", dynamic)
     force_blocked(monkeypatch)           # one tile unit per super-tile: 6000 rows of X = dozens of super-tiles
     pa, X0, Y0, _, _ = c4_problem(6000, 600, 100)
     api = hip()
@@ -493,7 +498,9 @@ def test_arrival_order_y_half_step_gives_the_bits_of_step_y(monkeypatch):
         assert np.array_equal(Xa, Xp) and np.array_equal(Ya, Yp)
     for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
         assert st1[key] == st0[key]
-    assert st0["ms_wait_y"] == 0.0 and st1["ms_wait_y"] > 0.0      # the launch stream did stand in front of late blocks (most of the pauses hide behind the super-tiles already there)
+    assert st0["ms_wait_y"] == 0.0
+    if dynamic == "0":
+        assert st1["ms_wait_y"] > 0.0      # the launch stream did stand in front of late blocks (most of the pauses hide behind the super-tiles already there)
 
 
 def test_arrival_order_on_a_family_that_needs_all_of_x_waits_for_everything(monkeypatch):
