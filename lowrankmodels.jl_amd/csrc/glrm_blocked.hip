@@ -196,12 +196,12 @@ static int launch_blocked_inst(glrm_handle* h, TiledArgs a, bool rows) {
   std::vector<int> pend;
   if (ordered) pend = h->sup_order;
   else for (int si = 0; si < a.nsup; ++si) pend.push_back(si);
-  if (ordered && env_int("GLRM_HIP_ARRIVAL_DYNAMIC", 1)) {
+  if (ordered && !h->arrival_static && env_int("GLRM_HIP_ARRIVAL_DYNAMIC", 1)) {
     // TRUE arrival order.  The fixed order above is the order blocks arrive in when every peer keeps pace; behind a lagging peer the
     // in-order stream would stand in front of its block while super-tiles further down the list are ready.  So the host enqueues a
     // super-tile only once the events of ALL its blocks have fired (hipEventQuery), the ready ones in list order, and polls for the
     // rest: the stream never stands in a wait while work is ready.  An event that cannot be queried (or 5 s without any progress) hands
-    // the remaining super-tiles to the in-stream waits below.  Which order the super-tiles run in changes no bit.
+    // the remaining super-tiles -- and every later call on this handle -- to the in-stream waits below.  Which order the super-tiles run in changes no bit.
     std::vector<char> fired((size_t)h->n_arrival, 0);
     bool unknown = false;
     auto ready = [&](int sup) {
@@ -232,6 +232,7 @@ static int launch_blocked_inst(glrm_handle* h, TiledArgs a, bool rows) {
       else if (std::chrono::duration<double>(now - t_progress).count() > 5.0) break;
       else std::this_thread::sleep_for(std::chrono::microseconds(20));
     }
+    if (!pend.empty()) h->arrival_static = true; // gave up: this handle keeps to the in-stream waits (no 5 s stall per iteration)
   }
   for (int sup : pend) {
     const int rcl = launch_sup(sup);

@@ -147,6 +147,7 @@ struct glrm_handle {
   const glrm_arrival* arrival = nullptr;
   int n_arrival = 0;
   std::vector<char> arrival_waited;
+  bool arrival_static = false; // true arrival order gave up once (an event that cannot be queried, 5 s without progress): in-stream waits from then on
   std::vector<int> sup_order;
   double ms_wait = 0;                 // profile: time the launch stream stood in those waits
   int sum_order_opt = 0;              // glrm_options.sum_order (1: reference-order validation sweeps, glrm_reforder.hip)
