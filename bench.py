@@ -13,8 +13,9 @@ X and Y replicated, one all-gather of the updated factor after each half-step; -
 Other configs: --config C2 | C3 | C5.
 
     python bench.py                                  # C4 on one GPU
+    python bench.py --gpus N                         # no launcher: spawns its own N ranks (torch.distributed.run on 127.0.0.1), one per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W       # the driver's launcher form: used as it is
 
 The JSON line carries
   roofline      the bound of the dominant kernel (the longest half-step): every candidate limiter of that kernel family is
@@ -80,6 +81,8 @@ def main():
     ap.add_argument("--zipf-s", type=float, default=0.5, help="--degree zipf: the exponent of both laws, w(rank) = (rank + 1)^-s")
     ap.add_argument("--no-create-from-host", action="store_true", help="default C4 line: skip the create-from-host-arrays leg (24 GB over PCIe, ~1 minute)")
     ap.add_argument("--no-other-configs", action="store_true", help="default C4 line at N = 1: skip the compact C2 / C3 / C5 lines (child runs, ~5 minutes)")
+    ap.add_argument("--launch-timeout", type=int, default=1500, help="--gpus N without a launcher: seconds the self-launched N-rank job may take before it is "
+                    "killed and the in-library host (one process, N devices) runs instead")
     ap.add_argument("--cpu-full", action="store_true", help="one warm-up + one timed iteration of the CPU oracle on the FULL lists of the config (minutes, tens of GB of host memory)")
     args = ap.parse_args()
     if args.emulate_rank >= 0:
@@ -88,6 +91,8 @@ def main():
         return cpu_full_leg(args)
     if args.host == "inlib":
         return inlib_host(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args, sys.argv[1:])  # plain `python bench.py --gpus N`: no launcher around us -- start the ranks ourselves
 
     import torch
     import torch.distributed as dist
@@ -110,6 +115,7 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    ranks_seen = ranks_seen_block(dist if world > 1 else None, torch, rank, dev_index)  # what the process group saw: ranks, backend, a device per rank
 
     cfg = dict(CONFIGS[args.config])
     if args.cols or args.obs_per_row or args.k:
@@ -253,8 +259,8 @@ def main():
                                     r"tiled_col_pass_kernel<[^>]*, false>"),
                  ("row", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (X half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
                  ("col", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (Y half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
-                 ("row", "cached"): ("regcached_sweep_kernel<G, R, LOSS, 7, 2> (X half-step: the row's list and opposing vectors fetched once into "
-                                     "registers, two waves per row; rows beyond 13 trips run sweep_kernel)", "regcached_sweep_kernel"),
+                 ("row", "cached"): ("regcached_persist_kernel / regcached_sweep_kernel<G, R, LOSS, 7, 2> (X half-step: the row's list and opposing vectors fetched "
+                                     "once into registers, two waves per row; rows beyond 13 trips run sweep_kernel)", r"regcached_(persist|sweep)_kernel"),
                  ("row", "dense"): ("dense_pass_kernel (X half-step, fp64 MFMA)", "dense_pass_kernel"),
                  ("col", "dense"): ("dense_pass_kernel (Y half-step, fp64 MFMA)", "dense_pass_kernel"),
                  ("row", "general"): ("multi_sweep_kernel (X half-step)", "multi_sweep_kernel"),
@@ -279,7 +285,7 @@ def main():
         out = {
             "metric": "observed-entry updates/sec", "value": value, "unit": "updates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic", "ranks_seen": ranks_seen,
             "config": {"workload": cfg["text"].format(m=m, n=n, k=k, pct=100.0 * q / n) + f" ({tot_r} observations), ProxGradParams defaults, stop rule off"
                                    + (", glrm_options.quad_gram = 1" if args.quad_gram else ""),
                        "name": args.config, "m": m, "n": n, "k": k, "observed": tot_r,

@@ -493,8 +493,11 @@ typedef struct glrm_sum_order {
   int32_t rotate;          /* WINDOWED: 1 = chunk walk i ^ ((global segment id & 7) >> 1) in the dot products of the passes */
   int64_t window;          /* WINDOWED: opposing vectors per window */
   int64_t windows_per_sup; /* WINDOWED: windows per super-tile; 0 = the whole list is one super-tile and nothing is re-added */
-  int32_t private_order;   /* 1 = the engine walks a private copy of the list in another order than the caller's (tile sort, grouping by
-                              loss kind): the order above applies to THAT copy and cannot be reproduced from the caller's lists */
+  int32_t private_order;   /* the engine walks a private copy of the list in another order than the caller's; the order above applies to
+                              THAT copy.  1 = the copy was tile-sorted (the caller's list was not ordered by window): not reproducible
+                              from the caller's lists.  2 = WINDOWED rows of a model with several loss kinds, lists already ordered by
+                              window: inside every window the entries are grouped by ascending glrm_loss.kind of their column, stably
+                              (list order inside a kind) -- a function of the caller's list alone, which the oracle restates */
   int32_t long_from;       /* WINDOWED (phase-aligned column passes): > 0 = segments of at least this many observations are swept by the
                               8-wave gather sweep instead and add in the STRIDED order (same lanes / comps, 8 waves, batch 1); 0 = none */
 } glrm_sum_order; /* 80 bytes */

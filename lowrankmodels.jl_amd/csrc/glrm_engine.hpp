@@ -203,6 +203,7 @@ int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_
 int glrm_setup_reforder(glrm_handle* h);               // finalize: refuses what the mode does not cover
 int glrm_run_reforder(glrm_handle* h, bool rows, double min_stepsize, int eval_only);
 int glrm_reforder_sum(glrm_handle* h, const void* dvec, int64_t n, double* out); // Julia's pairwise sum(::Vector{Float64})
+int glrm_reforder_objective(glrm_handle* h, int include_reg, double* out);       // objective(): ONE accumulator over all observations, then the penalties
 
 // GLRM_PROBLEM_ROWS_FROM_COLS (glrm_transpose.hip): the row view derived on the device from the uploaded column view
 int glrm_rows_from_cols(glrm_handle* h);

@@ -1430,7 +1430,8 @@ extern "C" int glrm_hip_sum_order(glrm_handle* h, int32_t which, glrm_sum_order*
     o.rotate = (!(rows && !h->row_split) && !lw && !quad && GLRM_TILE_ROT && (h->tG == 4 || h->tG == 8) && h->tR == 8) ? 1 : 0;
     // a private copy in another order: lists the engine tile-sorted, rows regrouped by loss kind inside the tile windows
     const bool sorted_here = rows ? h->sig_local.rows_unordered != 0 : h->sig_local.cols_unordered != 0;
-    o.private_order = (sorted_here || (rows && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_GROUP_KINDS", 1))) ? 1 : 0;
+    const bool grouped = rows && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_GROUP_KINDS", 1); // glrm_tiled.hpp: group_rows_by_kind_kernel
+    o.private_order = sorted_here ? 1 : grouped ? 2 : 0; // (2: stable grouping by ascending loss kind inside every window -- the oracle restates it)
   } else if (blocked) {
     const int Tb = ((150 * 1024) / (h->kp * 8 + 16)) / 16 * 16; // glrm_blocked.hip: tile_rows_b
     o.family = GLRM_ORDER_WINDOWED;
@@ -1471,6 +1472,10 @@ static double now_s() {
 static int device_objective(glrm_handle* h, int include_reg, double* out) {
   int rc;
   double loss = 0, px = 0, py = 0;
+  if (h->sum_order_opt) { // reference order: one accumulator over every observation, columns outer (src/evaluate_fit.jl:12-21)
+    if ((rc = ensure_owned(h))) return rc;
+    return glrm_reforder_objective(h, include_reg, out);
+  }
   if ((rc = run_sweep(h, 1, 0.0, 1))) return rc;
   if ((rc = glrm_hip_sum(h, h->objcol, h->n, &loss))) return rc;
   if (include_reg) {

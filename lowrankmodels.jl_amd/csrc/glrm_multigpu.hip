@@ -636,11 +636,22 @@ extern "C" int glrm_hip_multi_create(glrm_multi** out, const glrm_problem* p, co
     // from both views as usual
     if (p->dense_A || p->rowptr || p->colidx || p->rowvals) return fail(GLRM_ERR_INVALID, "GLRM_PROBLEM_ROWS_FROM_COLS: rowptr / colidx / rowvals must be NULL");
     if (p->m <= 0 || p->n <= 0 || !p->colptr) return fail(GLRM_ERR_INVALID, "m, n must be positive and colptr given");
-    const int64_t nz = p->colptr[p->n];
+    // the structure of the column view is checked BEFORE anything is counted or written through it (a colptr that does not start
+    // at 0, is not monotone or ends beyond the arrays made the fill loop read and write past the vectors; the single-device path checks first)
+    if (p->colptr[0] != 0) return fail(GLRM_ERR_INVALID, "colptr[0] must be 0");
+    for (int64_t f = 0; f < p->n; ++f)
+      if (p->colptr[f + 1] < p->colptr[f]) return fail(GLRM_ERR_INVALID, "colptr is not monotone at %lld", (long long)f);
+    const int64_t nz = p->colptr[p->n]; // >= 0 and >= every other entry from here on
     if (nz > 0 && (!p->rowidx || !p->colvals)) return fail(GLRM_ERR_INVALID, "index / value arrays are NULL");
-    std::vector<int64_t> rowptr((size_t)p->m + 1, 0), fill((size_t)p->m);
-    std::vector<int32_t> colidx((size_t)nz);
-    std::vector<double> rowvals((size_t)nz);
+    std::vector<int64_t> rowptr, fill;
+    std::vector<int32_t> colidx;
+    std::vector<double> rowvals;
+    try {
+      rowptr.assign((size_t)p->m + 1, 0); fill.resize((size_t)p->m);
+      colidx.resize((size_t)nz); rowvals.resize((size_t)nz);
+    } catch (const std::exception&) { // nothing may unwind across the extern "C" boundary
+      return fail(GLRM_ERR_OOM, "out of host memory for the row view of %lld observations", (long long)nz);
+    }
     for (int64_t t = 0; t < nz; ++t) {
       if (p->rowidx[t] < 0 || p->rowidx[t] >= p->m) return fail(GLRM_ERR_INVALID, "rowidx holds an index outside [0, m)");
       rowptr[(size_t)p->rowidx[t] + 1] += 1;
@@ -648,7 +659,8 @@ extern "C" int glrm_hip_multi_create(glrm_multi** out, const glrm_problem* p, co
     for (int64_t i = 0; i < p->m; ++i) { rowptr[i + 1] += rowptr[i]; fill[i] = rowptr[i]; }
     for (int64_t f = 0; f < p->n; ++f)
       for (int64_t t = p->colptr[f]; t < p->colptr[f + 1]; ++t) {
-        const int64_t at = fill[p->rowidx[t]]++;
+        const int64_t r = p->rowidx[t], at = fill[r]++;
+        if (at >= rowptr[r + 1]) return fail(GLRM_ERR_INVALID, "the column view changed while it was read"); // (cannot happen on a checked, unchanged view)
         colidx[at] = (int32_t)f;
         rowvals[at] = p->colvals[t];
       }

@@ -24,6 +24,9 @@
 // evaluation passes only (scalar losses, list problems, k <= 64); the sparse solver's fixed-step sweeps are not restated here.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <vector>
+
 #include "glrm_device.hpp"
 #include "glrm_engine.hpp"
 
@@ -357,6 +360,37 @@ __global__ void __launch_bounds__(64) ref_col_kernel(const RefArgs a) {
   if (a.trials) { a.trials[fl] += ntr; a.accepts[fl] += nacc; }
 }
 
+// objective() of the reference adds EVERY observation's loss into one accumulator, columns outer, list order inner
+// (src/evaluate_fit.jl:12-17).  That sum is serial by definition; the terms are not: entry t of the column view gets its loss at the
+// current factors (the same dot chain and loss formula as the passes above), the host adds them in order (glrm_reforder_objective).
+template <int KP, bool TRIG>
+__global__ void __launch_bounds__(256) ref_terms_kernel(const RefArgs a, int64_t t0, int64_t t1, double* __restrict__ out) {
+  const int64_t t = t0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= t1) return;
+  int64_t lo_ = 0, hi_ = a.nseg; // the column of entry t: last fl with ptr[fl] <= t
+  while (hi_ - lo_ > 1) {
+    const int64_t mid = lo_ + ((hi_ - lo_) >> 1);
+    if (a.ptr[mid] <= t) lo_ = mid; else hi_ = mid;
+  }
+  const int64_t fg = a.own_offset + lo_;
+  double y[KP];
+  load_vec<KP>(y, a.own + fg * KP);
+  const LossDesc lo = load_loss(a.losses, a.n_losses == 1 ? 0 : fg);
+  const double u = ref_dot<KP>(y, a.other + (int64_t)a.idx[t] * KP, a.k);
+  double L, dL;
+  loss_both<false, TRIG>(lo, u, a.vals[t], L, dL);
+  out[t - t0] = L;
+}
+
+template <int KP>
+int launch_ref_terms(bool trig, const RefArgs& a, int64_t t0, int64_t t1, double* out, hipStream_t st) {
+  const unsigned grid = (unsigned)((t1 - t0 + 255) / 256);
+  if (trig) hipLaunchKernelGGL((ref_terms_kernel<KP, true>), dim3(grid), dim3(256), 0, st, a, t0, t1, out);
+  else hipLaunchKernelGGL((ref_terms_kernel<KP, false>), dim3(grid), dim3(256), 0, st, a, t0, t1, out);
+  HIPCK(hipGetLastError());
+  return GLRM_OK;
+}
+
 template <int KP>
 int launch_ref(bool rows, bool trig, const RefArgs& a, hipStream_t st) {
   const unsigned grid = (unsigned)((a.nseg + 63) / 64);
@@ -435,6 +469,61 @@ static double julia_pairwise_host(const double* v, int64_t first, int64_t last) 
   const double v1 = julia_pairwise_host(v, first, mid);
   const double v2 = julia_pairwise_host(v, mid + 1, last);
   return v1 + v2;
+}
+
+// objective(glrm, X, Y; include_regularization) as the reference adds it (src/evaluate_fit.jl:4-23, calc_penalty :91-104): ONE accumulator
+// over all observations -- columns outer, list order inner -- then `err += penalty`, the penalty being ONE accumulator over rx(x_1) ..
+// rx(x_m), ry(y_1) .. ry(y_n) (the oracle's full_objective).  Whole problems only (glrm_hip_fit's prologue, glrm_hip_objective): with it
+// the recorded objective[0] of the reference-order mode equals the reference-order oracle's to the last bit.
+int glrm_reforder_objective(glrm_handle* h, int include_reg, double* out) {
+  double err = 0.0;
+  if (h->nl > 0 && h->nnz_c > 0) {
+    RefArgs a{};
+    a.nseg = h->nl; a.ptr = h->colptr; a.idx = h->rowidx; a.vals = h->colvals;
+    a.own = h->Y; a.own_offset = h->cb; a.other = h->X;
+    a.losses = h->losses; a.n_losses = h->n_losses; a.k = h->k;
+    const int64_t chunk = std::min<int64_t>(h->nnz_c, (int64_t)1 << 25); // 256 MB of terms at a time
+    double* dterms = nullptr;
+    HIPCK(hipMalloc((void**)&dterms, (size_t)chunk * 8));
+    std::vector<double> host;
+    try { host.resize((size_t)chunk); } catch (const std::exception&) { (void)hipFree(dterms); return fail(GLRM_ERR_OOM, "out of host memory"); }
+    for (int64_t t0 = 0; t0 < h->nnz_c; t0 += chunk) {
+      const int64_t t1 = std::min(h->nnz_c, t0 + chunk);
+      int rc;
+      switch (h->kp) {
+        case 8: rc = launch_ref_terms<8>(h->has_trig, a, t0, t1, dterms, h->stream); break;
+        case 16: rc = launch_ref_terms<16>(h->has_trig, a, t0, t1, dterms, h->stream); break;
+        case 32: rc = launch_ref_terms<32>(h->has_trig, a, t0, t1, dterms, h->stream); break;
+        case 64: rc = launch_ref_terms<64>(h->has_trig, a, t0, t1, dterms, h->stream); break;
+        default: rc = fail(GLRM_ERR_UNSUPPORTED, "no reference-order kernel for a padded rank of %d", h->kp);
+      }
+      hipError_t e = rc ? hipSuccess : hipMemcpyAsync(host.data(), dterms, (size_t)(t1 - t0) * 8, hipMemcpyDeviceToHost, h->stream);
+      if (!rc && e == hipSuccess) e = hipStreamSynchronize(h->stream);
+      if (rc || e != hipSuccess) {
+        (void)hipFree(dterms);
+        return rc ? rc : fail(GLRM_ERR_HIP, "reference-order objective: %s", hipGetErrorString(e));
+      }
+      const double* v = host.data();
+      for (int64_t i = 0, ne = t1 - t0; i < ne; ++i) err += v[i]; // err += evaluate(...), one accumulator (src/evaluate_fit.jl:15)
+    }
+    (void)hipFree(dterms);
+  }
+  if (include_reg) {
+    double penalty = 0.0; // calc_penalty: rows then columns into one accumulator (src/evaluate_fit.jl:96-102)
+    int rc;
+    std::vector<double> host((size_t)std::max<int64_t>(h->m, h->n));
+    if ((rc = glrm_hip_row_penalties(h))) return rc;
+    HIPCK(hipMemcpyAsync(host.data(), h->objrow, (size_t)h->m * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < h->m; ++i) penalty += host[(size_t)i];
+    if ((rc = glrm_hip_col_penalties(h))) return rc;
+    HIPCK(hipMemcpyAsync(host.data(), h->objcol, (size_t)h->n * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(hipStreamSynchronize(h->stream));
+    for (int64_t f = 0; f < h->n; ++f) penalty += host[(size_t)f];
+    err += penalty;
+  }
+  *out = err;
+  return GLRM_OK;
 }
 
 int glrm_reforder_sum(glrm_handle* h, const void* dvec, int64_t n, double* out) {

@@ -316,6 +316,8 @@ typedef struct glrm_cpu_handle {
   int64_t* ystart;    /* n+1: column f owns Y[:, ystart[f] .. ystart[f+1]) (get_yidxs, src/losses.jl:76-93) */
   int dense_faithful; /* 1 = reproduce the reference's Theta(mnk) cost model */
   double* XY;         /* m x n, only in dense_faithful mode */
+  int32_t* colidx_g;  /* engine order with private_order = 2: the row view grouped by loss kind inside every window (glrm_cpu_set_sum_order) */
+  double* rowvals_g;
   glrm_sum_order order_r, order_c; /* summation order of the row / column half-step: GLRM_ORDER_REFERENCE unless glrm_cpu_set_sum_order adopted an engine order */
   double accept_bias;              /* test knob, 0 = the reference's strict `<` (glrm_cpu_set_accept_bias) */
   glrm_kernel_stats st;
@@ -353,6 +355,7 @@ void glrm_cpu_destroy(glrm_cpu_handle* h) {
   free(h->rowvals); free(h->colvals); free(h->losses); free(h->rx); free(h->ry);
   free(h->ownX); free(h->ownY); free(h->ownobjcol); free(h->ownobjrow);
   free(h->alpharow); free(h->alphacol); free(h->XY); free(h->ystart);
+  free(h->colidx_g); free(h->rowvals_g);
   free(h);
 }
 
@@ -822,8 +825,9 @@ static int eng_step(glrm_cpu_handle* h, int rows, int64_t s0, int64_t s1, double
       double* x = (rows ? h->X : h->Y) + gseg * k;
       const double* fac = rows ? h->Y : h->X;
       const int64_t b = rows ? h->rowptr[sl] : h->colptr[sl], e = rows ? h->rowptr[sl + 1] : h->colptr[sl + 1];
-      const int32_t* idx = (rows ? h->colidx : h->rowidx) + b;
-      const double* vals = (rows ? h->rowvals : h->colvals) + b;
+      const int grouped = rows && o->private_order == 2 && h->colidx_g;
+      const int32_t* idx = (rows ? (grouped ? h->colidx_g : h->colidx) : h->rowidx) + b;
+      const double* vals = (rows ? (grouped ? h->rowvals_g : h->rowvals) : h->colvals) + b;
       const glrm_loss* segloss = rows ? (h->n_losses == 1 ? &h->losses[0] : NULL) : loss_of(h, gseg);
       const glrm_reg* r = rows ? rx_of(h, sl) : ry_of(h, sl);
       double Jold, Jn;
@@ -871,7 +875,8 @@ int glrm_cpu_set_sum_order(glrm_cpu_handle* h, int32_t which, const glrm_sum_ord
   if (h->multi || h->dense_faithful) return fail(GLRM_ERR_UNSUPPORTED, "engine summation orders cover the scalar-loss sparse path only");
   if (order->family != GLRM_ORDER_STRIDED && order->family != GLRM_ORDER_WINDOWED)
     return fail(GLRM_ERR_UNSUPPORTED, "summation order family %d is not restated by the oracle", order->family);
-  if (order->private_order) return fail(GLRM_ERR_UNSUPPORTED, "the engine walks a private re-ordered copy of the lists: not reproducible from the caller's");
+  if (order->private_order && !(order->private_order == 2 && which == 0 && order->family == GLRM_ORDER_WINDOWED))
+    return fail(GLRM_ERR_UNSUPPORTED, "the engine walks a private re-ordered copy of the lists: not reproducible from the caller's");
   const int G = order->lanes, R = order->comps;
   if (!(G == 1 || G == 2 || G == 4 || G == 8 || G == 16) || R < 2 || (R & 1) || G * R < h->k || G * R > 128)
     return fail(GLRM_ERR_INVALID, "sum order: bad lane layout %d x %d for rank %d", G, R, h->k);
@@ -898,6 +903,35 @@ int glrm_cpu_set_sum_order(glrm_cpu_handle* h, int32_t which, const glrm_sum_ord
     if ((64 / G) * (wmax > wc ? wmax : wc) > 128)
       return fail(GLRM_ERR_INVALID, "sum order: strided layout of %d lanes on %d waves is %d lane groups per segment (limit 128)", G, wmax > wc ? wmax : wc,
                   (64 / G) * (wmax > wc ? wmax : wc));
+  }
+  if (which == 0) { free(h->colidx_g); free(h->rowvals_g); h->colidx_g = NULL; h->rowvals_g = NULL; }
+  if (order->private_order == 2 && h->n_losses > 1) {
+    /* csrc/glrm_tiled.hpp: group_rows_by_kind_kernel -- inside every window of a row the entries are grouped by the loss kind of
+     * their column, ascending, list order inside a kind (a stable counting placement; windows hold a few dozen entries) */
+    const int64_t ns = h->row_end - h->row_begin, nnz = h->rowptr[ns];
+    h->colidx_g = (int32_t*)malloc((size_t)(nnz ? nnz : 1) * 4);
+    h->rowvals_g = (double*)malloc((size_t)(nnz ? nnz : 1) * 8);
+    if (!h->colidx_g || !h->rowvals_g) return fail(GLRM_ERR_OOM, "out of memory");
+    for (int64_t s = 0; s < ns; ++s) {
+      int64_t wb = h->rowptr[s];
+      const int64_t e = h->rowptr[s + 1];
+      while (wb < e) {
+        int64_t we = wb + 1;
+        const int64_t w = h->colidx[wb] / order->window;
+        while (we < e && h->colidx[we] / order->window == w) ++we;
+        int64_t at = wb;
+        for (int kind = 0; at < we; ++kind) { /* kinds ascending; every entry is placed once */
+          int left = 0;
+          for (int64_t t = wb; t < we; ++t) {
+            const int kt = loss_of(h, h->colidx[t])->kind;
+            if (kt == kind) { h->colidx_g[at] = h->colidx[t]; h->rowvals_g[at] = h->rowvals[t]; ++at; }
+            else if (kt > kind) left = 1;
+          }
+          if (!left) break;
+        }
+        wb = we;
+      }
+    }
   }
   *dst = *order;
   return GLRM_OK;

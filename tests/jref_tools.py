@@ -82,6 +82,7 @@ def jref_parity(fixture, api, h, X0, Y0):
     out["gpu_iterations_to_own_stop"] = len(obj) - 1
     out["gpu_seconds_to_own_stop"] = float(sec[-1])
     st = api.kernel_stats(h)
+    out["line_search_totals"] = {k_: int(st[k_]) for k_ in ("trials_x", "trials_y", "accepts_x", "accepts_y")}
 
     def samples(tag, X, Y):
         r = {}
@@ -135,7 +136,9 @@ def jref_reference_mode(fixture, api, h_ref, X0, Y0):
          "gpu_iterations_to_own_stop": len(obj) - 1, "cpu_iterations_to_own_stop": int(fixture["iterations_to_own_stop"]),
          "gpu_seconds_to_own_stop": float(sec[-1]),
          "trajectory": trajectory_deviation(obj, fixture["objective"]),
-         "trajectory_after_the_initial_objective": trajectory_deviation(obj[1:], fixture["objective"][1:])}
+         "trajectory_after_the_initial_objective": trajectory_deviation(obj[1:], fixture["objective"][1:]),
+         # the whole recorded vector, objective[0] included (one accumulator over all observations, src/evaluate_fit.jl:12-21)
+         "objective_vector_bit_identical": bool(np.array_equal(np.asarray(obj, dtype=np.float64), np.asarray(fixture["objective"], dtype=np.float64)))}
     if sm is not None and len(obj) == len(fixture["objective"]):
         for nm, F, ix in (("X", Xg, sm["rows"]), ("Y", Yg, sm["cols"])):
             ref = sm[f"{nm}_ref"]

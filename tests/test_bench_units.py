@@ -18,7 +18,7 @@ def test_algorithmic_bytes_match_the_survey():
 
 @pytest.mark.parametrize("family,kw,bound", [
     # measured half-step times of round 2 (profiles/r02_*_bench_final.json)
-    ("blocked", dict(nnz=10**9, nseg=100_000, nopp=10_000_000, k=64, ld=64, ms=143.0), "hbm"),   # C4 Y half-step: X = 5 GB
+    ("blocked", dict(nnz=10**9, nseg=100_000, nopp=10_000_000, k=64, ld=64, ms=143.0), "infinity_cache"),   # C4 Y half-step: X = 5 GB, gathers out of the window kept on chip
     ("gather", dict(nnz=10**9, nseg=10_000_000, nopp=100_000, k=64, ld=64, ms=128.8), "l2"),     # C4 X half-step: Y = 51 MB, cache resident
     ("tiled", dict(nnz=5 * 10**8, nseg=10_000, nopp=1_000_000, k=32, ld=32, ms=9.7), "lds"),     # C2 Y half-step
     ("dense", dict(nnz=10**10, nseg=1_000_000, nopp=10_000, k=32, ld=32, ms=42.3, m=1_000_000, n=10_000), "mfma"),
@@ -41,22 +41,69 @@ def test_c4_gather_column_sweep_is_priced_at_the_survey_bytes():
     assert r["best"]["frac"] == pytest.approx(0.812, abs=2e-3)  # profiles/r02_c4_bench.json
 
 
-def test_the_roofline_headline_is_one_kind_of_number_on_both_sides_of_one():
-    """the C4 Y half-step at 130.8 ms printed frac 0.876 (PMC) and at 131.7 ms frac 0.9946 (algorithmic).  Now `frac` is the
-    SURVEY 8(d) algorithmic fraction in both, `cache_served` flags it, `traffic_frac` stands beside it."""
+def test_the_roofline_headline_is_one_convention_and_a_fraction():
+    """VERDICT r4 weak 7 / r5 item 4.  The C4 Y half-step (phase-aligned passes) at 130.8 and 131.7 ms printed frac 0.876 (PMC) and 0.9946
+    (algorithmic) in round 4, 1.012 "of HBM" in round 5 -- bytes that demonstrably did not all come from HBM priced at the HBM spec, while the
+    cached row sweep of the same line was priced at the measured Infinity-Cache gather ceiling.  Now one convention: every limiter where its
+    bytes come from -- the gathers of the phase-aligned passes at the measured 8.2 TB/s like the cached row sweep's -- so `frac` = floor time /
+    measured time <= 1; SURVEY 8(d)'s algorithmic fraction and the PMC traffic fraction stand beside it."""
     fr = {}
-    for ms in (130.8, 131.7):
+    for ms in (129.4, 130.8, 131.7):
         rl = bench.kernel_roofline("blocked", nnz=10**9, nseg=100_000, nopp=10_000_000, k=64, ld=64, ms=ms)
         r = bench.roofline_block(rl, "col passes", ms, 10**9, 9.17e11, "pmc", {"hit_rate": 0.189})
-        assert r["bound"] == "hbm" and r["per_launch"] == 1048 * 10**9
-        assert r["frac"] == pytest.approx(1.048e12 / (ms * 1e-3) / 8e12) == r["algorithmic_frac"]
-        assert r["cache_served"] is True
+        assert r["bound"] == "infinity_cache" and r["per_launch"] == 2 * 512 * 10**9 and r["peak"] == 8200.0
+        assert r["frac"] == pytest.approx(1.024e12 / (ms * 1e-3) / 8.2e12) and 0.9 < r["frac"] <= 1.0
+        assert r["algorithmic_frac"] == pytest.approx(1.048e12 / (ms * 1e-3) / 8e12)
+        assert r["cache_served"] is False  # (the flag is about HBM-priced fractions)
         assert r["traffic_frac"] == pytest.approx(9.17e11 / (ms * 1e-3) / 8e12) and r["traffic_frac"] < r["frac"]
+        hbm = [c for c in r["candidates"] if c["bound"] == "hbm"][0]
+        assert hbm["frac"] < r["frac"] and hbm["frac"] == pytest.approx((2 * 12e9 + 2 * 100_000 * 512 + 2 * 5.12e9) / (ms * 1e-3) / 8e12)
         fr[ms] = r["frac"]
-    assert fr[130.8] > 1.0 > fr[131.7] and abs(fr[130.8] - fr[131.7]) < 0.01   # 1 % apart in time, 1 % apart in the headline
+    assert fr[129.4] > fr[130.8] > fr[131.7] and abs(fr[130.8] - fr[131.7]) < 0.01   # 1 % apart in time, 1 % apart in the headline
     slow = bench.roofline_block(bench.kernel_roofline("gather", nnz=10**9, nseg=100_000, nopp=10_000_000, k=64, ld=64, ms=161.3), "k", 161.3, 10**9, None, "off", None)
-    assert slow["cache_served"] is False and slow["traffic_frac"] is None and slow["frac"] == pytest.approx(0.812, abs=2e-3)
-    assert bench.side_summary(bench.kernel_roofline("blocked", nnz=10**9, nseg=100_000, nopp=10_000_000, k=64, ld=64, ms=120.0))["frac"] > 1.0
+    assert slow["cache_served"] is False and slow["traffic_frac"] is None and slow["frac"] == pytest.approx(0.812, abs=2e-3)  # random gathers from HBM: HBM-priced
+
+
+def test_every_family_of_the_committed_profile_lines_prints_a_fraction():
+    """frac <= 1 for every half-step of every config the driver and the builder recorded (profiles/, BENCH_r05.json), recomputed from the
+    recorded times under the one convention: the kernel did the work in that time, so no limiter's floor can exceed it."""
+    import glob
+    import json
+    lines = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[56]_c*_bench*.json"))) + [os.path.join(ROOT, "BENCH_r05.json")]:
+        try:
+            txt = open(path).read()
+        except OSError:
+            continue
+        cands = txt.splitlines()
+        try:
+            whole = json.loads(txt)
+            cands = [txt] if "kernels" in whole else str(whole.get("tail", "")).splitlines()  # (a driver record keeps the line in its `tail`)
+        except ValueError:
+            pass
+        for ln in cands:
+            ln = ln.strip()
+            if ln.startswith("{") and '"kernels"' in ln:
+                try:
+                    r = json.loads(ln)
+                except ValueError:
+                    continue
+                if "config" in r and "kernels" in r:
+                    lines.append((os.path.basename(path), r))
+    assert len(lines) >= 3, [p for p, _ in lines]
+    seen = set()
+    for name, r in lines:
+        c, kn = r["config"], r["kernels"]
+        if c.get("degree") == "zipf":
+            continue  # (the uniform-recipe byte model)
+        m, n, k = c["m"], c["n"], c["k"]
+        ld = 8 if k <= 8 else 16 if k <= 16 else 32 if k <= 32 else 64 if k <= 64 else 128
+        qg = "quad_gram" in c["workload"]
+        for side, fam, ms, nseg, nopp in (("row", c["row_sweep"], kn["row_sweep_ms"], m, n), ("col", c["col_sweep"], kn["col_sweep_ms"], n, m)):
+            rl = bench.kernel_roofline(fam, nnz=c["observed"], nseg=nseg, nopp=nopp, k=k, ld=ld, ms=ms, m=m, n=n, quad_gram=qg)
+            assert 0 < rl["best"]["frac"] <= 1.0, (name, side, fam, ms, rl["best"])
+            seen.add(fam)
+    assert {"cached", "blocked"} <= seen, seen
 
 
 def test_config_table():

@@ -33,7 +33,7 @@ pytestmark = pytest.mark.gpu
 SEED = 20260926
 
 
-@pytest.mark.parametrize("config", ["C4", "C2"])
+@pytest.mark.parametrize("config", ["C4", "C2", "C5"])
 def test_jref_trajectory_and_factor_samples(config, capsys):
     import torch
     fx = J.load_jref_fixture(config, SEED, bench.CONFIGS[config])
@@ -54,9 +54,19 @@ def test_jref_trajectory_and_factor_samples(config, capsys):
     assert eng["engine_reports_the_fixtures_order"], par["engine_sum_order"]
     # 2. nothing but the order: bit-identical factors, same stop, same line searches
     assert par["gpu_iterations_to_own_stop"] == eng["cpu_iterations_to_own_stop"]
-    assert eng["X_sample_bit_identical"] and eng["Y_sample_bit_identical"], eng
-    assert eng["line_search_totals_equal"] is True
-    assert eng["trajectory"]["max_rel"] < 1e-12, eng["trajectory"]
+    if cfg["loss_mix"]:
+        # C5 (Quad / Logistic / OrdinalHinge columns, src/losses.jl:247-311): the Logistic columns go through the in-kernel exp / log, the
+        # oracle through libm -- last-bit differences that every row and, one half-step later, every column inherits: 1e-9 on the whole
+        # trajectory and on the factor samples instead of bit equality, line-search totals within one in 10 000
+        assert eng["X_sample_rel_fro"] < 1e-9 and eng["Y_sample_rel_fro"] < 1e-9, eng
+        assert eng["trajectory"]["max_rel"] < 1e-9, eng["trajectory"]
+        for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
+            g_, c_ = par["line_search_totals"][key], fx["engine_order"]["line_search"][key]
+            assert abs(g_ - c_) <= 1e-4 * c_ + 2, (key, g_, c_)
+    else:
+        assert eng["X_sample_bit_identical"] and eng["Y_sample_bit_identical"], eng
+        assert eng["line_search_totals_equal"] is True
+        assert eng["trajectory"]["max_rel"] < 1e-12, eng["trajectory"]
     # 3. the reference's order: 1e-5 where summation order leaves it room, never beyond what order alone does
     lim = 1.5 * own["max_rel_over_trajectory"] + 1e-6
     assert ref["trajectory"]["max_rel"] < max(1e-5 if own["max_rel_over_trajectory"] < 1e-6 else 0.0, lim), (ref["trajectory"], own)
@@ -71,7 +81,7 @@ def test_jref_trajectory_and_factor_samples(config, capsys):
         assert abs(v["gpu"] - v["cpu"]) <= 0.01 * v["cpu"] + 5, (key, v)
 
 
-@pytest.mark.parametrize("config", ["C4", "C2"])
+@pytest.mark.parametrize("config", ["C4", "C2", "C5"])
 def test_jref_in_the_reference_order_mode(config, capsys):
     """glrm_options.sum_order = 1 (SURVEY.md section 8(b) `line_search_sum_order`; csrc/glrm_reforder.hip): the engine adding every sum as
     the reference adds it, held against the REFERENCE-ORDER fixture -- the north star's "1e-5 on trajectory and factor values" met
@@ -93,7 +103,10 @@ def test_jref_in_the_reference_order_mode(config, capsys):
         print(f"\n[jref {config} reference-order mode] " + json.dumps(r))
     assert r["engine_reports"] == ["reference", "reference"] and r["kernel_flags"] & 128
     assert r["gpu_iterations_to_own_stop"] == r["cpu_iterations_to_own_stop"]
-    assert r["trajectory_after_the_initial_objective"]["max_rel"] < 1e-9, r     # (objective[0] is summed per column first: rounding only)
+    assert r["trajectory_after_the_initial_objective"]["max_rel"] < 1e-9, r
     assert r["trajectory"]["max_rel"] < 1e-9, r
+    if not cfg["loss_mix"]:  # QuadLoss recipes: the same instructions on both sides -- the WHOLE recorded vector, objective[0] included (one
+        assert r["objective_vector_bit_identical"], r  # accumulator over all observations, src/evaluate_fit.jl:12-21), to the last bit
     assert r["X_sample_rel_fro"] < 1e-9 and r["Y_sample_rel_fro"] < 1e-9, r
-    assert r["line_search_totals_equal"] is True
+    if not cfg["loss_mix"]:  # (C5: in-kernel exp / log against libm may move a knife-edge decision)
+        assert r["line_search_totals_equal"] is True

@@ -102,3 +102,46 @@ def test_phase_aligned_passes_two_ranks_equal_one_rank():
     for r in (one, two):
         assert r["config"]["row_sweep"] == r["config"]["col_sweep"] == "blocked"
     assert two["objective"] == one["objective"]
+
+
+def test_plain_command_without_a_launcher_starts_its_own_ranks():
+    """`python bench.py --gpus N` -- the driver's plain command, no torch.distributed.run around it -- spawns its own N
+    ranks (here gloo: both ranks share the box's one GPU), prints ONE line with exit code 0, and the line says what the process group saw:
+    `ranks_seen` (world size, backend, a device per rank) and `launch` (the command it re-ran itself under).  Same objective bits as one rank;
+    the one-rank command is unchanged apart from carrying `ranks_seen` too."""
+    common = ["--config", "C4", "--rows", "48000", "--cols", "4000", "--obs-per-row", "100", "--steps", "3", "--warmup", "2", "--no-inlib-leg"] + QUIET
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + common, env=dict(env, GLRM_BENCH_BACKEND="gloo", GLRM_GATHER="allgather"),
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    two = json.loads(lines[0])
+    one = run([sys.executable, "bench.py"] + common, env)
+    assert two["n_gpus"] == 2 and two["objective"] == one["objective"] and two["value"] > 0
+    rs = two["ranks_seen"]
+    assert rs["world_size"] == 2 and rs["backend"] == "gloo" and [d["rank"] for d in rs["devices"]] == [0, 1]
+    assert rs["distinct_devices"] == 1  # one GPU on this box: the plumbing, not the speed -- a real run shows N distinct PCI addresses
+    assert "torch.distributed.run" in two["launch"]["command"] and two["launch"]["visible_devices"] >= 1
+    assert one["ranks_seen"]["world_size"] == 1 and one["ranks_seen"]["backend"] is None and "launch" not in one
+
+
+def test_plain_command_falls_back_and_says_so():
+    """The RCCL backend needs a device per rank: on a one-GPU box `bench.py --gpus 2` cannot run its ranks and says so in ONE line (value null,
+    `error`, exit code 1) instead of a traceback; with shared devices allowed (gloo) and the N-rank job failing to start -- an unusable
+    rendezvous address -- the in-library host (one process, N devices) runs the same problem and its line is printed with `fell_back_from`."""
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("written for the one-GPU box")
+    common = ["--config", "C4", "--rows", "48000", "--cols", "4000", "--obs-per-row", "100", "--steps", "2", "--warmup", "1"] + QUIET
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GLRM_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + common, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert r.returncode == 1 and line["value"] is None and "device" in line["error"]["error"] and line["n_gpus"] == 2
+    # the N-rank job dies at once (the backend name is not one torch.distributed knows): the in-library host takes over
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + common, env=dict(env, GLRM_BENCH_BACKEND="no-such-backend"), capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["host"] == "inlib" and line["n_gpus"] == 2 and line["value"] > 0 and "fell_back_from" in line
+    assert line["ranks_seen"]["world_size"] == 2 and line["host"]["shared_device"]

@@ -126,20 +126,18 @@ def test_heterogeneous_columns_on_the_gather_sweeps():
     assert o[0].batch == 4 and o[0].batch_one_wave_only == 0 and o[1].batch == 4 and o[1].batch_one_wave_only == 1
 
 
-def test_regrouped_private_copies_are_flagged():
-    """With the default kind grouping the row view of a heterogeneous model is walked in a private order: the engine says so and the
-    oracle refuses to claim it can follow."""
+def test_rows_regrouped_by_loss_kind_are_followed_by_the_oracle():
+    """With the default kind grouping the row view of a heterogeneous model is walked in a private order -- inside every tile window the
+    entries grouped by ascending loss kind, stably (glrm_tiled.hpp: group_rows_by_kind_kernel).  That is a function of the caller's list
+    alone: the engine reports private_order = 2 and the oracle restates the grouping (glrm_cpu_set_sum_order) -- bit-identical factors.
+    A TILE-SORTED private copy (private_order = 1) stays out of the oracle's reach."""
     pa, X0, Y0 = problem(5000, 1500, 32, 300, (1, 0, 1.0), mixed=True)
-    api = _capi.hip_api()
-    h = api.create(pa, tiled=2)
-    try:
-        o = api.sum_order(h, 0)
-        assert o.private_order == 1 and api.sum_order(h, 1).private_order == 0
-    finally:
-        api.destroy(h)
+    o = engine_and_oracle_in_its_order(pa, X0, Y0, 6, TILED_R | TILED_C, ("windowed", "windowed"), tiled=2)
+    assert o[0].private_order == 2 and o[1].private_order == 0 and o[0].batch == 4
     ho = O.oracle_api().create(pa)
     try:
+        o[0].private_order = 1
         with pytest.raises(_capi.GLRMError):
-            O.set_sum_order(ho, 0, o)
+            O.set_sum_order(ho, 0, o[0])
     finally:
         O.oracle_api().destroy(ho)

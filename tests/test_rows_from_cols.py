@@ -151,3 +151,29 @@ def test_device_arrays_multi_create_and_refusals():
     with pytest.raises(_capi.GLRMError):
         api.create(_capi.ProblemArrays(1500, 200, 8, None, None, None, cols_only.colptr, badidx, cols_only.colvals, both.losses, both.rx, both.ry,
                                        flags=_capi.PROBLEM_ROWS_FROM_COLS))
+
+
+def test_multi_create_checks_the_column_view_before_it_transposes():
+    """the host counting transpose of glrm_hip_multi_create ran BEFORE any structural check of colptr -- a colptr that does
+    not start at 0, is not monotone, or ends beyond the arrays read and wrote past the vectors; a negative colptr[n] threw across the extern "C"
+    boundary.  Every such view is now refused with GLRM_ERR_INVALID before anything is counted (no device is touched: this runs without a GPU,
+    through the product library's own entry point)."""
+    rng = np.random.default_rng(12)
+    both, cols_only, X0, Y0 = pattern(rng, 200, 40, 4, 0.2)
+    api = _capi.hip_api()
+
+    def refused(colptr, rowidx=None):
+        bad = _capi.ProblemArrays(200, 40, 4, None, None, None, np.ascontiguousarray(colptr, dtype=np.int64), cols_only.rowidx if rowidx is None else rowidx,
+                                  cols_only.colvals, both.losses, both.rx, both.ry, flags=_capi.PROBLEM_ROWS_FROM_COLS)
+        with pytest.raises(_capi.GLRMError) as e:
+            api.multi_create(bad, 2, device_ids=[0, 0])
+        assert e.value.code == _capi.ERR_INVALID, e.value
+
+    cp = cols_only.colptr
+    refused(cp + 1)                                                # does not start at 0 (and ends one past the arrays)
+    swapped = cp.copy(); swapped[10], swapped[11] = cp[11] + 5, cp[10]
+    refused(swapped)                                               # not monotone
+    neg = cp.copy(); neg[-1] = -1
+    refused(neg)                                                   # negative total: used to throw std::length_error through the C ABI
+    badidx = cols_only.rowidx.copy(); badidx[3] = 200
+    refused(cp, badidx)                                            # row index outside [0, m)

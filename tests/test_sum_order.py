@@ -230,3 +230,38 @@ def test_sum_order_is_refused_where_the_oracle_cannot_follow():
         assert api.sum_order(h, 0).asdict()["family_name"] == "reference"
     finally:
         api.destroy(h)
+
+
+def test_kind_grouped_rows_equal_a_host_regrouped_row_view():
+    """glrm_sum_order.private_order = 2 (rows of a model with several loss kinds on the LDS tiles): inside every window the entries are
+    grouped by ascending loss kind, stably (csrc/glrm_tiled.hpp: group_rows_by_kind_kernel).  The oracle's restatement of that grouping
+    must give the bits of the plain windowed order on a row view regrouped HERE, with numpy, before the hand-over."""
+    pa, X0, Y0 = small_problem(40, 96, 8, [30, 17, 44, 9], seed=11, reg=(1, 0, 0.5))
+    n, win = pa.n, 16
+    kinds = np.array([0, 7, 6, 1])                                    # Quad, Logistic, OrdinalHinge, L1 by column (f mod 4)
+    lt = np.zeros(n, dtype=_capi.LOSS_DTYPE)
+    for f in range(n):
+        lt[f] = (kinds[f % 4], 0, 1.0 + 0.25 * (f % 3), 1.0, 5.0)
+    vals = pa.rowvals.copy()
+    cls = lt["kind"][pa.colidx]
+    vals[cls == 7] = (vals[cls == 7] > 0).astype(np.float64)         # Logistic labels
+    vals[cls == 6] = np.clip(np.round(3 + vals[cls == 6]), 1, 5)      # OrdinalHinge levels
+    order = np.lexsort((np.repeat(np.arange(pa.m), np.diff(pa.rowptr)), pa.colidx))
+    mixed = _capi.ProblemArrays(pa.m, n, pa.k, pa.rowptr, pa.colidx, vals, pa.colptr, pa.rowidx, vals[order], lt, pa.rx, pa.ry)
+    # the same grouping on the host: stable sort of every row by (window, kind)
+    gi, gv = pa.colidx.copy(), vals.copy()
+    for e in range(pa.m):
+        b, en = int(pa.rowptr[e]), int(pa.rowptr[e + 1])
+        key = np.lexsort((lt["kind"][pa.colidx[b:en]], pa.colidx[b:en] // win))
+        gi[b:en], gv[b:en] = pa.colidx[b:en][key], vals[b:en][key]
+    assert not np.array_equal(gi, pa.colidx)
+    grouped = _capi.ProblemArrays(pa.m, n, pa.k, pa.rowptr, gi, gv, pa.colptr, pa.rowidx, vals[order], lt, pa.rx, pa.ry)
+    o_plain = O.make_sum_order("windowed", 4, 2, window=win, batch=4)
+    o_priv = O.make_sum_order("windowed", 4, 2, window=win, batch=4)
+    o_priv.private_order = 2
+    oc = O.make_sum_order("windowed", 4, 2, window=win, windows_per_sup=2, batch=4)
+    Xa, Ya, sa = oracle_half_steps(mixed, X0, Y0, o_priv, oc)
+    Xb, Yb, sb = oracle_half_steps(grouped, X0, Y0, o_plain, oc)
+    assert np.array_equal(Xa, Xb) and np.array_equal(Ya, Yb) and sa["trials_x"] == sb["trials_x"]
+    Xc, _, _ = oracle_half_steps(mixed, X0, Y0, o_plain, oc)          # ungrouped walk: same sums up to rounding, not the same bits
+    assert np.abs(Xa - Xc).max() < 1e-9

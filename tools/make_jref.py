@@ -42,7 +42,7 @@ def tile_rows(kp):
     return ((150 * 1024) // (kp * 8 + 16)) // 16 * 16  # csrc/glrm_tiled.hip: tile_rows_c(kp, 1)
 
 
-def expected_orders(m, n, k, q):
+def expected_orders(m, n, k, q, mixed=False):
     """The summation order the engine's auto choice lands on for a bench recipe problem of m x n, rank k, q sorted observations per row
     (csrc/glrm_tiled.hip: glrm_setup_tiled, csrc/glrm_cached.hip: glrm_setup_cached, csrc/glrm_blocked.hip: glrm_setup_blocked,
     csrc/glrm_hip.hip: glrm_hip_sum_order), as dicts in the field names of glrm_sum_order.  A statement of what is expected, checked
@@ -58,8 +58,12 @@ def expected_orders(m, n, k, q):
     tiled_r = q * T / n >= 4.0 and nnz >= 2e7 and m >= 512 * spb
     tiled_c = (nnz / n) * T / m >= 4.0 and nnz >= 2e7 and n >= 256
     rows, cols = dict(base), dict(base)
+    # models with several loss kinds (C5): the whole batch of G observations per step, one loss partial per lane; the column passes walk
+    # their chunks rotated; the row view is grouped by loss kind inside every window (private_order = 2, which the oracle restates)
+    if mixed and not (tiled_r and tiled_c and G in (4, 8) and R == 8):
+        raise SystemExit("a heterogeneous recipe outside the LDS-tiled families: write the gather families' batch rules down here first")
     if tiled_r:
-        rows.update(family=2, window=T, windows_per_sup=0, batch=2)
+        rows.update(family=2, window=T, windows_per_sup=0, batch=G if mixed else 2, private_order=2 if mixed else 0)
     else:
         rows.update(family=1)
         if n * kp * 8 > 32 * 2 ** 20 and nnz >= 1e8 and G in (4, 8) and R == 8:
@@ -68,7 +72,7 @@ def expected_orders(m, n, k, q):
         ntiles = -(-m // T)
         groups = -(-n // spb)
         tps = max(1, min(ntiles // max(1, -(-1024 // groups)), max(1, 32768 // T)))
-        cols.update(family=2, window=T, windows_per_sup=tps, batch=2)
+        cols.update(family=2, window=T, windows_per_sup=tps, batch=G if mixed else 2, rotate=1 if mixed else 0)
     else:
         if m * kp * 8 > 32 * 2 ** 20 and nnz >= 2e8:
             raise SystemExit("this problem would run the phase-aligned column passes: write their geometry down here first")
@@ -117,7 +121,7 @@ def main():
     pa, X0, Y0 = bench._oracle_problem(a.rows, n, k, q, cfg, a.seed)
     t_gen = time.time() - t0
     api = O.oracle_api()
-    orders = expected_orders(a.rows, n, k, q)
+    orders = expected_orders(a.rows, n, k, q, mixed=bool(cfg["loss_mix"]))
     path = os.path.join(ROOT, "tests", "golden", f"jref_{a.config}{a.out_tag}.json")
     old = json.load(open(path)) if os.path.exists(path) else None
 
