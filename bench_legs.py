@@ -630,6 +630,9 @@ def inlib_host(args):
     cfg = dict(CONFIGS[args.config])
     if args.config == "C3":
         raise SystemExit("--host inlib covers the list configs")
+    # the link emulator exists in the TEST BUILD of the engine only (libglrm_hip_testing.so): a line with --emulate-link-gbps is a schedule
+    # experiment and says which library ran it; every other line runs the product library
+    get_api = _capi.hip_testing_api if args.emulate_link_gbps > 0 else _capi.hip_api
     if args.cols or args.obs_per_row or args.k:
         cfg.update(cols=args.cols or cfg["cols"], q=args.obs_per_row or cfg["q"], k=args.k or cfg["k"])
     k, q, n = cfg["k"], cfg["q"], cfg["cols"]
@@ -639,7 +642,7 @@ def inlib_host(args):
         raise SystemExit(f"--host inlib --gpus {N}: {ndev} device(s) visible (use --shared-device to put every shard on device 0)")
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    api = _capi.hip_api()
+    api = get_api()
     t0 = time.time()
     pa, X0, Y0 = host_problem(args, cfg, m, n, k, q, device)
     t_gen = time.time() - t0
@@ -674,6 +677,7 @@ def inlib_host(args):
     base = one_fit(0.0) if args.emulate_link_gbps > 0 else None  # the same fit with free copies: what the link adds is the difference
     obj, info, elapsed = run["obj"], run["info"], run["ms_per_step"] * 1e-3 * args.steps
     host = {"kind": "in-library (glrm_hip_multi_create / glrm_hip_multi_fit): what julia/HipGLRM.jl ccalls for HipProxGradParams(ngpus = N)",
+            "library": "libglrm_hip_testing.so (test build: link emulator)" if args.emulate_link_gbps > 0 else "libglrm_hip.so",
             "exchange_used": {0: "direct peer pushes (hipMemcpyPeerAsync, one copy stream per (source, destination) pair)", 1: "RCCL ncclAllGather / grouped broadcasts"}.get(info["exchange"], info["exchange"]),
             "arrival_order": {0: "on (default)", 1: "on", 2: "off: the Y half-step waits for the whole X exchange"}[args.arrival] + (
                 "" if args.arrival == 2 else ": the Y half-step consumes the peers' row chunks of X as their copy events fire (glrm_hip_step_y_arrival)"),

@@ -321,7 +321,8 @@ int glrm_hip_step_y(glrm_handle* h, double min_stepsize);                   /* o
  * super-tile) that col_reduce adds in super-tile order whatever order the launches ran in: they launch each super-tile behind the events
  * of the blocks it touches, own rows first, so the exchange overlaps the half-step that consumes it.  Every other family waits for all
  * events and then runs glrm_hip_step_y.  Results are those of glrm_hip_step_y bit for bit.  With glrm_options.profile the time the
- * launch stream spent in those waits is accounted in glrm_kernel_stats.ms_wait_y.
+ * launch stream spent in those waits is accounted in glrm_kernel_stats.ms_wait_y (in true arrival order: plus the time the calling
+ * thread polled while no super-tile was ready).
  * TRUE arrival order (default; GLRM_HIP_ARRIVAL_DYNAMIC=0 restores the announced order): a super-tile is enqueued once the events of all
  * its blocks have fired (hipEventQuery), the ready ones in the announced order, and the calling thread polls for the rest -- behind a
  * lagging peer the launch stream no longer stands in front of its block while other super-tiles are ready.  The call therefore returns
@@ -447,7 +448,9 @@ typedef struct glrm_kernel_stats {
                                   bit6: cached gather row sweep (the short rows' opposing vectors fetched once per half-step
                                   and kept in registers / LDS for every pass), bit7: reference-order validation sweeps
                                   (glrm_options.sum_order = 1) */
-  double ms_wait_y;            /* glrm_hip_step_y_arrival with profile=1: time the launch stream waited for blocks of X to arrive */
+  double ms_wait_y;            /* glrm_hip_step_y_arrival with profile=1: time the launch stream waited for blocks of X to arrive; in TRUE
+                                  arrival order also the time the calling thread polled with NO super-tile ready (an upper bound on the
+                                  device's idle time: earlier super-tiles may still have been running) */
 } glrm_kernel_stats;
 
 int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int reset);

@@ -498,6 +498,22 @@ HIP_LIB_PATH = os.environ.get("GLRM_HIP_LIB_PATH") or os.path.join(_PKG_DIR, "li
 _hip_api = None
 
 
+HIP_TESTING_LIB_PATH = os.path.join(_PKG_DIR, "libglrm_hip_testing.so")
+_hip_testing_api = None
+
+
+def hip_testing_api() -> Api:
+    """The TEST BUILD of the engine (libglrm_hip_testing.so: the product objects with csrc/glrm_testhooks.hip and csrc/glrm_multigpu.hip rebuilt
+    under -DGLRM_HIP_TESTING): the only library in which GLRM_HIP_TEST_FAIL_FINALIZE, GLRM_HIP_RCCL_LIB / GLRM_HIP_RCCL_ALLOW_SHARED and the
+    link emulator (GLRM_EXCHANGE_EMULATE_*) exist.  For tests and `bench.py --emulate-link-gbps`; never what `fit_b` runs on."""
+    global _hip_testing_api
+    if _hip_testing_api is None:
+        if not os.path.exists(HIP_TESTING_LIB_PATH):
+            raise RuntimeError(f"{HIP_TESTING_LIB_PATH} is missing: build it with `python __graft_entry__.py`")
+        _hip_testing_api = Api(C.CDLL(HIP_TESTING_LIB_PATH, mode=C.RTLD_LOCAL), "glrm_hip_", "cuda")
+    return _hip_testing_api
+
+
 def hip_api() -> Api:
     """The MI355X engine.  Fails loudly when the HIP library has not been built -- there is no
     CPU fallback in the product path."""

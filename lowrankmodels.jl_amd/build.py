@@ -1,7 +1,10 @@
 """In-tree build of the gfx950 shared libraries (explicit hipcc; hipcc cross-compiles without a GPU).
 
-    libglrm_hip.so    the engine + C ABI (include/glrm_hip.h)
-    libglrm_synth.so  device-side synthetic workload generator (bench / test tooling)
+    libglrm_hip.so          the engine + C ABI (include/glrm_hip.h) -- the PRODUCT library: no test hook, no link emulator in it
+    libglrm_hip_testing.so  the same objects, with csrc/glrm_testhooks.hip and csrc/glrm_multigpu.hip rebuilt under -DGLRM_HIP_TESTING: the
+                            environment-driven test hooks (injected set-up failure, RCCL stand-in, link emulator) live only here; loaded by name
+                            by the tests that need them (_capi.hip_testing_api) and by `bench.py --emulate-link-gbps`
+    libglrm_synth.so        device-side synthetic workload generator (bench / test tooling)
 """
 from __future__ import annotations
 
@@ -16,10 +19,18 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 TARGETS = {
-    "libglrm_hip.so": (["glrm_hip.hip", "glrm_tiled.hip", "glrm_dense.hip", "glrm_multi.hip", "glrm_subset.hip", "glrm_svd.hip", "glrm_impute.hip", "glrm_tilesort.hip", "glrm_multigpu.hip", "glrm_blocked.hip", "glrm_cached.hip", "glrm_reforder.hip", "glrm_transpose.hip"],
+    "libglrm_hip.so": (["glrm_hip.hip", "glrm_tiled.hip", "glrm_dense.hip", "glrm_multi.hip", "glrm_subset.hip", "glrm_svd.hip", "glrm_impute.hip", "glrm_tilesort.hip", "glrm_multigpu.hip", "glrm_blocked.hip", "glrm_cached.hip", "glrm_reforder.hip", "glrm_transpose.hip", "glrm_testhooks.hip"],
                        ["glrm_device.hpp", "glrm_fastmath.hpp", "glrm_tiled.hpp", "glrm_dense.hpp", "glrm_multi.hpp", "glrm_impute.hpp", "glrm_engine.hpp", "../../include/glrm_hip.h"]),
     "libglrm_synth.so": (["glrm_synth.hip"], ["../../include/glrm_synth.h"]),
 }
+
+
+# translation units that differ between the product library and the test build (everything else is shared object for object)
+TESTING_UNITS = ("glrm_testhooks.hip", "glrm_multigpu.hip")
+TESTING_LIB = "libglrm_hip_testing.so"
+# -Bsymbolic: a library's calls to its own extern "C" entry points bind inside the library, so the product library and the test build can
+# live in one process (the suite loads both) without one interposing on the other
+LINK = ["--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-Bsymbolic"]
 
 
 def _stale(out, deps):
@@ -52,12 +63,45 @@ def build_all(force=False, verbose=True):
             for cmd, pr in procs:
                 if pr.wait() != 0:
                     raise subprocess.CalledProcessError(pr.returncode, cmd)
-            link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", out]
+            link = [HIPCC] + LINK + objs + ["-ldl", "-o", out]
             if verbose:
                 print("[build]", " ".join(link), flush=True)
             subprocess.run(link, check=True)
             built.append(name)
+    built += build_testing(force=force, verbose=verbose)
     return built
+
+
+def build_testing(force=False, verbose=True):
+    """libglrm_hip_testing.so: the product library's objects with TESTING_UNITS recompiled under -DGLRM_HIP_TESTING."""
+    srcs, hdrs = TARGETS["libglrm_hip.so"]
+    out = os.path.join(PKG, TESTING_LIB)
+    hdr_paths = [os.path.normpath(os.path.join(CSRC, h)) for h in hdrs]
+    objs, procs = [], []
+    for sname in srcs:
+        sp = os.path.join(CSRC, sname)
+        if sname not in TESTING_UNITS:
+            objs.append(os.path.join(PKG, "build", sname + ".o"))
+            continue
+        obj = os.path.join(PKG, "build", "testing", sname + ".o")
+        os.makedirs(os.path.dirname(obj), exist_ok=True)
+        objs.append(obj)
+        if not force and not _stale(obj, [sp] + hdr_paths):
+            continue
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-DGLRM_HIP_TESTING", "-c", sp, "-o", obj]
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    if not force and not _stale(out, objs):
+        return []
+    link = [HIPCC] + LINK + objs + ["-ldl", "-o", out]
+    if verbose:
+        print("[build]", " ".join(link), flush=True)
+    subprocess.run(link, check=True)
+    return [TESTING_LIB]
 
 
 def build_variant(tag, defines, verbose=True):
@@ -78,7 +122,7 @@ def build_variant(tag, defines, verbose=True):
     for cmd, pr in procs:
         if pr.wait() != 0:
             raise subprocess.CalledProcessError(pr.returncode, cmd)
-    subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", out], check=True)
+    subprocess.run([HIPCC] + LINK + objs + ["-ldl", "-o", out], check=True)
     return out
 
 

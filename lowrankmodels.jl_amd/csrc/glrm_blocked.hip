@@ -218,6 +218,10 @@ static int launch_blocked_inst(glrm_handle* h, TiledArgs a, bool rows) {
       return true;
     };
     auto t_progress = std::chrono::steady_clock::now();
+    // the host polls where the stream used to wait: with glrm_options.profile the time in which NO super-tile was ready is booked as exposed
+    // exchange time (glrm_kernel_stats.ms_wait_y, ADVICE r5: in true arrival order the in-stream waits are ~0 and this time was counted nowhere).
+    // An upper bound on what the device stood idle for: super-tiles enqueued earlier may still be running while the host finds nothing ready.
+    double idle_s = 0.0;
     while (!pend.empty() && !unknown) {
       bool progressed = false;
       for (size_t i = 0; i < pend.size() && !unknown;) {
@@ -230,8 +234,12 @@ static int launch_blocked_inst(glrm_handle* h, TiledArgs a, bool rows) {
       const auto now = std::chrono::steady_clock::now();
       if (progressed) t_progress = now;
       else if (std::chrono::duration<double>(now - t_progress).count() > 5.0) break;
-      else std::this_thread::sleep_for(std::chrono::microseconds(20));
+      else {
+        std::this_thread::sleep_for(std::chrono::microseconds(20));
+        idle_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - now).count();
+      }
     }
+    if (h->profile) h->ms_wait += idle_s * 1e3;
     if (!pend.empty()) h->arrival_static = true; // gave up: this handle keeps to the in-stream waits (no 5 s stall per iteration)
   }
   for (int sup : pend) {

@@ -200,6 +200,8 @@ int glrm_arrival_wait(glrm_handle* h, int64_t lo, int64_t hi);
 int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals, bool free_old);
 
 // reference-order validation sweeps (glrm_reforder.hip; glrm_options.sum_order = 1)
+// test hooks (csrc/glrm_testhooks.hip): constant in the product library, environment-driven in the test build (-DGLRM_HIP_TESTING)
+int glrm_test_fail_finalize();                        // 1 = glrm_hip_finalize fails half way (the set-up-failed latch cannot be reached otherwise)
 int glrm_setup_reforder(glrm_handle* h);               // finalize: refuses what the mode does not cover
 int glrm_run_reforder(glrm_handle* h, bool rows, double min_stepsize, int eval_only);
 int glrm_reforder_sum(glrm_handle* h, const void* dvec, int64_t n, double* out); // Julia's pairwise sum(::Vector{Float64})

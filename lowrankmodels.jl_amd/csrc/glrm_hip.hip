@@ -796,8 +796,8 @@ static int finalize_impl(glrm_handle* h, const glrm_signature* whole) {
   } else if (!h->multi && !h->dense) {
     // a failure from here on leaves re-ordered private views and partial buffers behind: the handle can then only be destroyed
     h->finalize_failed = true;
-    if (env_int("GLRM_HIP_TEST_FAIL_FINALIZE", 0))  // test hook (tests/test_gpu_crossval.py): the latch below cannot be reached on purpose otherwise
-      return fail(GLRM_ERR_OOM, "injected set-up failure (GLRM_HIP_TEST_FAIL_FINALIZE)");
+    if (glrm_test_fail_finalize())  // csrc/glrm_testhooks.hip: always 0 in the product library; the test build injects a failure on request
+      return fail(GLRM_ERR_OOM, "injected set-up failure (test build hook)");
     if ((rc = glrm_setup_tiled(h))) return rc;
     if ((rc = glrm_setup_cached(h))) return rc;
     if ((rc = glrm_setup_blocked(h))) return rc;

@@ -23,7 +23,8 @@
 // super-tile) and are added in super-tile order, so no bit depends on the arrival order (tests: test_multi_in_process.py,
 // test_gpu_families.py).  The Y blocks (k x n / N: 0.08 ms per link at C4) are exchanged the old way.
 //
-// Link emulation (one box, fewer GPUs than shards): GLRM_EXCHANGE_EMULATE_GBPS=<rate> makes every direct push occupy its (source,
+// Link emulation (TEST BUILD ONLY: compiled with -DGLRM_HIP_TESTING into libglrm_hip_testing.so, never into the product library --
+// lowrankmodels.jl_amd/build.py; one box, fewer GPUs than shards): GLRM_EXCHANGE_EMULATE_GBPS=<rate> makes every direct push occupy its (source,
 // destination) link for bytes / rate counted from the moment the source range was complete -- a device-to-device copy on one GPU takes
 // no such time.  Mechanism 1 (default where hipDeviceAttributeCanUseStreamWaitValue is set): the copy stream writes a start mark
 // (hipStreamWriteValue64), copies, then waits (hipStreamWaitValue64) for a release value that a host timer thread posts bytes / rate
@@ -64,8 +65,12 @@ struct Rccl {
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
   Rccl() {
-    const char* path = getenv("GLRM_HIP_RCCL_LIB"); // another build of the library -- or the test suite's stand-in (tests/stubs/rccl_stub.cpp)
+#ifdef GLRM_HIP_TESTING // the test build may load a stand-in (tests/stubs/rccl_stub.cpp); the product library only ever opens librccl
+    const char* path = getenv("GLRM_HIP_RCCL_LIB");
     void* lib = (path && *path) ? dlopen(path, RTLD_LAZY | RTLD_LOCAL) : nullptr;
+#else
+    void* lib = nullptr;
+#endif
     if (!lib) lib = dlopen("librccl.so", RTLD_LAZY | RTLD_LOCAL);
     if (!lib) lib = dlopen("librccl.so.1", RTLD_LAZY | RTLD_LOCAL);
     if (!lib) return;
@@ -139,6 +144,7 @@ struct ShardPool {
   }
 };
 
+#ifdef GLRM_HIP_TESTING
 // ---- link emulator ----------------------------------------------------------------------------------------------------
 __global__ void link_mark_kernel(unsigned long long* t0) { *t0 = (unsigned long long)wall_clock64(); }
 __global__ void link_delay_kernel(const unsigned long long* t0, unsigned long long ticks) {
@@ -190,6 +196,8 @@ struct LinkEmu {
   }
 };
 
+#endif // GLRM_HIP_TESTING
+
 struct glrm_multi {
   int n = 0;
   ShardPool pool;
@@ -205,7 +213,9 @@ struct glrm_multi {
   std::vector<std::vector<hipEvent_t>> ev_arr;       // ev_arr[s][t]: block of s landed on t
   std::vector<std::vector<std::vector<hipEvent_t>>> ev_chunk; // ev_chunk[s][t][j]: row chunk j of s's X block landed on t
   int arrival = 1;                                   // Y half-step consumes the X chunks in arrival order (glrm_hip_step_y_arrival)
+#ifdef GLRM_HIP_TESTING
   LinkEmu emu;
+#endif
   std::vector<double> wait_y0;                       // ms_wait_y of every shard at the start of the fit
   std::vector<int64_t> rbs, cbs, ybs;                // shard bounds: rows, columns, vectors of Y
   int exchange = 0;                                  // in use: 0 direct, 1 rccl
@@ -264,6 +274,7 @@ int run_all(glrm_multi* mh, const std::function<int(int)>& fn) {
     if (e_ != hipSuccess) return fail(GLRM_ERR_COMM, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
 
+#ifdef GLRM_HIP_TESTING
 // Link emulation around the pushes of source `link` on its link stream c: before / after hooks
 int emu_before(glrm_multi* mh, hipStream_t c, int link) {
   LinkEmu& e = mh->emu;
@@ -289,6 +300,8 @@ int emu_after(glrm_multi* mh, hipStream_t c, int link, size_t bytes) {
   }
   return GLRM_OK;
 }
+
+#endif // GLRM_HIP_TESTING
 
 // Shard s owns buf[bounds[s]*unit .. bounds[s+1]*unit) (doubles) restricted to the sub-range [lo_s, hi_s) of its block given by
 // (cj, cn) (fractions j/C of the block for the pipelined X exchange; 0/1 = the whole block).  Phase 1 (push): after the work already
@@ -322,12 +335,15 @@ int exchange_push(glrm_multi* mh, std::vector<double*>& buf, const std::vector<i
     if (rc || rc2) return fail(GLRM_ERR_COMM, "RCCL exchange failed: %s", R.GetErrorString ? R.GetErrorString(rc ? rc : rc2) : "?");
     return GLRM_OK;
   }
+#ifdef GLRM_HIP_TESTING
   const bool emulate = mh->emu.bytes_per_s > 0.0;
+#endif
   for (int s = 0; s < n; ++s) {
     const int64_t blk = bounds[s + 1] - bounds[s];
     const int64_t lo = bounds[s] + blk * cj / cn, hi = bounds[s] + blk * (cj + 1) / cn;
     const size_t bytes = (size_t)((hi - lo) * unit) * 8;
     COMMCK(hipSetDevice(mh->dev[s]));
+#ifdef GLRM_HIP_TESTING
     if (emulate) {
       // ONE stream per source stands for its n - 1 links (they run in parallel and carry equal sizes, so they finish together):
       // mark, the copies, then the wait for bytes / rate since the mark, then the arrival events.  Few streams on purpose: a queue
@@ -351,6 +367,7 @@ int exchange_push(glrm_multi* mh, std::vector<double*>& buf, const std::vector<i
       }
       continue;
     }
+#endif
     for (int d = 1; d < n; ++d) { // destinations in ring order from s: no destination is everybody's first
       const int t = (s + d) % n;
       if (only_dst >= 0 && t != only_dst) continue;
@@ -426,11 +443,13 @@ extern "C" void glrm_hip_multi_destroy(glrm_multi* mh) {
   if (!mh) return;
   int prev = 0;
   (void)hipGetDevice(&prev);
+#ifdef GLRM_HIP_TESTING
   if (mh->emu.timer.joinable()) { // nothing may be left waiting for a release on the device
     mh->emu.release_all();
     mh->emu.quit.store(true, std::memory_order_release);
     mh->emu.timer.join();
   }
+#endif
   for (int s = 0; s < (int)mh->sh.size(); ++s) {
     if (mh->sh[s]) glrm_hip_destroy(mh->sh[s]);
   }
@@ -450,9 +469,11 @@ extern "C" void glrm_hip_multi_destroy(glrm_multi* mh) {
       for (auto& v : mh->ev_chunk[s])
         for (hipEvent_t e : v)
           if (e) (void)hipEventDestroy(e);
+#ifdef GLRM_HIP_TESTING
     if (s < (int)mh->emu.mark.size() && mh->emu.mark[s]) (void)hipFree(mh->emu.mark[s]);
     if (s < (int)mh->emu.release.size() && mh->emu.release[s]) (void)hipFree(mh->emu.release[s]);
     if (s < (int)mh->emu.t0.size() && mh->emu.t0[s]) (void)hipFree(mh->emu.t0[s]);
+#endif
     if (s < (int)mh->ev_done.size() && mh->ev_done[s]) (void)hipEventDestroy(mh->ev_done[s]);
     if (s < (int)mh->ev_ready.size() && mh->ev_ready[s]) (void)hipEventDestroy(mh->ev_ready[s]);
     if (s < (int)mh->st.size() && mh->st[s]) (void)hipStreamDestroy(mh->st[s]);
@@ -564,8 +585,13 @@ static int multi_create_impl(glrm_multi* mh, const glrm_problem* p, const glrm_o
   const int want = env_int("GLRM_HIP_EXCHANGE_RCCL", mo->exchange);
   if (want == 1 && n > 1) {
     Rccl& R = Rccl::get();
-    // RCCL wants one device per rank; GLRM_HIP_RCCL_ALLOW_SHARED=1 lifts that for the test suite's stand-in library
-    if (R.ok && (distinct || env_int("GLRM_HIP_RCCL_ALLOW_SHARED", 0))) {
+    // RCCL wants one device per rank (the test build's GLRM_HIP_RCCL_ALLOW_SHARED=1 lifts that for the suite's stand-in library)
+#ifdef GLRM_HIP_TESTING
+    const bool shared_ok = env_int("GLRM_HIP_RCCL_ALLOW_SHARED", 0) != 0;
+#else
+    const bool shared_ok = false;
+#endif
+    if (R.ok && (distinct || shared_ok)) {
       mh->comms.assign(n, nullptr);
       const int e = R.CommInitAll(mh->comms.data(), n, mh->dev.data());
       if (e) return fail(GLRM_ERR_COMM, "ncclCommInitAll failed: %s", R.GetErrorString ? R.GetErrorString(e) : "?");
@@ -585,6 +611,7 @@ static int multi_create_impl(glrm_multi* mh, const glrm_problem* p, const glrm_o
         for (int j = 0; j < mh->x_chunks; ++j) HIPCK(hipEventCreateWithFlags(&mh->ev_chunk[s][t][j], hipEventDisableTiming));
       }
     }
+#ifdef GLRM_HIP_TESTING
   // link emulation (see the head of this file)
   const char* eg = getenv("GLRM_EXCHANGE_EMULATE_GBPS");
   const double gbps = (eg && *eg) ? atof(eg) : 0.0;
@@ -624,6 +651,10 @@ static int multi_create_impl(glrm_multi* mh, const glrm_problem* p, const glrm_o
     }
     e.bytes_per_s = gbps * 1e9 / e.dilate; // set last: the hooks are live from here
   }
+#else
+  if (getenv("GLRM_EXCHANGE_EMULATE_GBPS") && *getenv("GLRM_EXCHANGE_EMULATE_GBPS") && atof(getenv("GLRM_EXCHANGE_EMULATE_GBPS")) > 0.0)
+    return fail(GLRM_ERR_UNSUPPORTED, "GLRM_EXCHANGE_EMULATE_GBPS: the link emulator lives in the test build (libglrm_hip_testing.so), not in this library");
+#endif
   return GLRM_OK;
 }
 

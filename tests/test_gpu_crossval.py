@@ -161,8 +161,15 @@ def test_subset_of_shard_parents_is_deferred_until_the_host_finalizes(monkeypatc
     finally:
         for q in parents + kids:
             api.destroy(q)
-    # the latch: a set-up that failed half way refuses a second finalize
+    # the latch: a set-up that failed half way refuses a second finalize.  The failure is injected through a hook that exists in the TEST BUILD
+    # of the engine only (libglrm_hip_testing.so, csrc/glrm_testhooks.hip); the product library ignores the variable
     monkeypatch.setenv("GLRM_HIP_TEST_FAIL_FINALIZE", "1")
+    q = api.create(cases.shard_of(pa, 0, 900, 0, 40), defer=True)
+    try:
+        api.finalize(q, whole)          # the product library: no such hook
+    finally:
+        api.destroy(q)
+    api = _capi.hip_testing_api()
     q = api.create(cases.shard_of(pa, 0, 900, 0, 40), defer=True)
     try:
         with pytest.raises(_capi.GLRMError) as ei:

@@ -24,7 +24,7 @@ import cases, oracle as O
 import lowrankmodels.jl_amd as L
 from lowrankmodels.jl_amd import _capi
 from test_multi_in_process import run_multi
-api = _capi.hip_api()
+api = _capi.hip_testing_api()   # the stand-in can only be loaded by the TEST BUILD of the engine (GLRM_HIP_RCCL_LIB does not exist in the product library)
 stub = ctypes.CDLL(os.environ["GLRM_HIP_RCCL_LIB"])
 def counts():
     a, b, g = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)

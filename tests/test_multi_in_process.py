@@ -187,9 +187,13 @@ def test_hip_multi_arrival_order_and_link_emulation(monkeypatch, emulate):
     o1, X1, Y1, st1 = cases.run_engine(api, pa, X0, Y0, params)
     assert st1["tiled"] & 32
     gbps, dilate = 0.5, 4                       # X block: 2000 rows x 64 x 8 B = 1.02 MB -> 8.2 ms per iteration at 0.5 / 4 GB/s
-    if emulate != "off":
+    if emulate != "off":  # the link emulator lives in the test build of the engine only (libglrm_hip_testing.so); the product library refuses the variable
         monkeypatch.setenv("GLRM_EXCHANGE_EMULATE_GBPS", str(gbps))
         monkeypatch.setenv("GLRM_EXCHANGE_EMULATE_MODE", {"wait-value": "1", "delay-kernel": "2"}[emulate])
+        with pytest.raises(_capi.GLRMError) as ei:
+            api.multi_create(pa, 4, device_ids=[0] * 4, x_chunks=4, arrival=1, profile=1)
+        assert ei.value.code == _capi.ERR_UNSUPPORTED and "test build" in str(ei.value)
+        api = _capi.hip_testing_api()
     for arrival, chunks in ((1, 4), (2, 4), (0, 1), (2, 1)):
         t0 = time.perf_counter()
         try:
