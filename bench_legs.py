@@ -685,7 +685,8 @@ def inlib_host(args):
             "exchange_ms_is": "time the compute streams stood waiting for blocks that had not arrived (Y-block exchange: end of the sweeps to the last "
                               "arrival; X: the waits inside the arrival-ordered Y half-step), max over shards, summed over the call, per iteration.  In TRUE arrival "
                               "order (the default on the phase-aligned column passes) a super-tile is only enqueued once its blocks have arrived: the stream "
-                              "never stands in a wait, the host thread polls instead, and that time is NOT in this figure -- link_emulation's A/B is the measure",
+                              "never stands in a wait, the host thread polls instead; since round 6 the time it polled with NO super-tile ready is booked in this figure too "
+                              "(an upper bound on the device's idle time) -- link_emulation's A/B stays the direct measure",
             "row_bounds": info["row_bounds"], "col_bounds": info["col_bounds"], "x_chunks": args.x_chunks if N > 1 else 0,
             "shared_device": bool(args.shared_device),
             "timed_region": "iterations warmup+1 .. warmup+steps of ONE glrm_hip_multi_fit call on the library's per-iteration clock (ch.times)",
