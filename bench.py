@@ -242,8 +242,8 @@ def main():
         value = args.steps * updates_per_step / elapsed
         ms_x = st["ms_x"] / max(args.steps, 1)  # per outer iteration (the X half-step may run as several chunk launches)
         ms_y = st["ms_y"] / max(args.steps, 1)
-        fam_r = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 1 else "cached" if flags & 64 else "blocked" if flags & 16 else "gather"
-        fam_c = "general" if flags & 8 else "dense" if flags & 4 else "tiled" if flags & 2 else "blocked" if flags & 32 else "gather"
+        fam_r = "general" if flags & 8 else "dense" if flags & 4 else "lane" if flags & 256 else "tiled" if flags & 1 else "cached" if flags & 64 else "blocked" if flags & 16 else "gather"
+        fam_c = "general" if flags & 8 else "dense" if flags & 4 else "lane" if flags & 512 else "tiled" if flags & 2 else "blocked" if flags & 32 else "gather"
         ld = st["ld"]
         tile = 150 * 1024 // (ld * 8 + 16) // 16 * 16  # csrc/glrm_tiled.hip: tile_rows_c
         rl_r = kernel_roofline(fam_r, nnz=nnz_r, nseg=nseg_r, nopp=n, k=k, ld=ld, ms=ms_x, m=nseg_r, n=n, tile=tile, quad_gram=args.quad_gram)
@@ -257,6 +257,8 @@ def main():
                                     "(X half-step, LDS-tiled)", r"tiled_sweep_kernel|tiled_col_pass_kernel<[^>]*, true>"),
                  ("col", "tiled"): ("tiled_col_pass_kernel gradient pass + trial rounds + col_reduce/col_decide (Y half-step, LDS-tiled)",
                                     r"tiled_col_pass_kernel<[^>]*, false>"),
+                 ("row", "lane"): ("lane_pass_kernel gradient pass + trial rounds + col_reduce/col_decide (X half-step, LDS tiles, one lane per row)", "lane_pass_kernel"),
+                 ("col", "lane"): ("lane_pass_kernel gradient pass + trial rounds + col_reduce/col_decide (Y half-step, LDS tiles, one lane per column)", "lane_pass_kernel"),
                  ("row", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (X half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
                  ("col", "blocked"): ("tiled_col_pass_kernel<L2> passes + col_reduce/col_decide (Y half-step, phase-aligned L2 gathers)", "tiled_col_pass_kernel"),
                  ("row", "cached"): ("regcached_persist_kernel / regcached_sweep_kernel<G, R, LOSS, 7, 2> (X half-step: the row's list and opposing vectors fetched "
@@ -275,8 +277,10 @@ def main():
                 # the row and the column pass of the blocked family are the same kernel instantiation: the child runs only the dominant
                 # side on it (the other side on the one-kernel gather sweep), so its dispatches can be told apart by name
                 cenv = {"GLRM_HIP_BLOCKED": "1" if dom == "row" else "2"} if dom_fam == "blocked" else None
-                traffic, traffic_src, l2_hits = pmc_traffic(args, kre, per_halfstep=dom_fam in ("blocked", "tiled"), child_env=cenv,
-                                                            eval_pass=dom == "col" and dom_fam in ("blocked", "tiled"))
+                if dom_fam == "lane":  # rows and columns run ONE kernel: the child keeps only the dominant side on it (the other on the four-lane kernels)
+                    cenv = {"GLRM_HIP_LANE": "1" if dom == "row" else "2"}
+                traffic, traffic_src, l2_hits = pmc_traffic(args, kre, per_halfstep=dom_fam in ("blocked", "tiled", "lane"), child_env=cenv,
+                                                            eval_pass=dom == "col" and dom_fam in ("blocked", "tiled", "lane"))
                 if traffic is not None and dom_fam == "gather" and st["waves_row"] == st["waves_col"]:
                     traffic_src += " (row and column sweeps run the same instantiation here: the mean is over both)"
             except Exception as e:  # the bench line must survive a profiler problem

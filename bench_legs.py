@@ -80,6 +80,7 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
 
     family   'gather'  every update fetches the opposing k-vector from memory (csrc/glrm_hip.hip sweep_kernel)
              'tiled'   the opposing factor is staged tile by tile in LDS (csrc/glrm_tiled.hpp)
+             'lane'    the same with ONE LANE per segment and 512 segments per staged tile (csrc/glrm_lane.hpp)
              'blocked' phase-aligned gather passes: the k-vector gathers are served by the L2 of the XCD (csrc/glrm_blocked.hip)
              'dense'   fully observed QuadLoss on the fp64 matrix cores (csrc/glrm_dense.hpp)
              'general' multi-dimensional losses (csrc/glrm_multi.hpp)
@@ -107,7 +108,9 @@ def kernel_roofline(family, *, nnz, nseg, nopp, k, ld, ms, m=0, n=0, tile=560, s
                                                 used="v_mfma_f64_16x16x4_f64", source="profiles/r02_ubench_mfma.txt")))
         cands.append(dict(bound="hbm", achieved=passes * m * n * 8 / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=passes * m * n * 8,
                           what="A streamed once per pass, %d pass%s per half-step" % (passes, "es" if passes > 1 else "")))
-    elif family == "tiled":
+    elif family in ("tiled", "lane"):
+        if family == "lane":  # csrc/glrm_lane.hpp: 8 waves x 64 segments share a staged tile
+            segs_per_wg = 512
         nwg = max(1, -(-nseg // segs_per_wg))
         staged = nwg * P * opp                   # every workgroup stages the whole opposing factor once per pass
         cands.append(dict(bound="hbm", achieved=(stream + opp) / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", per_launch=stream + opp,
@@ -218,7 +221,7 @@ def family_step_bytes(family, nnz, nseg, nopp, k, ld, hbm_floor=False):
     P = passes_priced(family)
     own = 2 * nseg * ld * 8
     opp = nopp * ld * 8
-    if family == "tiled" or (hbm_floor and opp <= MALL_BYTES):
+    if family in ("tiled", "lane") or (hbm_floor and opp <= MALL_BYTES):
         return P * 12 * nnz + own + opp
     return P * (12 + 8 * k) * nnz + own
 
@@ -556,8 +559,8 @@ def emulate_rank(args):
     sf.close()
     ms_x, ms_y = st["ms_x"] / args.steps, st["ms_y"] / args.steps
     flags, ld = st["tiled"], st["ld"]
-    fam_r = "tiled" if flags & 1 else "cached" if flags & 64 else "blocked" if flags & 16 else "gather"
-    fam_c = "tiled" if flags & 2 else "blocked" if flags & 32 else "gather"
+    fam_r = "lane" if flags & 256 else "tiled" if flags & 1 else "cached" if flags & 64 else "blocked" if flags & 16 else "gather"
+    fam_c = "lane" if flags & 512 else "tiled" if flags & 2 else "blocked" if flags & 32 else "gather"
     ex_x = exchange_model_ms((m // N) * ld * 8, N)
     ex_y = exchange_model_ms((n // N) * ld * 8 + (n // N) * 8, N)
     bytes_x = nnz_r * (12 + 8 * k) * (1 if fam_r == "cached" else 2)

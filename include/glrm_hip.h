@@ -447,7 +447,8 @@ typedef struct glrm_kernel_stats {
                                   bit4 / bit5: phase-aligned gather passes (L2-blocked) for the row / column sweep,
                                   bit6: cached gather row sweep (the short rows' opposing vectors fetched once per half-step
                                   and kept in registers / LDS for every pass), bit7: reference-order validation sweeps
-                                  (glrm_options.sum_order = 1) */
+                                  (glrm_options.sum_order = 1), bit8 / bit9: the LDS-tiled row / column passes run in their
+                                  lane-per-segment form (csrc/glrm_lane.hpp) */
   double ms_wait_y;            /* glrm_hip_step_y_arrival with profile=1: time the launch stream waited for blocks of X to arrive; in TRUE
                                   arrival order also the time the calling thread polled with NO super-tile ready (an upper bound on the
                                   device's idle time: earlier super-tiles may still have been running) */
@@ -493,7 +494,9 @@ typedef struct glrm_sum_order {
   int32_t cached_waves;
   int32_t batch;           /* loss partial sums per lane group: STRIDED 1 or 4 (4 applies to one-wave segments only when batch_one_wave_only), WINDOWED 2 or lanes */
   int32_t batch_one_wave_only;
-  int32_t rotate;          /* WINDOWED: 1 = chunk walk i ^ ((global segment id & 7) >> 1) in the dot products of the passes */
+  int32_t rotate;          /* WINDOWED: the lane's fma chain walks its 16-byte chunks in the order i ^ r: 1 = r = (global segment id & 7) >> 1
+                              (four-lane groups, conflict-free column passes); 2 = r = (global segment id >> 1) & 7 (the lane-per-segment
+                              passes, csrc/glrm_lane.hpp: lanes = 2, comps = kp / 2 -- two chains over the even / odd chunks) */
   int64_t window;          /* WINDOWED: opposing vectors per window */
   int64_t windows_per_sup; /* WINDOWED: windows per super-tile; 0 = the whole list is one super-tile and nothing is re-added */
   int32_t private_order;   /* the engine walks a private copy of the list in another order than the caller's; the order above applies to

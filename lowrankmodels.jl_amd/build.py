@@ -19,8 +19,8 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"]
 
 TARGETS = {
-    "libglrm_hip.so": (["glrm_hip.hip", "glrm_tiled.hip", "glrm_dense.hip", "glrm_multi.hip", "glrm_subset.hip", "glrm_svd.hip", "glrm_impute.hip", "glrm_tilesort.hip", "glrm_multigpu.hip", "glrm_blocked.hip", "glrm_cached.hip", "glrm_reforder.hip", "glrm_transpose.hip", "glrm_testhooks.hip"],
-                       ["glrm_device.hpp", "glrm_fastmath.hpp", "glrm_tiled.hpp", "glrm_dense.hpp", "glrm_multi.hpp", "glrm_impute.hpp", "glrm_engine.hpp", "../../include/glrm_hip.h"]),
+    "libglrm_hip.so": (["glrm_hip.hip", "glrm_tiled.hip", "glrm_dense.hip", "glrm_multi.hip", "glrm_subset.hip", "glrm_svd.hip", "glrm_impute.hip", "glrm_tilesort.hip", "glrm_multigpu.hip", "glrm_blocked.hip", "glrm_cached.hip", "glrm_reforder.hip", "glrm_transpose.hip", "glrm_testhooks.hip", "glrm_lane.hip"],
+                       ["glrm_device.hpp", "glrm_fastmath.hpp", "glrm_tiled.hpp", "glrm_dense.hpp", "glrm_multi.hpp", "glrm_impute.hpp", "glrm_engine.hpp", "glrm_lane.hpp", "../../include/glrm_hip.h"]),
     "libglrm_synth.so": (["glrm_synth.hip"], ["../../include/glrm_synth.h"]),
 }
 

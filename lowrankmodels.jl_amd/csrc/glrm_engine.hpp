@@ -75,6 +75,13 @@ struct glrm_handle {
   glrm_loss* udesc = nullptr;         // the model's distinct loss descriptors (<= 256), device
   int n_udesc = 0;
   int32_t *colperm = nullptr, *rowperm = nullptr; // tiled sweeps: segments sorted by (loss kind, length) / by length
+  // lane-per-segment LDS-tiled passes (glrm_lane.hpp), [0] rows, [1] columns: family flag and the SELL layout of the view
+  int lane[2] = {0, 0};
+  int64_t* lane_bptr[2] = {nullptr, nullptr};
+  int32_t* lane_off[2] = {nullptr, nullptr};
+  double* lane_val[2] = {nullptr, nullptr};
+  int64_t lane_nwb[2] = {0, 0}, lane_steps[2] = {0, 0};
+  int lane_ntiles[2] = {0, 0};
   // general sweeps: multi-dimensional losses / wrapped regularizers (glrm_multi.hip)
   bool multi = false;
   int64_t d = 0;                      // vectors of Y = sum of embedding dimensions (= n for scalar losses)
@@ -187,6 +194,14 @@ inline int64_t glrm_cached_reg_maxlen(int G) { return (int64_t)13 * (64 / G); }
 int glrm_prepare_tiled(glrm_handle* h);
 int glrm_setup_tiled(glrm_handle* h);
 int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, double min_stepsize, int eval_only);
+
+// lane-per-segment LDS-tiled passes (glrm_lane.hip): setup decides lane[] from the whole problem's signature and builds the SELL layouts;
+// run takes the TiledArgs glrm_run_tiled prepared (glrm_tiled.hpp)
+namespace glrm { struct TiledArgs; }
+bool glrm_lane_wants(const glrm_handle* h, bool rows);   // the whole problem's shape / losses / options admit the family on that side (given that the side runs the LDS tiles)
+int glrm_setup_lane(glrm_handle* h);
+bool glrm_lane_loss_ok(int loss);
+int glrm_run_lane(glrm_handle* h, bool rows, int loss, const glrm::TiledArgs& a, double min_stepsize, int eval_only);
 
 // phase-aligned gather passes (glrm_blocked.hip): setup decides blocked_row / blocked_col and allocates the pass buffers
 int glrm_setup_blocked(glrm_handle* h);

@@ -585,7 +585,8 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
                   h->activebuf, h->ntrialbuf, h->nactive, h->dflag, h->Arow, h->Acol, h->part_r, h->gsum_r, h->trial_r,
                   h->jold_r, h->active_r, h->ntrial_r, h->ystart, h->mtrial, h->mpart_loss, h->mpart_G, h->mgtot,
                   h->mobjold, h->mactive, h->mnactive, h->colperm, h->rowperm, h->seglist_r, h->seglist_c, h->rowdescid, h->udesc,
-                  h->gramH, h->gram_part, h->jloss_r, h->jloss_c, h->lock_ctr, h->actlist, h->blk_perm_c, h->blk_long_c};
+                  h->gramH, h->gram_part, h->jloss_r, h->jloss_c, h->lock_ctr, h->actlist, h->blk_perm_c, h->blk_long_c,
+                  h->lane_bptr[0], h->lane_bptr[1], h->lane_off[0], h->lane_off[1], h->lane_val[0], h->lane_val[1]};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->iter_exec) (void)hipGraphExecDestroy(h->iter_exec);
@@ -1384,7 +1385,7 @@ extern "C" int glrm_hip_kernel_stats(glrm_handle* h, glrm_kernel_stats* out, int
   out->nnz_rows = h->nnz_r; out->nnz_cols = h->nnz_c;
   out->waves_row = h->waves_row; out->waves_col = h->waves_col; out->ld = h->kp;
   out->tiled = h->multi ? 8 : (h->tiled_row ? 1 : 0) | (h->tiled_col ? 2 : 0) | (h->dense ? 4 : 0) | (h->cached_row ? 64 : 0) | (h->blocked_row ? 16 : 0) |
-               (h->blocked_col ? 32 : 0) | (h->sum_order_opt ? 128 : 0); // bit0 / bit1: LDS-tiled row / column sweep, bit4 / bit5: phase-aligned gather passes, bit7: reference order
+               (h->blocked_col ? 32 : 0) | (h->sum_order_opt ? 128 : 0) | (h->lane[0] ? 256 : 0) | (h->lane[1] ? 512 : 0); // bit8 / bit9: lane-per-segment form of the LDS-tiled row / column passes; bit0 / bit1: LDS-tiled row / column sweep, bit4 / bit5: phase-aligned gather passes, bit7: reference order
   if (reset) {
     h->launches_x = h->launches_y = 0;
     h->ms_x = h->ms_y = h->ms_wait = 0;
@@ -1432,6 +1433,13 @@ extern "C" int glrm_hip_sum_order(glrm_handle* h, int32_t which, glrm_sum_order*
     const bool sorted_here = rows ? h->sig_local.rows_unordered != 0 : h->sig_local.cols_unordered != 0;
     const bool grouped = rows && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_GROUP_KINDS", 1); // glrm_tiled.hpp: group_rows_by_kind_kernel
     o.private_order = sorted_here ? 1 : grouped ? 2 : 0; // (2: stable grouping by ascending loss kind inside every window -- the oracle restates it)
+    if (h->lane[rows ? 0 : 1]) { // lane-per-segment passes (glrm_lane.hpp): two fma chains over the even / odd chunks = the two-lane layout, rotated walk
+      o.lanes = 2; o.comps = h->kp / 2;
+      o.batch = 2;
+      o.rotate = 2;
+      o.window = T;
+      o.windows_per_sup = rows ? 0 : h->tiles_per_sup;
+    }
   } else if (blocked) {
     const int Tb = ((150 * 1024) / (h->kp * 8 + 16)) / 16 * 16; // glrm_blocked.hip: tile_rows_b
     o.family = GLRM_ORDER_WINDOWED;

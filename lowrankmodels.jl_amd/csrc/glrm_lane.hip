@@ -1,0 +1,206 @@
+// glrm_lane.hip -- host side + instantiations of the lane-per-segment LDS-tiled passes (kernels and rationale: glrm_lane.hpp).
+//
+// A side (rows / columns) of a handle runs this family instead of the four-lane tiled kernels when glrm_setup_tiled chose the LDS tiles for it
+// and (all functions of the WHOLE problem's signature and of (k, losses, options), never of the shard -- the two families add in different
+// orders): padded rank 32; one loss descriptor per segment or per model (rows of a model with a loss per column stay on the four-lane kernels);
+// at most GLRM_HIP_LANE_MAX_NNZ observations in the view (default 2e9: the SELL copy is 12 B x ~1.5 per observation on top of the lists).
+// The half-step is the pass machinery of the tiled column sweep on BOTH sides: gradient pass -> col_reduce (J_old, first trial point, list of
+// searching segments) -> rounds of (trial pass, col_decide); rows run it with ONE super-tile (nothing is re-added).  The first trial of a
+// half-step walks the SELL layout over the full grid (idle segments masked); later rounds, whose segments are few, run the CSR form of the
+// same kernel over the compact list: the same sums in the same order, so which form ran changes no bit.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+#include "glrm_engine.hpp"
+#include "glrm_lane.hpp"
+
+using namespace glrm;
+
+namespace {
+
+constexpr int LANE_NW = 8; // 8 waves x 64 segments per workgroup, 256 VGPRs per lane
+constexpr int lane_tile_rows(int kp) { return ((150 * 1024) / (kp * 8 + 16)) / 16 * 16; } // = tile_rows_c(kp, 1): the order unit of the lists
+
+template <int LOSS, bool GRAD, bool CSR>
+int launch_lane_inst(const TiledArgs& a, const LaneArgs& la, int64_t nblocks, hipStream_t st) {
+  constexpr int KP = 32, T = lane_tile_rows(KP), LDSB = T * KP * 8;
+  auto k = lane_pass_kernel<KP, LANE_NW, T, LOSS, GRAD, CSR>;
+  HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); // (per device: a process may drive several)
+  const unsigned gx = (unsigned)((nblocks + LANE_NW - 1) / LANE_NW);
+  if (gx == 0) return GLRM_OK;
+  hipLaunchKernelGGL(k, dim3(gx, (unsigned)a.nsup), dim3(LANE_NW * 64), LDSB, st, a, la);
+  return GLRM_OK;
+}
+
+template <bool GRAD, bool CSR>
+int launch_lane_loss(int loss, const TiledArgs& a, const LaneArgs& la, int64_t nblocks, hipStream_t st) {
+  switch (loss) {
+    case LOSS_QUAD_UNIFORM: return launch_lane_inst<0, GRAD, CSR>(a, la, nblocks, st);
+    case LOSS_SEGMENT: return launch_lane_inst<1, GRAD, CSR>(a, la, nblocks, st);
+    case LOSS_SEGMENT_NOTRIG: return launch_lane_inst<3, GRAD, CSR>(a, la, nblocks, st);
+    default: return fail(GLRM_ERR_UNSUPPORTED, "lane-per-segment passes: no kernel for loss variant %d", loss);
+  }
+}
+
+// the small kernels of the pass machinery in the two-lane layout the family's sums are reported in
+void launch_small(int which, const TiledArgs& a, hipStream_t st) {
+  constexpr int G = 2, R = 16;
+  const unsigned gx = (unsigned)((a.nseg + 4 * (64 / G) - 1) / (4 * (64 / G)));
+  if (which == 0) hipLaunchKernelGGL((col_reduce_kernel<G, R>), dim3(gx), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((col_decide_kernel<G, R>), dim3(gx), dim3(256), 0, st, a);
+}
+
+} // namespace
+
+bool glrm_lane_loss_ok(int loss) { return loss == LOSS_QUAD_UNIFORM || loss == LOSS_SEGMENT || loss == LOSS_SEGMENT_NOTRIG; }
+
+// what does not depend on the buffers: padded rank, tile configuration, losses, view size -- all of the WHOLE problem
+bool glrm_lane_wants(const glrm_handle* h, bool rows) {
+  const int want = env_int("GLRM_HIP_LANE", 3); // bit0 rows, bit1 columns
+  if (!((want >> (rows ? 0 : 1)) & 1) || h->kp != 32 || !h->tile_cfg || h->tile_lw > 0 || h->multi || h->dense || h->sum_order_opt) return false;
+  if (lane_tile_rows(h->kp) != h->order_unit) return false; // (loader-wave experiments order the lists by half tiles)
+  if (rows && h->n_losses > 1) return false;                // a loss per column: the row view meets a descriptor per observation
+  const int64_t max_nnz = (int64_t)env_int("GLRM_HIP_LANE_MAX_NNZ_M", 2000) * 1000000ll;
+  return (rows ? h->sig.nnz_rows : h->sig.nnz_cols) <= max_nnz;
+}
+
+// finalize, after glrm_setup_tiled has chosen the LDS tiles and built the slot permutations: decide the family per side and build its SELL layout
+int glrm_setup_lane(glrm_handle* h) {
+  h->lane[0] = h->lane[1] = 0;
+  const int T = lane_tile_rows(h->kp);
+  hipStream_t st = h->stream;
+  for (int side = 0; side < 2; ++side) {
+    const bool rows = side == 0;
+    if (!glrm_lane_wants(h, rows)) continue;
+    if (rows ? !(h->tiled_row && !h->row_split && (h->tile_rounds & 1) && h->actlist && h->part_r) : !h->tiled_col) continue;
+    h->lane[side] = 1;
+    const int64_t nseg = rows ? h->ml : h->nl;
+    const int64_t nslots = rows ? nseg : (h->blk_nlong_c > 0 ? h->blk_nshort_c : nseg);
+    const int64_t nother = rows ? h->n : h->m;
+    const int ntiles = (int)((nother + T - 1) / T);
+    const int64_t nwb = (nslots + 63) / 64;
+    h->lane_nwb[side] = nwb;
+    h->lane_ntiles[side] = ntiles;
+    if (nwb == 0 || ntiles == 0) continue;
+    const int64_t* ptr = rows ? h->rowptr : h->colptr;
+    const int32_t* idx = rows ? h->colidx : h->rowidx;
+    const double* vals = rows ? h->rowvals : h->colvals;
+    const int32_t* perm = rows ? h->rowperm : h->colperm;
+    const int64_t ncell = nwb * ntiles;
+    if (ncell > (int64_t)1 << 30) { h->lane[side] = 0; continue; } // (cannot happen at shapes the LDS tiles are chosen for)
+    int64_t *cnt = nullptr, *scan = nullptr;
+    void* tmp = nullptr;
+    auto cleanup = [&](int rc) { (void)hipFree(cnt); (void)hipFree(scan); (void)hipFree(tmp); return rc; };
+    HIPCK(hipMalloc((void**)&cnt, (size_t)ncell * 8));
+    if (hipMalloc((void**)&scan, (size_t)ncell * 8) != hipSuccess) return cleanup(fail(GLRM_ERR_OOM, "out of device memory"));
+    hipLaunchKernelGGL(lane_count_kernel, dim3((unsigned)nwb), dim3(64), 0, st, ptr, idx, perm, nslots, T, ntiles, cnt);
+    size_t bytes = 0;
+    if (hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt, scan, (int)ncell, st) != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "scan (size query) failed"));
+    if (hipMalloc(&tmp, bytes ? bytes : 1) != hipSuccess) return cleanup(fail(GLRM_ERR_OOM, "out of device memory"));
+    if (hipcub::DeviceScan::ExclusiveSum(tmp, bytes, cnt, scan, (int)ncell, st) != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "scan failed"));
+    if (hipMalloc((void**)&h->lane_bptr[side], (size_t)nwb * (ntiles + 1) * 8) != hipSuccess) return cleanup(fail(GLRM_ERR_OOM, "out of device memory"));
+    const int64_t nb = nwb * (ntiles + 1);
+    hipLaunchKernelGGL(lane_bptr_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, scan, cnt, nwb, ntiles, h->lane_bptr[side]);
+    int64_t last[2] = {0, 0};
+    if (hipMemcpyAsync(&last[0], scan + ncell - 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&last[1], cnt + ncell - 1, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+      return cleanup(fail(GLRM_ERR_HIP, "lane layout: copy failed"));
+    const int64_t steps = last[0] + last[1];
+    h->lane_steps[side] = steps;
+    const int64_t s1 = steps > 0 ? steps : 1;
+    if (hipMalloc((void**)&h->lane_off[side], (size_t)s1 * 64 * 4) != hipSuccess || hipMalloc((void**)&h->lane_val[side], (size_t)s1 * 64 * 8) != hipSuccess)
+      return cleanup(fail(GLRM_ERR_OOM, "out of device memory for the lane-per-segment stream of the %s view (%lld steps of 64 entries)", rows ? "row" : "column", (long long)steps));
+    hipLaunchKernelGGL(lane_fill_kernel, dim3((unsigned)nwb), dim3(64), 0, st, ptr, idx, vals, perm, nslots, T, ntiles, h->kp * 8, h->lane_bptr[side], h->lane_off[side],
+                       h->lane_val[side]);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "lane layout: build failed"));
+    cleanup(0);
+    if (env_int("GLRM_HIP_LANE_TRACE", 0))
+      fprintf(stderr, "[glrm lane] %s view: %lld slots in %lld wave blocks x %d tiles, %lld steps of 64 = %.3f x the %lld observations\n", rows ? "row" : "column",
+              (long long)nslots, (long long)nwb, ntiles, (long long)steps, (double)steps * 64.0 / (double)std::max<int64_t>(1, rows ? h->nnz_r : h->nnz_c),
+              (long long)(rows ? h->nnz_r : h->nnz_c));
+  }
+  return GLRM_OK;
+}
+
+// One half-step (or the evaluation pass of the column view) on the lane-per-segment passes.  `a` comes prepared by glrm_run_tiled: the side's
+// views, factors, pass buffers, slot permutation and -- rows of a sub-range sweep -- everything offset to the range's first row.
+int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, double min_stepsize, int eval_only) {
+  TiledArgs a = a_in;
+  const int side = rows ? 0 : 1;
+  hipStream_t st = h->stream;
+  LaneArgs la{};
+  la.bptr = h->lane_bptr[side];
+  la.off = h->lane_off[side];
+  la.val = h->lane_val[side];
+  la.ntiles = h->lane_ntiles[side];
+  la.nwb = h->lane_nwb[side];
+  la.slot0 = 0;
+  (void)min_stepsize;
+  // does the SELL layout cover this launch?  It was built on the side's full slot space (slot permutation included); a row sub-range
+  // (glrm_hip_step_x_range) is covered when the slots are the rows themselves: its wave blocks run with the lanes outside the range masked
+  const bool range = rows && h->rng_e >= 0;
+  const bool sell_ok = !range || h->rowperm == nullptr;
+  if (range) la.slot0 = h->rng_b;
+  const int64_t nslots = a.npass > 0 ? a.npass : a.nseg;
+  const int64_t blk_lo = la.slot0 / 64, blk_hi = (la.slot0 + nslots + 63) / 64;
+  int rc;
+  const bool lists = h->actlist && (rows ? (h->tile_rounds & 1) != 0 : (h->tile_rounds & 2) != 0) && a.nseg <= h->actlist_cap;
+  int32_t* list[2] = {lists ? h->actlist : nullptr, lists ? h->actlist + h->actlist_cap : nullptr};
+  int cur = 0;
+  HIPCK(hipMemsetAsync(h->nactive, 0, 4, st));
+  a.actlist_out = list[cur];
+  auto csr_args = [&](const TiledArgs& t) { // the CSR form numbers its slots from 0 over t.nseg (a compact list or a plain range)
+    LaneArgs c = la;
+    c.slot0 = 0;
+    return c;
+  };
+  if (sell_ok) rc = launch_lane_loss<true, false>(loss, a, la, blk_hi - blk_lo, st);
+  else {
+    TiledArgs t = a;
+    t.npass = 0;
+    rc = launch_lane_loss<true, true>(loss, t, csr_args(t), (t.nseg + 63) / 64, st);
+  }
+  if (rc) return rc;
+  launch_small(0, a, st);
+  HIPCK(hipGetLastError());
+  if (eval_only) return GLRM_OK;
+  const TiledArgs full = a;
+  constexpr int MAX_ROUNDS = 4096; // see glrm_run_tiled
+  for (int round = 0;; ++round) {
+    if (round == MAX_ROUNDS) return fail(GLRM_ERR_INVALID, "line search still running after %d rounds (min_stepsize %g)", MAX_ROUNDS, min_stepsize);
+    unsigned int nact = 0;
+    HIPCK(hipMemcpyAsync(&nact, h->nactive, 4, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    if (nact == 0) break;
+    HIPCK(hipMemsetAsync(h->nactive, 0, 4, st));
+    TiledArgs t = full;
+    // while nearly every segment still searches (the first trial) the pass walks the SELL layout over the full grid; the few that are left
+    // afterwards run the CSR form over the compact list
+    const bool compact = lists && ((int64_t)nact * 4 < full.nseg * 3 || !sell_ok);
+    if (compact) {
+      t.segperm = list[cur];
+      t.nseg = nact;
+      t.npass = 0;
+      rc = launch_lane_loss<false, true>(loss, t, csr_args(t), ((int64_t)nact + 63) / 64, st);
+    } else if (sell_ok) {
+      rc = launch_lane_loss<false, false>(loss, t, la, blk_hi - blk_lo, st);
+    } else {
+      t.npass = 0;
+      rc = launch_lane_loss<false, true>(loss, t, csr_args(t), (t.nseg + 63) / 64, st);
+    }
+    if (rc) return rc;
+    TiledArgs d = full;
+    if (lists) {
+      d.actlist_in = list[cur];
+      d.nact_in = nact;
+      d.actlist_out = list[cur ^ 1];
+      cur ^= 1;
+    }
+    launch_small(1, d, st);
+    HIPCK(hipGetLastError());
+  }
+  return GLRM_OK;
+}

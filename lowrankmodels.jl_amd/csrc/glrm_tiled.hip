@@ -213,9 +213,13 @@ int glrm_setup_tiled(glrm_handle* h) {
     // enough (column group, super-tile) workgroups to fill the chip a few times over: the column groups come from the GLOBAL n
     // (256 columns per 16-wave workgroup at G=4), so the super-tile size -- hence the order of the partial sums -- is a function
     // of (m, n, tile) only, never of the shard layout
-    const int spb = (h->tile_cfg ? 16 : 8) * (64 / h->tG);
+    // (the lane-per-segment form of the passes holds 512 columns per workgroup and stages its tiles of X at ~3 TB/s with nothing to overlap
+    // them: more, shorter super-tiles even the workgroups out -- C2 Y half-step 7.6 -> 7.0 ms at twice the workgroups, session r6_09; the
+    // family is a function of the whole problem's signature, so this still is)
+    const bool lane_c = h->tiled_col && glrm_lane_wants(h, false);
+    const int spb = lane_c ? 512 : (h->tile_cfg ? 16 : 8) * (64 / h->tG);
     const int64_t groups = (h->n + spb - 1) / spb;
-    const int64_t want_wg = env_int("GLRM_HIP_COL_WORKGROUPS", 1024);
+    const int64_t want_wg = env_int("GLRM_HIP_COL_WORKGROUPS", lane_c ? 2048 : 1024);
     int64_t nsup_target = (want_wg + groups - 1) / groups;
     if (nsup_target < 1) nsup_target = 1;
     int64_t tps = ntiles / nsup_target;
@@ -310,7 +314,7 @@ int glrm_setup_tiled(glrm_handle* h) {
       h->row_split = 1;
     }
   }
-  return GLRM_OK;
+  return glrm_setup_lane(h); // the lane-per-segment form of the passes where it applies (glrm_lane.hip)
 }
 
 template <typename K>
@@ -454,6 +458,8 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
     a.trials += s0; a.accepts += s0;
   }
   const bool row_rounds = rows && !h->row_split && (h->tile_rounds & 1) && !eval_only && a.fixed_alpha <= 0.0 && h->actlist;
+  // lane-per-segment passes (glrm_lane.hpp): the ProxGradParams half-steps and the evaluation pass of the sides that run that family
+  const bool lane_here = h->lane[rows ? 0 : 1] && glrm_lane_loss_ok(loss) && a.fixed_alpha <= 0.0 && (rows ? row_rounds : true);
   if (rows && !h->row_split && !row_rounds) {
     a.segperm = h->rng_e >= 0 ? nullptr : h->rowperm; // a sub-range sweep keeps the natural order
     return launch_tiled(h, loss, 0, a);
@@ -480,6 +486,7 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
       }
     }
   }
+  if (lane_here) return glrm_run_lane(h, rows, loss, a, min_stepsize, eval_only);
   int rc;
   const bool lists = h->actlist && (rows ? (h->tile_rounds & 1) != 0 : (h->tile_rounds & 2) != 0) && a.nseg <= h->actlist_cap;
   int32_t* list[2] = {lists ? h->actlist : nullptr, lists ? h->actlist + h->actlist_cap : nullptr};

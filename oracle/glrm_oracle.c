@@ -707,6 +707,10 @@ static double eng_reg_evaluate(const glrm_reg* r, const double* x, int k, int G,
   return r->scale * eng_butterfly(p, G);
 }
 
+/* lane layout of the engine's gather sweeps for a padded rank (csrc/glrm_hip.hip: 4 / 8 / 16 lanes for kp <= 32 / 64 / 128) -- what a
+ * segment DIVERTED from the windowed passes (glrm_sum_order.long_from) is swept in, whatever layout the passes themselves use */
+static int eng_gather_lanes(int kp) { return kp <= 32 ? 4 : (kp <= 64 ? 8 : 16); }
+
 static int eng_wave_count(const glrm_sum_order* o, int64_t len, int rows) {
   if (rows && o->cached_maxlen >= 0 && len <= o->cached_maxlen) return o->cached_waves > 0 ? o->cached_waves : 1;
   if (o->waves > 0) return o->waves;
@@ -718,9 +722,10 @@ static int eng_wave_count(const glrm_sum_order* o, int64_t len, int rows) {
  * `work` holds ENG_WORK_DOUBLES(k) doubles: T <= 128 lane groups (glrm_cpu_set_sum_order refuses STRIDED layouts beyond that). */
 static void eng_pass(const glrm_cpu_handle* h, const glrm_sum_order* o, int rows, int64_t gseg, const int32_t* idx, const double* vals, int64_t len,
                      const double* xv, const double* fac, const glrm_loss* segloss, double* J, double* g, double* work) {
-  const int k = h->k, G = o->lanes, R = o->comps;
+  const int k = h->k;
   /* WINDOWED with long_from: the phase-aligned column passes hand segments of at least that many observations to the 8-wave gather sweep */
   const int diverted = o->family == GLRM_ORDER_WINDOWED && o->long_from > 0 && len >= o->long_from;
+  const int G = diverted ? eng_gather_lanes(o->lanes * o->comps) : o->lanes, R = o->lanes * o->comps / G;
   if (o->family == GLRM_ORDER_STRIDED || diverted) {
     const int NG = 64 / G, W = diverted ? 8 : eng_wave_count(o, len, rows), T = NG * W;
     const int cached = !diverted && rows && o->cached_maxlen >= 0 && len <= o->cached_maxlen;
@@ -763,7 +768,9 @@ static void eng_pass(const glrm_cpu_handle* h, const glrm_sum_order* o, int rows
   }
   /* GLRM_ORDER_WINDOWED: one lane group walks the list in list order */
   const int batch = o->batch > 0 ? o->batch : 2;
-  const int rot = o->rotate ? (int)((gseg & 7) >> 1) : 0;
+  /* rotate: 1 = four-lane groups of the conflict-free column passes (glrm_tiled.hpp: tile_rot_of); 2 = the lane-per-segment passes
+   * (glrm_lane.hpp: register i of the lane holds chunk i ^ (gseg & 15); its two chains are the two lanes of this layout) */
+  const int rot = o->rotate == 2 ? (int)((gseg >> 1) & 7) : o->rotate ? (int)((gseg & 7) >> 1) : 0;
   const int64_t win = o->window, wps = o->windows_per_sup;
   double Jtot = 0.0, Jp[16];
   double* gp = work; /* k */
@@ -831,8 +838,11 @@ static int eng_step(glrm_cpu_handle* h, int rows, int64_t s0, int64_t s1, double
       const glrm_loss* segloss = rows ? (h->n_losses == 1 ? &h->losses[0] : NULL) : loss_of(h, gseg);
       const glrm_reg* r = rows ? rx_of(h, sl) : ry_of(h, sl);
       double Jold, Jn;
+      /* the regularizer sums run in the layout of the kernel that sweeps the segment (a diverted segment: the gather sweep's) */
+      const int dv = o->family == GLRM_ORDER_WINDOWED && o->long_from > 0 && e - b >= o->long_from;
+      const int rG = dv ? eng_gather_lanes(o->lanes * o->comps) : o->lanes, rR = o->lanes * o->comps / rG;
       eng_pass(h, o, rows, gseg, idx, vals, e - b, x, fac, segloss, &Jold, g, work);
-      Jold += eng_reg_evaluate(r, x, k, o->lanes, o->comps);
+      Jold += eng_reg_evaluate(r, x, k, rG, rR);
       const double l = (double)(e - b) + 1;
       double alpha = rows ? h->alpharow[sl] : h->alphacol[sl];
       while (alpha > min_stepsize) {
@@ -840,7 +850,7 @@ static int eng_step(glrm_cpu_handle* h, int rows, int64_t s0, int64_t s1, double
         for (int c = 0; c < k; ++c) xn[c] = fma(-s, g[c], x[c]);
         glrm_cpu_reg_prox(r, xn, k, s);
         eng_pass(h, o, rows, gseg, idx, vals, e - b, xn, fac, segloss, &Jn, NULL, work);
-        Jn += eng_reg_evaluate(r, xn, k, o->lanes, o->comps);
+        Jn += eng_reg_evaluate(r, xn, k, rG, rR);
         ++trials;
         if (accept_test(h, Jn, Jold)) {
           memcpy(x, xn, (size_t)k * 8);
@@ -883,8 +893,8 @@ int glrm_cpu_set_sum_order(glrm_cpu_handle* h, int32_t which, const glrm_sum_ord
   if (order->family == GLRM_ORDER_WINDOWED) {
     if (order->window <= 0 || order->windows_per_sup < 0 || !(order->batch == 2 || order->batch == G))
       return fail(GLRM_ERR_INVALID, "sum order: bad window geometry");
-    if (order->long_from < 0 || (order->long_from > 0 && (64 / G) * 8 > 128))
-      return fail(GLRM_ERR_INVALID, "sum order: long_from needs a lane layout of at least 4 lanes (8 waves x 64 / lanes groups)");
+    if (order->long_from < 0 || (order->long_from > 0 && (64 / eng_gather_lanes(G * R)) * 8 > 128))
+      return fail(GLRM_ERR_INVALID, "sum order: long_from needs a gather layout of at least 4 lanes (8 waves x 64 / lanes groups)");
     /* the walk needs the lists ordered by window, like the engine's own check (glrm_tiled.hpp: check_sorted_kernel) */
     const int64_t ns = which == 0 ? h->row_end - h->row_begin : h->col_end - h->col_begin;
     const int64_t* ptr = which == 0 ? h->rowptr : h->colptr;

@@ -260,3 +260,64 @@ def half_step(passfn, regfn, proxfn, x, alpha, nobs, min_stepsize=0.01):
             alpha = min_stepsize * 1.1
             break
     return list(x), alpha, Jold, trials
+
+
+def lane_kernel_pass(idx, vals, xv, fac, k, TILE, tiles_per_sup, n_other, scale, grad, gseg, KP=32):
+    """csrc/glrm_lane.hpp: lane_pass_kernel, literally.  ONE lane owns the segment; register i holds the 16-byte chunk i ^ p of x, g and y,
+    p = gseg & 15; the dot product is two fma chains -- uA over the even registers, uB over the odd ones -- added once; the loss terms go to J0 /
+    J1 by the entry's position inside its tile window modulo 2 and are added at the end of the pass (one pass = one super-tile, or all tiles
+    when tiles_per_sup = 0); gradient terms in list order; the super-tiles' partial sums are added in order from 0 (col_reduce_kernel)."""
+    C = KP // 2
+    p = gseg & (C - 1)
+
+    def reg(v, i):  # the double2 register i of a vector: chunk i ^ p (zero padded beyond k)
+        c = (i ^ p) * 2
+        return (v[c] if c < k else 0.0, v[c + 1] if c + 1 < k else 0.0)
+
+    ntiles = (n_other + TILE - 1) // TILE
+    tps = tiles_per_sup if tiles_per_sup > 0 else ntiles
+    nsup = (ntiles + tps - 1) // tps
+    Jtot, gtot = 0.0, [0.0] * k
+    pos = 0
+    for s in range(nsup):
+        J0 = J1 = 0.0
+        g = [[0.0, 0.0] for _ in range(C)]
+        for t in range(s * tps, min((s + 1) * tps, ntiles)):
+            hi = min((t + 1) * TILE, n_other)
+            e = 0
+            while pos < len(idx) and idx[pos] < hi:
+                y = fac[idx[pos]]
+                uA = uB = 0.0
+                for i in range(0, C, 2):
+                    xa, ya = reg(xv, i), reg(y, i)
+                    uA = fma(xa[0], ya[0], uA)
+                    uA = fma(xa[1], ya[1], uA)
+                    xb, yb = reg(xv, i + 1), reg(y, i + 1)
+                    uB = fma(xb[0], yb[0], uB)
+                    uB = fma(xb[1], yb[1], uB)
+                dot = uA + uB
+                L, dL = quad_loss(scale, dot, vals[pos])
+                if e & 1:
+                    J1 += L
+                else:
+                    J0 += L
+                if grad:
+                    for i in range(C):
+                        yi = reg(y, i)
+                        g[i][0] = fma(dL, yi[0], g[i][0])
+                        g[i][1] = fma(dL, yi[1], g[i][1])
+                pos += 1
+                e += 1
+        Js = J0 + J1
+        gs = [0.0] * k
+        for i in range(C):
+            c = (i ^ p) * 2
+            for h in (0, 1):
+                if c + h < k:
+                    gs[c + h] = g[i][h]
+        if tiles_per_sup > 0:
+            Jtot += Js
+            gtot = [gtot[c] + gs[c] for c in range(k)]
+        else:
+            Jtot, gtot = Js, gs
+    return Jtot, gtot

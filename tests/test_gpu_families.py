@@ -309,7 +309,8 @@ def test_borrowed_device_arrays_give_the_bits_of_copied_ones(tiled, mix):
         out.append((obj, X, Y, st["tiled"]))
         for a, b in zip(snap, (w.rowptr, w.colidx, w.rowvals, w.colptr, w.rowidx, w.colvals)):
             assert torch.equal(a, b)
-    assert out[0][3] == out[1][3] == (3 if tiled == 2 else 0)
+    # bit0 / bit1: the LDS tiles on both sides; bit8 / bit9: in their lane-per-segment form (rank 32; rows only with ONE loss descriptor)
+    assert out[0][3] == out[1][3] == ((3 | 512 | (0 if mix else 256)) if tiled == 2 else 0)
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     with pytest.raises(_capi.GLRMError):   # host arrays cannot be borrowed
         pa, X0, Y0 = ragged_problem(np.random.default_rng(1), 30, 20, 4, 5)
@@ -351,6 +352,7 @@ def test_lds_tiled_rounds_over_the_searching_segments_give_the_bits_of_the_in_ke
     rounds the same way.  Which workgroup slot a segment sits in changes no sum: factors, step sizes' effects and trial counts must equal
     the round-3 forms (GLRM_HIP_TILE_ROUNDS=0: the whole search inside the row kernel, column rounds over every workgroup that holds an
     active column) bit for bit -- from a start and a step size that make most segments reject several trials."""
+    monkeypatch.setenv("GLRM_HIP_LANE", "0")   # the four-lane kernels (rank 32 would otherwise run the lane-per-segment passes, whose search always runs in rounds)
     m, n, k, q = 4000, 1500, 32, 150
     rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, q, value_model=0, loss_mix=1 if mixed else 0)
     if mixed:

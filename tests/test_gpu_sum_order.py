@@ -95,6 +95,18 @@ def test_lds_tiled_sweeps_quadloss(k):
     pa, X0, Y0 = problem(6000, 1500, k, 300, (1, 0, 1.0))
     o = engine_and_oracle_in_its_order(pa, X0, Y0, 8, TILED_R | TILED_C, ("windowed", "windowed"), tiled=2)
     assert o[0].windows_per_sup == 0 and o[1].windows_per_sup >= 1 and o[0].batch == 2 and not o[0].private_order
+    # padded rank 32: both sides run the lane-per-segment form of the passes (csrc/glrm_lane.hpp), reported as the two-lane layout with the
+    # rotated chunk walk; rank 64 stays on the four / eight-lane kernels
+    assert [(x.lanes, x.comps, x.rotate) for x in o] == ([(2, 16, 2)] * 2 if k == 32 else [(8, 8, 0)] * 2)
+
+
+def test_lds_tiled_sweeps_quadloss_on_the_four_lane_kernels(monkeypatch):
+    """GLRM_HIP_LANE=0: the four-lane tiled kernels at rank 32 (what rows of models with a loss per column, views beyond 2e9 observations and
+    the sparse solver's fixed-step sweeps keep running on)."""
+    monkeypatch.setenv("GLRM_HIP_LANE", "0")
+    pa, X0, Y0 = problem(6000, 1500, 32, 300, (1, 0, 1.0))
+    o = engine_and_oracle_in_its_order(pa, X0, Y0, 8, TILED_R | TILED_C, ("windowed", "windowed"), tiled=2)
+    assert [(x.lanes, x.comps, x.rotate, x.batch) for x in o] == [(4, 8, 0, 2)] * 2
 
 
 def test_phase_aligned_passes(monkeypatch):
@@ -113,9 +125,19 @@ def test_heterogeneous_columns_on_the_lds_tiles(monkeypatch):
     per lane, the conflict-free chunk walk of the column passes (rotate), the LDS descriptor table.  The row view is NOT regrouped by
     loss kind here (GLRM_HIP_GROUP_KINDS=0): a regrouped private copy adds in an order the caller's lists do not determine."""
     monkeypatch.setenv("GLRM_HIP_GROUP_KINDS", "0")
+    monkeypatch.setenv("GLRM_HIP_LANE", "0")
     pa, X0, Y0 = problem(5000, 1500, 32, 300, (1, 0, 1.0), mixed=True)
     o = engine_and_oracle_in_its_order(pa, X0, Y0, 6, TILED_R | TILED_C, ("windowed", "windowed"), tiled=2)
     assert o[0].batch == 4 and o[1].batch == 4 and o[1].rotate == 1 and o[0].rotate == 0
+
+
+def test_heterogeneous_columns_on_the_lane_per_segment_passes(monkeypatch):
+    """The same model with the default family choice: the column view (ONE loss descriptor per column) runs the lane-per-segment passes, the row
+    view (a descriptor per observation) stays on the four-lane kernels."""
+    monkeypatch.setenv("GLRM_HIP_GROUP_KINDS", "0")
+    pa, X0, Y0 = problem(5000, 1500, 32, 300, (1, 0, 1.0), mixed=True)
+    o = engine_and_oracle_in_its_order(pa, X0, Y0, 6, TILED_R | TILED_C, ("windowed", "windowed"), tiled=2)
+    assert (o[0].lanes, o[0].batch, o[0].rotate) == (4, 4, 0) and (o[1].lanes, o[1].comps, o[1].batch, o[1].rotate) == (2, 16, 2, 2)
 
 
 def test_heterogeneous_columns_on_the_gather_sweeps():

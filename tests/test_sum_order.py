@@ -146,6 +146,34 @@ def test_windowed_order_equals_the_lane_simulation_of_the_tiled_passes(k, G, R, 
     assert (tx, ty) == (st["trials_x"], st["trials_y"])
 
 
+@pytest.mark.parametrize("k", [32, 27])
+def test_lane_per_segment_order_equals_the_simulation_of_the_lane_kernel(k):
+    """csrc/glrm_lane.hpp (round 6): one lane per segment, chunk walk i ^ (gseg & 15), two fma chains over the even / odd registers.  The engine
+    reports that family as WINDOWED with lanes = 2, comps = 16, batch = 2, rotate = 2 -- the two chains ARE the two lanes of that layout, each
+    walking its own chunks in the order i ^ ((gseg >> 1) & 7) -- and the oracle's restatement of that order must equal a literal simulation of
+    the kernel bit for bit (rows: one super-tile; columns: super-tiles of `tps` tiles; the regularizer sums in the two-lane layout of
+    col_reduce / col_decide<2, 16>)."""
+    tile, tps = 7, 3
+    pa, X0, Y0 = small_problem(40, 70, k, [1, 2, 8, 23, 64, 65], seed=300 + k, reg=(1, 0, 0.2))
+    orow = O.make_sum_order("windowed", 2, 16, window=tile, windows_per_sup=0, batch=2, rotate=2)
+    ocol = O.make_sum_order("windowed", 2, 16, window=tile, windows_per_sup=tps, batch=2, rotate=2)
+    X1, Y2, st = oracle_half_steps(pa, X0, Y0, orow, ocol)
+
+    def pf_rows(s, ix, vv, facl):
+        return lambda x, grad: LO.lane_kernel_pass(ix, vv, x, facl, k, tile, 0, pa.n, 0.75, grad, s)
+    Xs, tx = simulate(pa, X0, Y0, True, pf_rows, (1, 0, 0.2), 2, 16)
+    assert np.array_equal(Xs, X1)
+
+    def pf_cols(s, ix, vv, facl):
+        return lambda x, grad: LO.lane_kernel_pass(ix, vv, x, facl, k, tile, tps, pa.m, 0.75, grad, s)
+    Ys, ty = simulate(pa, Xs, Y0, False, pf_cols, (1, 0, 0.2), 2, 16)
+    assert np.array_equal(Ys, Y2)
+    assert (tx, ty) == (st["trials_x"], st["trials_y"])
+    # ... and it is a different order from the four-lane kernels' (the reason the family choice comes from the whole problem's signature)
+    X4, _, _ = oracle_half_steps(pa, X0, Y0, O.make_sum_order("windowed", 4, 8, window=tile, batch=2), ocol)
+    assert not np.array_equal(X4, X1) and np.abs(X4 - X1).max() < 1e-12
+
+
 def test_windowed_order_of_the_phase_aligned_passes():
     """tiled_pass<..., L2 = true>: the super-tile is one window walked in a single go (glrm_blocked.hip)."""
     k, G, R, unit, tps = 64, 8, 8, 4, 3

@@ -62,17 +62,25 @@ def expected_orders(m, n, k, q, mixed=False):
     # their chunks rotated; the row view is grouped by loss kind inside every window (private_order = 2, which the oracle restates)
     if mixed and not (tiled_r and tiled_c and G in (4, 8) and R == 8):
         raise SystemExit("a heterogeneous recipe outside the LDS-tiled families: write the gather families' batch rules down here first")
+    # lane-per-segment form of the LDS-tiled passes (csrc/glrm_lane.hip: glrm_setup_lane): padded rank 32, at most 2e9 observations in the view;
+    # rows only when the model has ONE loss descriptor.  Reported as the two-lane layout with the rotated chunk walk (rotate = 2)
+    lane_r = tiled_r and kp == 32 and not mixed and nnz <= 2_000_000_000
+    lane_c = tiled_c and kp == 32 and nnz <= 2_000_000_000
     if tiled_r:
         rows.update(family=2, window=T, windows_per_sup=0, batch=G if mixed else 2, private_order=2 if mixed else 0)
+        if lane_r:
+            rows.update(lanes=2, comps=kp // 2, batch=2, rotate=2)
     else:
         rows.update(family=1)
         if n * kp * 8 > 32 * 2 ** 20 and nnz >= 1e8 and G in (4, 8) and R == 8:
             rows.update(cached_maxlen=13 * (64 // G), cached_waves=2)
     if tiled_c:
         ntiles = -(-m // T)
-        groups = -(-n // spb)
-        tps = max(1, min(ntiles // max(1, -(-1024 // groups)), max(1, 32768 // T)))
+        groups = -(-n // (512 if lane_c else spb))          # (glrm_setup_tiled: 512 columns per workgroup and twice the workgroups on the lane family)
+        tps = max(1, min(ntiles // max(1, -(-(2048 if lane_c else 1024) // groups)), max(1, 32768 // T)))
         cols.update(family=2, window=T, windows_per_sup=tps, batch=G if mixed else 2, rotate=1 if mixed else 0)
+        if lane_c:
+            cols.update(lanes=2, comps=kp // 2, batch=2, rotate=2)
     else:
         if m * kp * 8 > 32 * 2 ** 20 and nnz >= 2e8:
             raise SystemExit("this problem would run the phase-aligned column passes: write their geometry down here first")

@@ -379,8 +379,8 @@ static void run_lds1(const double* dY, double* dout) {
 }
 
 int main(int argc, char** argv) {
-  const int lg = argc > 1 ? atoi(argv[1]) : 19;
-  const int m = 1 << lg, n = 10000, ntiles = (n + TILE - 1) / TILE;
+  const int m = argc > 1 ? atoi(argv[1]) : 393216; // divisible by 64 x 8, 64 x 12 and 64 x 16
+  const int n = 10000, ntiles = (n + TILE - 1) / TILE;
   const uint32_t thresh = (uint32_t)(0.05 * 4294967296.0);
   int32_t* dcnt;
   const int64_t nt = (int64_t)m * ntiles;
@@ -427,5 +427,11 @@ int main(int argc, char** argv) {
   hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, 0, m, n, ntiles, thresh, dsptr, sidx, sval);
   CK(hipDeviceSynchronize());
   run<8, 1, false, 4>(m, n, ntiles, thresh, dsptr, sidx, sval, dX, dY, hX, hY, nobs, steps);
+  run<8, 1, false, 2>(m, n, ntiles, thresh, dsptr, sidx, sval, dX, dY, hX, hY, nobs, steps);
+  run<8, 1, false, 1>(m, n, ntiles, thresh, dsptr, sidx, sval, dX, dY, hX, hY, nobs, steps);
+  run<12, 1, false, 4>(m, n, ntiles, thresh, dsptr, sidx, sval, dX, dY, hX, hY, nobs, steps);
+  run<12, 1, false, 2>(m, n, ntiles, thresh, dsptr, sidx, sval, dX, dY, hX, hY, nobs, steps);
+  run<16, 1, false, 2>(m, n, ntiles, thresh, dsptr, sidx, sval, dX, dY, hX, hY, nobs, steps);
+  run<16, 1, true, 2>(m, n, ntiles, thresh, dsptr, sidx, sval, dX, dY, hX, hY, nobs, steps);
   return 0;
 }
