@@ -51,7 +51,10 @@ struct CMultiOptions; n_shards::Int32; exchange::Int32; device_ids::Ptr{Int32}; 
 
 include("HipGLRMDescriptors.jl")              # closs / creg / descriptors / dense_ok / value
 
-"The 7 ProxGradParams fields (src/algorithms/proxgrad.jl:4-12) + where and how to run (include/glrm_hip.h: glrm_options, glrm_multi_options)."
+"""The 7 ProxGradParams fields (src/algorithms/proxgrad.jl:4-12) + where and how to run (include/glrm_hip.h: glrm_options, glrm_multi_options).
+Tolerance: `mode = :fast` (production) keeps ch.objective within 1e-5 of the reference's on every committed fixture and equals the CPU oracle bit for
+bit in the engine's own summation order; factor ENTRIES of recipes that amplify rounding (NNMF of BASELINE config 4: 7e-3 after 100 iterations, the
+oracle against itself in two orders) meet 1e-5 only with `mode = :reference_order` (every sum added as the reference adds it; ~7x slower)."""
 mutable struct HipProxGradParams <: AbstractParams
     stepsize::Float64; max_iter::Int; inner_iter_X::Int; inner_iter_Y::Int
     abs_tol::Float64; rel_tol::Float64; min_stepsize::Float64

@@ -55,7 +55,7 @@ template <int KP, int NW, int TILE, int LOSS, bool GRAD, bool CSR>
 __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a, const LaneArgs la) {
   static_assert(KP == 32, "one lane per segment: x, g and y of a segment in one lane's registers -- built for a padded rank of 32");
   constexpr int C = KP / 2;            // 16-byte chunks per vector
-  constexpr int U = GRAD ? 2 : 4;      // steps in flight ahead of their use
+  constexpr int U = GRAD ? 2 : 4;      // steps in flight ahead of their use (even: a step's position parity inside its window is u & 1)
   constexpr int PSTRIDE = KP + 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

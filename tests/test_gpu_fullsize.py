@@ -45,7 +45,7 @@ def test_c2_full_size_properties(scale):
     ld = api.factor_ld(h)
     assert ld == 32
     st = api.kernel_stats(h)
-    assert st["waves_row"] == 1 and st["waves_col"] == 4 and st["tiled"] == 3  # C2 runs on the LDS-tiled sweeps
+    assert st["waves_row"] == 1 and st["waves_col"] == 4 and st["tiled"] == 3 + 256 + 512  # C2 runs on the LDS tiles, in their lane-per-segment form (rank 32)
     dX, dY = w.init_factors(ld)
     dC, dR = torch.zeros(n, dtype=torch.float64, device=dX.device), torch.zeros(m, dtype=torch.float64, device=dX.device)
     api.bind_buffers(h, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())
@@ -146,7 +146,7 @@ def test_c2_full_size_three_iterations_against_the_oracle():
     obj_g, _ = api.fit(h, p, Xg, Yg)
     st = api.kernel_stats(h)
     api.destroy(h)
-    assert st["tiled"] == 3 and st["nnz_rows"] == m * q
+    assert st["tiled"] == 3 + 256 + 512 and st["nnz_rows"] == m * q
     one = np.array([synth.QUAD], dtype=_capi.LOSS_DTYPE)
     reg = np.array([(1, 0, 1.0)], dtype=_capi.REG_DTYPE)
     pa = _capi.ProblemArrays(m, n, k, host[0], host[1][:m * q], host[2][:m * q], host[3], host[4][:m * q], host[5][:m * q], one, reg, reg)
