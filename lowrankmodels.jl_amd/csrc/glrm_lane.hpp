@@ -32,6 +32,13 @@
 
 #include "glrm_tiled.hpp"
 
+// Experiment switch (session r6_14, measured and dropped): request one dword of every 128-byte line of the NEXT tile while the current one is
+// consumed, so that the LDS-DMA finds its lines in L2.  C2 13.0-13.2 ms against 12.5-12.6: vmcnt counts in order, so the first wait for stream
+// data after these loads inherits their latency, and the extra registers push the gradient pass into scratch.
+#ifndef GLRM_LANE_PREFETCH
+#define GLRM_LANE_PREFETCH 0
+#endif
+
 namespace glrm {
 
 struct LaneArgs {
@@ -125,13 +132,34 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
   }
   const bool wb_ok = CSR || wb < la.nwb;
   const int64_t* bp = (CSR || !wb_ok) ? nullptr : la.bptr + wb * (int64_t)(la.ntiles + 1);
+#if GLRM_LANE_PREFETCH
+  int pf0 = 0, pf1 = 0, pf2 = 0;
+#endif
   for (int t = tb; t < te; ++t) {
     const int64_t lo = (int64_t)t * TILE;
     const int64_t hi = lo + TILE < a.n_other ? lo + TILE : a.n_other;
     __syncthreads(); // everybody is done with the previous tile
     dma_tile_all<2, KP / 2, NW, true>(a.other, lo, hi, lds, wave, lane); // unpadded rows: a plain copy by LDS-DMA from all waves
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if GLRM_LANE_PREFETCH
+    asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2)); // the prefetch registers of the previous tile stay reserved until their loads have landed
+#endif
     __syncthreads();
+#if GLRM_LANE_PREFETCH
+    // The staging above is latency: 143 KB per workgroup, all of it requested at once, then everybody waits (11.5 of 31 us per tile in the
+    // column passes, whose factor does not live in L2).  While this tile is consumed, one dword of every 128-byte line of the NEXT tile is
+    // requested and dropped: the lines are in the XCD's L2 when the LDS-DMA asks for them.  (vmcnt counts in order: the first wait for stream
+    // data issued after these loads also waits for them -- once per tile, against the whole staging latency before.)
+    if (t + 1 < te) {
+      const int64_t nlo = hi, nhi = nlo + TILE < a.n_other ? nlo + TILE : a.n_other;
+      const char* nsrc = reinterpret_cast<const char*>(a.other) + nlo * (KP * 8);
+      const int nlines = (int)(nhi - nlo) * (KP * 8) / 128;
+      const int l0 = (int)threadIdx.x, l1 = l0 + NW * 64, l2 = l1 + NW * 64;
+      if (l0 < nlines) asm volatile("global_load_dword %0, %1, off" : "=v"(pf0) : "v"(nsrc + (int64_t)l0 * 128) : "memory");
+      if (l1 < nlines) asm volatile("global_load_dword %0, %1, off" : "=v"(pf1) : "v"(nsrc + (int64_t)l1 * 128) : "memory");
+      if (l2 < nlines) asm volatile("global_load_dword %0, %1, off" : "=v"(pf2) : "v"(nsrc + (int64_t)l2 * 128) : "memory");
+    }
+#endif
     if constexpr (CSR) {
       int e = 0;
       while (pos < end) {

@@ -577,10 +577,18 @@ int glrm_cpu_set_dense_faithful(glrm_cpu_handle* h, int on) {
 
 /* -------------------------------------------------------------- primitives */
 
+/* TEST KNOB (glrm_cpu_set_dot_bias; 0 = off, the reference's value): every dot product <x_e, y_f> is returned times (1 + bias).  A run with
+ * bias = +2^-52 and one with -2^-52 move every u_ef by about one ulp -- what another order of adding its k terms does to it.  If either leaves
+ * the unbiased trajectory, some loss on it amplifies the rounding of its own argument beyond any tolerance (a PeriodicLoss column at |u| ~ 1e13:
+ * one ulp of u is 2e-3 rad, and the accept test of a trial out there is a coin flip; soak seeds 66071, 69955), and parity with an engine whose
+ * dot products add in another order is undefined on it (tests/perf/soak_fuzz.py: ill_conditioned). */
+static double g_dot_bias = 0.0;
+void glrm_cpu_set_dot_bias(double bias) { g_dot_bias = bias; }
+
 static inline double dotk(const double* x, const double* y, int k) {
   double s = 0.0;
   for (int c = 0; c < k; ++c) s = fma(x[c], y[c], s);
-  return s;
+  return g_dot_bias == 0.0 ? s : s * (1.0 + g_dot_bias);
 }
 
 /* gemm!('T','N',1.0,X,Y,0.0,XY), src/algorithms/proxgrad.jl:66,157,202 (dense-faithful only). */

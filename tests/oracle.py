@@ -74,6 +74,14 @@ def set_sum_order(h, which, order):
     api._ck(oracle_lib().glrm_cpu_set_sum_order(h, int(which), C.byref(order) if order is not None else None))
 
 
+def set_dot_bias(bias):
+    """Oracle-only test knob (process-wide): every dot product <x_e, y_f> times (1 + bias); 0 restores the reference's value."""
+    lib = oracle_lib()
+    lib.glrm_cpu_set_dot_bias.argtypes = [C.c_double]
+    lib.glrm_cpu_set_dot_bias.restype = None
+    lib.glrm_cpu_set_dot_bias(float(bias))
+
+
 def set_accept_bias(h, bias):
     """Test knob: the line search accepts iff new < old + bias * |old| (0 = the reference's strict `<`).  Runs with +eps and -eps bracket
     every decision that hangs on the last bits of the two sums (oracle/glrm_oracle.c: accept_test)."""

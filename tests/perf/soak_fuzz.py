@@ -78,7 +78,8 @@ def oracle_with_bias(pa, X0, Y0, p, bias):
 
 
 def ill_conditioned(pa, X0, Y0, p, ref, seed, tries=8):
-    """A failure only counts when the oracle reproduces ITSELF.  Three probes, each a question about the ORACLE alone:
+    """A failure only counts when the oracle reproduces ITSELF.  Four probes, each a question about the ORACLE alone (the fourth, round 6:
+      dot products   every <x_e, y_f> moved by one ulp either way -- see below):
       ties           does a line-search decision hang on the last bits of the two sums it compares?  The oracle runs with the accept test
                      `new < old (1 +- 4 ulps)` (oracle/glrm_oracle.c: accept_test); if either run leaves the unbiased one, some trial's
                      objective equals the old one to rounding -- e.g. a MultinomialOrdinalLoss column whose thresholds are all clamped: the
@@ -106,6 +107,21 @@ def ill_conditioned(pa, X0, Y0, p, ref, seed, tries=8):
         return True, float("inf")
     if worst > TOL / 10:
         return True, worst
+    # dot products: every <x_e, y_f> moved by one ulp either way (oracle/glrm_oracle.c: glrm_cpu_set_dot_bias) -- what another order of adding
+    # its k terms does.  Round 6 (seeds 66071, 69955: a PeriodicLoss column whose trial point sits at |u| ~ 1e13, one ulp = 2e-3 rad, the accept
+    # test of that trial a coin flip that eight perturbed starts happened to call the same way)
+    for bias in (2.0 ** -52, -2.0 ** -52):
+        O.set_dot_bias(bias)
+        try:
+            o_d, X_d, Y_d, _ = cases.run_engine(O.oracle_api(), pa, X0, Y0, p)
+        finally:
+            O.set_dot_bias(0.0)
+        try:
+            worst = max(worst, cases.rel_err(o_d, o_c) if len(o_d) == len(o_c) else float("inf"), vec_err(X_d, X_c), vec_err(Y_d, Y_c))
+        except AssertionError:
+            return True, float("inf")
+        if worst > TOL / 10:
+            return True, worst
     for _ in range(tries):
         Xp = np.asfortranarray(X0 * (1 + 1e-13 * rng.standard_normal(X0.shape)))
         Yp = np.asfortranarray(Y0 * (1 + 1e-13 * rng.standard_normal(Y0.shape)))
