@@ -200,7 +200,8 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
 namespace glrm { struct TiledArgs; }
 bool glrm_lane_wants(const glrm_handle* h, bool rows);   // the whole problem's shape / losses / options admit the family on that side (given that the side runs the LDS tiles)
 int glrm_setup_lane(glrm_handle* h);
-bool glrm_lane_loss_ok(int loss);
+bool glrm_lane_loss_ok(const glrm_handle* h, int loss);
+bool glrm_lane_few_descriptors(const glrm_handle* h);
 int glrm_run_lane(glrm_handle* h, bool rows, int loss, const glrm::TiledArgs& a, double min_stepsize, int eval_only);
 
 // phase-aligned gather passes (glrm_blocked.hip): setup decides blocked_row / blocked_col and allocates the pass buffers

@@ -1431,7 +1431,7 @@ extern "C" int glrm_hip_sum_order(glrm_handle* h, int32_t which, glrm_sum_order*
     o.rotate = (!(rows && !h->row_split) && !lw && !quad && GLRM_TILE_ROT && (h->tG == 4 || h->tG == 8) && h->tR == 8) ? 1 : 0;
     // a private copy in another order: lists the engine tile-sorted, rows regrouped by loss kind inside the tile windows
     const bool sorted_here = rows ? h->sig_local.rows_unordered != 0 : h->sig_local.cols_unordered != 0;
-    const bool grouped = rows && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_GROUP_KINDS", 1); // glrm_tiled.hpp: group_rows_by_kind_kernel
+    const bool grouped = rows && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_GROUP_KINDS", 1) && !h->lane[0]; // glrm_tiled.hpp: group_rows_by_kind_kernel (lane rows keep the caller's order)
     o.private_order = sorted_here ? 1 : grouped ? 2 : 0; // (2: stable grouping by ascending loss kind inside every window -- the oracle restates it)
     if (h->lane[rows ? 0 : 1]) { // lane-per-segment passes (glrm_lane.hpp): two fma chains over the even / odd chunks = the two-lane layout, rotated walk
       o.lanes = 2; o.comps = h->kp / 2;

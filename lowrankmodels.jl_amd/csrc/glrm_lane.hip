@@ -26,7 +26,8 @@ constexpr int lane_tile_rows(int kp) { return ((150 * 1024) / (kp * 8 + 16)) / 1
 
 template <int LOSS, bool GRAD, bool CSR>
 int launch_lane_inst(const TiledArgs& a, const LaneArgs& la, int64_t nblocks, hipStream_t st) {
-  constexpr int KP = 32, T = lane_tile_rows(KP), LDSB = T * KP * 8;
+  constexpr int KP = 32, T = lane_tile_rows(KP);
+  const int LDSB = T * KP * 8 + (loss_mode(LOSS) == 2 ? a.n_udesc * 32 : 0);
   auto k = lane_pass_kernel<KP, LANE_NW, T, LOSS, GRAD, CSR>;
   HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); // (per device: a process may drive several)
   const unsigned gx = (unsigned)((nblocks + LANE_NW - 1) / LANE_NW);
@@ -41,6 +42,8 @@ int launch_lane_loss(int loss, const TiledArgs& a, const LaneArgs& la, int64_t n
     case LOSS_QUAD_UNIFORM: return launch_lane_inst<0, GRAD, CSR>(a, la, nblocks, st);
     case LOSS_SEGMENT: return launch_lane_inst<1, GRAD, CSR>(a, la, nblocks, st);
     case LOSS_SEGMENT_NOTRIG: return launch_lane_inst<3, GRAD, CSR>(a, la, nblocks, st);
+    case LOSS_PER_OBS: return launch_lane_inst<2, GRAD, CSR>(a, la, nblocks, st);
+    case LOSS_PER_OBS_NOTRIG: return launch_lane_inst<4, GRAD, CSR>(a, la, nblocks, st);
     default: return fail(GLRM_ERR_UNSUPPORTED, "lane-per-segment passes: no kernel for loss variant %d", loss);
   }
 }
@@ -55,15 +58,40 @@ void launch_small(int which, const TiledArgs& a, hipStream_t st) {
 
 } // namespace
 
-bool glrm_lane_loss_ok(int loss) { return loss == LOSS_QUAD_UNIFORM || loss == LOSS_SEGMENT || loss == LOSS_SEGMENT_NOTRIG; }
+// (a loss per observation -- rows of a model with a loss per column -- needs the one-byte descriptor ids: at most 256 distinct descriptors)
+bool glrm_lane_loss_ok(const glrm_handle* h, int loss) {
+  return loss == LOSS_QUAD_UNIFORM || loss == LOSS_SEGMENT || loss == LOSS_SEGMENT_NOTRIG ||
+         ((loss == LOSS_PER_OBS || loss == LOSS_PER_OBS_NOTRIG) && h->rowdescid && h->n_udesc > 0 && h->n_udesc <= 256);
+}
+
+// at most 256 distinct loss descriptors in the model (what TiledArgs::descid can number)?  Host-side, from the descriptors alone.
+bool glrm_lane_few_descriptors(const glrm_handle* h) {
+  std::vector<glrm_loss> uniq;
+  for (const glrm_loss& l : h->losses_h) {
+    size_t u = 0;
+    for (; u < uniq.size(); ++u)
+      if (uniq[u].kind == l.kind && uniq[u].dim == l.dim && uniq[u].scale == l.scale && uniq[u].p0 == l.p0 && uniq[u].p1 == l.p1) break;
+    if (u == uniq.size()) {
+      if (uniq.size() == 256) return false;
+      uniq.push_back(l);
+    }
+  }
+  return true;
+}
 
 // what does not depend on the buffers: padded rank, tile configuration, losses, view size -- all of the WHOLE problem
 bool glrm_lane_wants(const glrm_handle* h, bool rows) {
   const int want = env_int("GLRM_HIP_LANE", 3); // bit0 rows, bit1 columns
   if (!((want >> (rows ? 0 : 1)) & 1) || h->kp != 32 || !h->tile_cfg || h->tile_lw > 0 || h->multi || h->dense || h->sum_order_opt) return false;
   if (lane_tile_rows(h->kp) != h->order_unit) return false; // (loader-wave experiments order the lists by half tiles)
-  if (rows && h->n_losses > 1) return false;                // a loss per column: the row view meets a descriptor per observation
-  const int64_t max_nnz = (int64_t)env_int("GLRM_HIP_LANE_MAX_NNZ_M", 2000) * 1000000ll;
+  // a loss per column: the row view meets a descriptor per observation -- through one-byte ids, i.e. at most 256 distinct descriptors
+  // OPT-IN (GLRM_HIP_LANE_PER_OBS=1): parity-green, but measured slower than the four-lane kernels on the C5 recipe (1M rows: X half-step 64.4
+  // against 45.8 ms, session r6_19/20 -- three serialized loss formulas per step, spills around them, and the line search's later rounds,
+  // 45 % / 20 % / ... of the rows, on the slow CSR form)
+  if (rows && h->n_losses > 1 && (!env_int("GLRM_HIP_UDESC", 1) || !env_int("GLRM_HIP_LANE_PER_OBS", 0) || !glrm_lane_few_descriptors(h))) return false;
+  // the SELL copy is 12 B x its padding per observation on top of the lists: a memory policy per view (rows: the copy REPLACES the kind-grouped
+  // private row view of such models, and rows pad little; columns pad x 1.5-1.8).  C5 at its stated size: 5e9 observations per view
+  const int64_t max_nnz = (int64_t)env_int(rows ? "GLRM_HIP_LANE_MAX_NNZ_ROWS_M" : "GLRM_HIP_LANE_MAX_NNZ_M", rows ? 6000 : 2000) * 1000000ll;
   return (rows ? h->sig.nnz_rows : h->sig.nnz_cols) <= max_nnz;
 }
 
@@ -76,6 +104,7 @@ int glrm_setup_lane(glrm_handle* h) {
     const bool rows = side == 0;
     if (!glrm_lane_wants(h, rows)) continue;
     if (rows ? !(h->tiled_row && !h->row_split && (h->tile_rounds & 1) && h->actlist && h->part_r) : !h->tiled_col) continue;
+    if (rows && h->n_losses > 1 && !(h->rowdescid && h->n_udesc > 0)) continue;
     h->lane[side] = 1;
     const int64_t nseg = rows ? h->ml : h->nl;
     const int64_t nslots = rows ? nseg : (h->blk_nlong_c > 0 ? h->blk_nshort_c : nseg);
@@ -113,8 +142,8 @@ int glrm_setup_lane(glrm_handle* h) {
     const int64_t s1 = steps > 0 ? steps : 1;
     if (hipMalloc((void**)&h->lane_off[side], (size_t)s1 * 64 * 4) != hipSuccess || hipMalloc((void**)&h->lane_val[side], (size_t)s1 * 64 * 8) != hipSuccess)
       return cleanup(fail(GLRM_ERR_OOM, "out of device memory for the lane-per-segment stream of the %s view (%lld steps of 64 entries)", rows ? "row" : "column", (long long)steps));
-    hipLaunchKernelGGL(lane_fill_kernel, dim3((unsigned)nwb), dim3(64), 0, st, ptr, idx, vals, perm, nslots, T, ntiles, h->kp * 8, h->lane_bptr[side], h->lane_off[side],
-                       h->lane_val[side]);
+    hipLaunchKernelGGL(lane_fill_kernel, dim3((unsigned)nwb), dim3(64), 0, st, ptr, idx, vals, (rows && h->n_losses > 1) ? h->rowdescid : nullptr, perm, nslots, T, ntiles,
+                       h->kp * 8, h->lane_bptr[side], h->lane_off[side], h->lane_val[side]);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "lane layout: build failed"));
     cleanup(0);
     if (env_int("GLRM_HIP_LANE_TRACE", 0))
@@ -177,9 +206,10 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
     if (nact == 0) break;
     HIPCK(hipMemsetAsync(h->nactive, 0, 4, st));
     TiledArgs t = full;
-    // while nearly every segment still searches (the first trial) the pass walks the SELL layout over the full grid; the few that are left
-    // afterwards run the CSR form over the compact list
-    const bool compact = lists && ((int64_t)nact * 4 < full.nseg * 3 || !sell_ok);
+    // while many segments still search the pass walks the SELL layout over the full grid (idle segments masked: the cost of a whole pass,
+    // whatever the fraction); the few that are left afterwards run the CSR form over the compact list, which costs 5-8 x as much per
+    // observation (one lane walks its own list: uncoalesced) -- measured cross-over at about a sixth of the segments (session r6_20)
+    const bool compact = lists && ((int64_t)nact * 6 < full.nseg || !sell_ok);
     if (compact) {
       t.segperm = list[cur];
       t.nseg = nact;

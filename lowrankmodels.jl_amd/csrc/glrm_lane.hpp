@@ -43,7 +43,8 @@ namespace glrm {
 
 struct LaneArgs {
   const int64_t* bptr; // [wave blocks][ntiles + 1]: first step of (wave block, tile); a step = 64 (offset, value) pairs, one per lane
-  const int32_t* off;  // [steps][64] byte offset of the staged vector inside its tile (local index x kp x 8); -1 = idle lane
+  const int32_t* off;  // [steps][64] byte offset of the staged vector inside its tile (local index x kp x 8, below 2^20) | the id of the
+                       // entry's loss descriptor << 20 (rows of a model with a loss per column; 0 otherwise); -1 = idle lane
   const double* val;   // [steps][64]
   int ntiles;          // tiles of the opposing factor (stride of bptr minus one)
   int64_t nwb;         // wave blocks the layout holds (a launch rounds its grid up to whole workgroups: blocks beyond have no steps)
@@ -93,7 +94,7 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
   const double two_scale = 2 * segloss.scale;
   // one observation: y from the tile (chunk order i ^ p), two fma chains over the even / odd registers (= the even / odd chunks or the
   // other way round: the sum of the two commutes), loss and derivative, gradient in list order
-  auto entry = [&](int off, double av, int par) {
+  auto entry = [&](int off, double av, int par, int did) {
     const char* yp = lds + off;
     double2 y[C];
 #pragma unroll
@@ -112,8 +113,14 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
       const double dq = dot - av;
       L = segloss.scale * (dq * dq);
       dL = dq * two_scale; // == (2 * d) * scale bit for bit: doubling is exact
-    } else {
+    } else if constexpr (loss_mode(LOSS) == 1) {
       loss_both<GRAD, loss_trig(LOSS)>(segloss, dot, av, L, dL);
+    } else { // a loss per observation: the 32-byte descriptor from the LDS table behind the tile (glrm_loss layout: kind, dim, scale, p0, p1)
+      const char* dp = lds + TILE * KP * 8 + did * 32;
+      const int2 kd = *reinterpret_cast<const int2*>(dp);
+      const double sc = *reinterpret_cast<const double*>(dp + 8);
+      const double2 pp = *reinterpret_cast<const double2*>(dp + 16);
+      loss_both<GRAD, loss_trig(LOSS)>(LossDesc{kd.x, sc, pp.x, pp.y}, dot, av, L, dL);
     }
     if (par) J1 += L; else J0 += L;
     if (GRAD) {
@@ -124,6 +131,12 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
       }
     }
   };
+  if constexpr (loss_mode(LOSS) == 2) { // the model's distinct loss descriptors behind the tile (read after the first tile's barriers)
+    const int words = a.n_udesc * 8;
+    const int* src = reinterpret_cast<const int*>(a.udesc);
+    int* dst = reinterpret_cast<int*>(lds + TILE * KP * 8);
+    for (int w = threadIdx.x; w < words; w += NW * 64) dst[w] = src[w];
+  }
   int64_t pos = 0, end = 0;
   if constexpr (CSR) {
     const int64_t beg = have ? a.ptr[seg] : 0;
@@ -165,7 +178,9 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
       while (pos < end) {
         const int c = a.idx[pos];
         if (c >= (int)hi) break;
-        entry((c - (int)lo) * (KP * 8), a.vals[pos], e & 1);
+        int did = 0;
+        if constexpr (loss_mode(LOSS) == 2) did = a.descid[pos];
+        entry((c - (int)lo) * (KP * 8), a.vals[pos], e & 1, did);
         ++pos;
         ++e;
       }
@@ -192,7 +207,10 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-          if (off[u] >= 0) entry(off[u], av[u], u & 1);
+          if (off[u] >= 0) {
+            if constexpr (loss_mode(LOSS) == 2) entry(off[u] & 0xFFFFF, av[u], u & 1, off[u] >> 20);
+            else entry(off[u], av[u], u & 1, 0);
+          }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           off[u] = noff[u];
@@ -245,7 +263,7 @@ static __global__ void lane_bptr_kernel(const int64_t* __restrict__ scan, const 
 }
 
 static __global__ void __launch_bounds__(64) lane_fill_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const double* __restrict__ vals,
-                                                              const int32_t* __restrict__ perm, int64_t nslots, int tile, int ntiles, int rowbytes,
+                                                              const uint8_t* __restrict__ descid, const int32_t* __restrict__ perm, int64_t nslots, int tile, int ntiles, int rowbytes,
                                                               const int64_t* __restrict__ bptr, int32_t* __restrict__ off, double* __restrict__ val) {
   const int lane = threadIdx.x;
   const int64_t wb = blockIdx.x, slot = wb * 64 + lane;
@@ -264,7 +282,7 @@ static __global__ void __launch_bounds__(64) lane_fill_kernel(const int64_t* __r
       if (pos < end) {
         const int c = idx[pos];
         if (c < hi) {
-          o = (int32_t)(c - lo) * rowbytes;
+          o = (int32_t)(c - lo) * rowbytes | (descid ? (int32_t)descid[pos] << 20 : 0);
           v = vals[pos];
           ++pos;
         }

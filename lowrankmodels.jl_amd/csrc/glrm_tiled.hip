@@ -159,7 +159,10 @@ int glrm_setup_tiled(glrm_handle* h) {
   }
   h->tiled_row = (h->rows_sorted && want_row) ? 1 : 0;
   h->tiled_col = (h->cols_sorted && want_col) ? 1 : 0;
-  if (h->tiled_row && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_GROUP_KINDS", 1)) {
+  // (rows on the lane-per-segment passes -- glrm_lane.hpp -- keep the caller's order: every lane evaluates its own observation's loss, so
+  // there is no wave-wide formula to align, and the grouped copy would cost 12 B per observation beside the SELL stream)
+  const bool lane_rows = h->tiled_row && !env_int("GLRM_HIP_ROW_SPLIT", 0) && (env_int("GLRM_HIP_TILE_ROUNDS", 3) & 1) && !(h->tile_cfg12) && glrm_lane_wants(h, true);
+  if (h->tiled_row && h->n_losses > 1 && h->nnz_r > 0 && env_int("GLRM_HIP_GROUP_KINDS", 1) && !lane_rows) {
     int32_t* oidx = nullptr;
     double* ovals = nullptr;
     HIPCK(hipMalloc((void**)&oidx, (size_t)h->nnz_r * 4));
@@ -459,7 +462,7 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
   }
   const bool row_rounds = rows && !h->row_split && (h->tile_rounds & 1) && !eval_only && a.fixed_alpha <= 0.0 && h->actlist;
   // lane-per-segment passes (glrm_lane.hpp): the ProxGradParams half-steps and the evaluation pass of the sides that run that family
-  const bool lane_here = h->lane[rows ? 0 : 1] && glrm_lane_loss_ok(loss) && a.fixed_alpha <= 0.0 && (rows ? row_rounds : true);
+  const bool lane_here = h->lane[rows ? 0 : 1] && glrm_lane_loss_ok(h, loss) && a.fixed_alpha <= 0.0 && (rows ? row_rounds : true);
   if (rows && !h->row_split && !row_rounds) {
     a.segperm = h->rng_e >= 0 ? nullptr : h->rowperm; // a sub-range sweep keeps the natural order
     return launch_tiled(h, loss, 0, a);

@@ -132,12 +132,22 @@ def test_heterogeneous_columns_on_the_lds_tiles(monkeypatch):
 
 
 def test_heterogeneous_columns_on_the_lane_per_segment_passes(monkeypatch):
-    """The same model with the default family choice: the column view (ONE loss descriptor per column) runs the lane-per-segment passes, the row
-    view (a descriptor per observation) stays on the four-lane kernels."""
-    monkeypatch.setenv("GLRM_HIP_GROUP_KINDS", "0")
+    """The same model with both views on the lane-per-segment passes -- the column view with ONE loss descriptor per column, the row view
+    (opt-in: GLRM_HIP_LANE_PER_OBS=1; measured slower than the four-lane kernels) with a descriptor per OBSERVATION: its
+    one-byte id rides in the SELL offset word, the descriptors sit in LDS behind the tile, and the row view keeps the caller's order (no kind
+    grouping: every lane evaluates its own observation's formula)."""
+    monkeypatch.setenv("GLRM_HIP_LANE_PER_OBS", "1")
     pa, X0, Y0 = problem(5000, 1500, 32, 300, (1, 0, 1.0), mixed=True)
     o = engine_and_oracle_in_its_order(pa, X0, Y0, 6, TILED_R | TILED_C, ("windowed", "windowed"), tiled=2)
-    assert (o[0].lanes, o[0].batch, o[0].rotate) == (4, 4, 0) and (o[1].lanes, o[1].comps, o[1].batch, o[1].rotate) == (2, 16, 2, 2)
+    assert [(x.lanes, x.comps, x.batch, x.rotate, x.private_order) for x in o] == [(2, 16, 2, 2, 0)] * 2
+
+
+def test_heterogeneous_rows_stay_on_the_four_lane_kernels_by_default():
+    """The default family choice for a model with a loss per column: the lane-per-segment passes on the column view, the four-lane kernels
+    (kind-grouped windows, private_order = 2) on the row view."""
+    pa, X0, Y0 = problem(5000, 1500, 32, 300, (1, 0, 1.0), mixed=True)
+    o = engine_and_oracle_in_its_order(pa, X0, Y0, 6, TILED_R | TILED_C, ("windowed", "windowed"), tiled=2)
+    assert (o[0].lanes, o[0].batch, o[0].rotate, o[0].private_order) == (4, 4, 0, 2) and (o[1].lanes, o[1].comps, o[1].batch, o[1].rotate) == (2, 16, 2, 2)
 
 
 def test_heterogeneous_columns_on_the_gather_sweeps():

@@ -64,12 +64,12 @@ def expected_orders(m, n, k, q, mixed=False):
         raise SystemExit("a heterogeneous recipe outside the LDS-tiled families: write the gather families' batch rules down here first")
     # lane-per-segment form of the LDS-tiled passes (csrc/glrm_lane.hip: glrm_setup_lane): padded rank 32, at most 2e9 observations in the view;
     # rows only when the model has ONE loss descriptor.  Reported as the two-lane layout with the rotated chunk walk (rotate = 2)
-    lane_r = tiled_r and kp == 32 and not mixed and nnz <= 2_000_000_000
+    lane_r = tiled_r and kp == 32 and not mixed and nnz <= 6_000_000_000   # (rows of a model with a loss per column: opt-in only, GLRM_HIP_LANE_PER_OBS)
     lane_c = tiled_c and kp == 32 and nnz <= 2_000_000_000
     if tiled_r:
         rows.update(family=2, window=T, windows_per_sup=0, batch=G if mixed else 2, private_order=2 if mixed else 0)
         if lane_r:
-            rows.update(lanes=2, comps=kp // 2, batch=2, rotate=2)
+            rows.update(lanes=2, comps=kp // 2, batch=2, rotate=2, private_order=0)
     else:
         rows.update(family=1)
         if n * kp * 8 > 32 * 2 ** 20 and nnz >= 1e8 and G in (4, 8) and R == 8:
