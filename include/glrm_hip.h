@@ -319,8 +319,9 @@ int glrm_hip_step_y(glrm_handle* h, double min_stepsize);                   /* o
  * range is already there, e.g. the shard's own rows) has fired.  The order of the array is the order in which the host expects the
  * blocks.  The phase-aligned column passes (csrc/glrm_blocked.hip) walk X one super-tile per launch and keep one partial sum per (column,
  * super-tile) that col_reduce adds in super-tile order whatever order the launches ran in: they launch each super-tile behind the events
- * of the blocks it touches, own rows first, so the exchange overlaps the half-step that consumes it.  Every other family waits for all
- * events and then runs glrm_hip_step_y.  Results are those of glrm_hip_step_y bit for bit.  With glrm_options.profile the time the
+ * of the blocks it touches, own rows first, so the exchange overlaps the half-step that consumes it.  The LDS-tiled column passes and their
+ * lane-per-segment form launch their gradient pass in runs of super-tiles, each behind the blocks it reads, in the announced order.  Every
+ * other family waits for all events and then runs glrm_hip_step_y.  Results are those of glrm_hip_step_y bit for bit.  With glrm_options.profile the time the
  * launch stream spent in those waits is accounted in glrm_kernel_stats.ms_wait_y (in true arrival order: plus the time the calling
  * thread polled while no super-tile was ready).
  * TRUE arrival order (default; GLRM_HIP_ARRIVAL_DYNAMIC=0 restores the announced order): a super-tile is enqueued once the events of all

@@ -211,6 +211,11 @@ int glrm_run_blocked(glrm_handle* h, bool rows, int loss, int loss_by_segment, d
 // glrm_hip_step_y_arrival (glrm_hip.hip): make h->stream wait for every block of h->arrival that intersects rows [lo, hi) of X and has
 // not been waited for yet
 int glrm_arrival_wait(glrm_handle* h, int64_t lo, int64_t hi);
+// LDS-tiled / lane column passes under glrm_hip_step_y_arrival (round 6): runs of super-tiles in the order their rows of X are announced --
+// launch(sup_lo, sup_hi) is called once per run, behind the in-stream waits for the blocks the run touches; without arrival blocks: one call
+// over all super-tiles.  Partial sums are per (column, super-tile) and are reduced in super-tile order: which run went first changes no bit.
+#include <functional>
+int glrm_for_sup_runs_in_arrival_order(glrm_handle* h, int nsup, int64_t rows_per_sup, const std::function<int(int, int)>& launch);
 
 // stable segmented sort of a view by tile index (glrm_tilesort.hip)
 int glrm_tile_sort_view(hipStream_t st, const int64_t* ptr, int64_t nseg, int64_t nnz, int tile, int64_t n_other, int32_t** idx, double** vals, bool free_old);

@@ -1266,6 +1266,30 @@ int glrm_arrival_wait(glrm_handle* h, int64_t lo, int64_t hi) {
   return GLRM_OK;
 }
 
+int glrm_for_sup_runs_in_arrival_order(glrm_handle* h, int nsup, int64_t rows_per_sup, const std::function<int(int, int)>& launch) {
+  if (!h->arrival || h->n_arrival <= 0 || nsup <= 1) return launch(0, nsup);
+  // need[s] = the LAST announced block super-tile s touches: the run of super-tiles that become complete with block b is launched behind b
+  std::vector<int> need((size_t)nsup, -1);
+  for (int s = 0; s < nsup; ++s) {
+    const int64_t lo = (int64_t)s * rows_per_sup, hi = std::min<int64_t>(lo + rows_per_sup, h->m);
+    for (int b = 0; b < h->n_arrival; ++b)
+      if (h->arrival[b].begin < hi && h->arrival[b].end > lo && h->arrival[b].begin < h->arrival[b].end) need[s] = b;
+  }
+  for (int b = -1; b < h->n_arrival; ++b) { // (-1: super-tiles no block touches -- beyond m -- first)
+    for (int s = 0; s < nsup;) {
+      if (need[s] != b) { ++s; continue; }
+      int e = s + 1;
+      while (e < nsup && need[e] == b) ++e;
+      const int64_t lo = (int64_t)s * rows_per_sup, hi = std::min<int64_t>((int64_t)e * rows_per_sup, h->m);
+      int rc = glrm_arrival_wait(h, lo, hi);
+      if (!rc) rc = launch(s, e);
+      if (rc) return rc;
+      s = e;
+    }
+  }
+  return GLRM_OK;
+}
+
 extern "C" int glrm_hip_step_y_arrival(glrm_handle* h, double min_stepsize, const glrm_arrival* blocks, int32_t n_blocks) {
   if (!h) return fail(GLRM_ERR_INVALID, "NULL handle");
   if (n_blocks < 0 || (n_blocks > 0 && !blocks)) return fail(GLRM_ERR_INVALID, "bad block list");
@@ -1290,8 +1314,9 @@ extern "C" int glrm_hip_step_y_arrival(glrm_handle* h, double min_stepsize, cons
   h->n_arrival = n_blocks;
   h->arrival_waited.assign((size_t)n_blocks, 0);
   int rc = GLRM_OK;
-  // only the phase-aligned column passes can start on a part of X; everything else needs all of it
-  const bool by_super_tile = h->blocked_col && !h->lockstep && !h->multi && !h->dense && !h->tiled_col && !h->sum_order_opt && env_int("GLRM_HIP_ARRIVAL", 1);
+  // the pass families of the column view can start on a part of X (the phase-aligned passes super-tile by super-tile in true arrival order,
+  // the LDS-tiled / lane passes in runs of super-tiles in the announced order: round 6); everything else needs all of it
+  const bool by_super_tile = ((h->blocked_col && !h->lockstep && !h->tiled_col) || h->tiled_col) && !h->multi && !h->dense && !h->sum_order_opt && env_int("GLRM_HIP_ARRIVAL", 1);
   if (!by_super_tile) rc = glrm_arrival_wait(h, 0, h->m);
   if (!rc) rc = run_sweep(h, 1, min_stepsize, 0);
   if (!rc) rc = glrm_arrival_wait(h, 0, h->m); // (a shard without columns launches nothing: later work on the stream still follows the arrivals)

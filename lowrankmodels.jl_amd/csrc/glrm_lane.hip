@@ -32,7 +32,7 @@ int launch_lane_inst(const TiledArgs& a, const LaneArgs& la, int64_t nblocks, hi
   HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); // (per device: a process may drive several)
   const unsigned gx = (unsigned)((nblocks + LANE_NW - 1) / LANE_NW);
   if (gx == 0) return GLRM_OK;
-  hipLaunchKernelGGL(k, dim3(gx, (unsigned)a.nsup), dim3(LANE_NW * 64), LDSB, st, a, la);
+  hipLaunchKernelGGL(k, dim3(gx, (unsigned)(a.nsup_launch > 0 ? a.nsup_launch : a.nsup)), dim3(LANE_NW * 64), LDSB, st, a, la);
   return GLRM_OK;
 }
 
@@ -186,12 +186,16 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
     c.slot0 = 0;
     return c;
   };
-  if (sell_ok) rc = launch_lane_loss<true, false>(loss, a, la, blk_hi - blk_lo, st);
-  else {
-    TiledArgs t = a;
-    t.npass = 0;
-    rc = launch_lane_loss<true, true>(loss, t, csr_args(t), (t.nseg + 63) / 64, st);
-  }
+  // gradient pass: under glrm_hip_step_y_arrival (columns) in runs of super-tiles, each behind the blocks of X it reads (announced order)
+  auto grad = [&](int s0, int s1) {
+    TiledArgs r = a;
+    r.sup0 = s0;
+    r.nsup_launch = s1 - s0;
+    if (sell_ok) return launch_lane_loss<true, false>(loss, r, la, blk_hi - blk_lo, st);
+    r.npass = 0;
+    return launch_lane_loss<true, true>(loss, r, csr_args(r), (r.nseg + 63) / 64, st);
+  };
+  rc = rows ? grad(0, a.nsup) : glrm_for_sup_runs_in_arrival_order(h, a.nsup, (int64_t)a.tiles_per_sup * lane_tile_rows(h->kp), grad); // (rows read Y: complete)
   if (rc) return rc;
   launch_small(0, a, st);
   HIPCK(hipGetLastError());

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
   const int64_t slot = wb * 64 + lane;
   const int64_t rel = CSR ? slot : slot - la.slot0;                                 // slot relative to TiledArgs' segment 0
   const int64_t nslots = CSR ? a.nseg : (a.npass > 0 ? a.npass : a.nseg);
-  const int sup = (int)blockIdx.y;
+  const int sup = a.sup0 + (int)blockIdx.y;
   bool have = rel >= 0 && rel < nslots;
   const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[rel] : (have ? rel : 0);
   if (!GRAD && have) have = a.active[seg] != 0;

@@ -346,13 +346,13 @@ static int launch_tiled_inst(int kind, const TiledArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((tiled_sweep_kernel<G, R, NW, TILE, LOSS, false, LW, true>), dim3(gx), dim3(NW * 64), lds, st, a);
   } else if (kind == 4) {
     if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false, false, LW, true>, lds))) return rc;
-    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false, false, LW, true>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false, false, LW, true>), dim3(gx, (unsigned)(a.nsup_launch > 0 ? a.nsup_launch : a.nsup)), dim3(NW * 64), lds, st, a);
   } else if (kind == 1) {
     if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true, false, LW>, lds))) return rc;
-    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true, false, LW>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, true, false, LW>), dim3(gx, (unsigned)(a.nsup_launch > 0 ? a.nsup_launch : a.nsup)), dim3(NW * 64), lds, st, a);
   } else {
     if ((rc = set_lds(tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false, false, LW>, lds))) return rc;
-    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false, false, LW>), dim3(gx, (unsigned)a.nsup), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((tiled_col_pass_kernel<G, R, NW, TILE, LOSS, false, false, LW>), dim3(gx, (unsigned)(a.nsup_launch > 0 ? a.nsup_launch : a.nsup)), dim3(NW * 64), lds, st, a);
   }
   return GLRM_OK;
 }
@@ -499,7 +499,16 @@ int glrm_run_tiled(glrm_handle* h, bool rows, int loss, int loss_by_segment, dou
   if (row_rounds) {
     if ((rc = launch_tiled(h, loss, 3, a))) return rc; // gradient pass + first trial; rejected rows are listed
   } else {
-    if ((rc = launch_tiled(h, loss, 1, a))) return rc;
+    // gradient pass: under glrm_hip_step_y_arrival in runs of super-tiles, each behind the blocks of X it reads (announced order)
+    const int T_ = tile_rows(h->kp, h->tile_cfg);
+    if (rows) rc = launch_tiled(h, loss, 1, a); // (the row view reads Y, which is complete)
+    else rc = glrm_for_sup_runs_in_arrival_order(h, a.nsup, (int64_t)a.tiles_per_sup * T_, [&](int s0, int s1) {
+      TiledArgs r = a;
+      r.sup0 = s0;
+      r.nsup_launch = s1 - s0;
+      return launch_tiled(h, loss, 1, r);
+    });
+    if (rc) return rc;
     launch_col_small_any(h, 0, a);
   }
   HIPCK(hipGetLastError());

@@ -67,6 +67,8 @@ struct TiledArgs {
   // of super-tile sup_fixed
   int64_t seg_begin, nseg_slice;
   int sup_fixed;
+  int nsup_launch;       // > 0: super-tiles this launch covers (grid y); 0 = all nsup
+  int sup0;              // LDS-tiled / lane column passes: the launch covers super-tiles sup0 .. sup0 + gridDim.y - 1 (arrival order, round 6)
   const int32_t* segperm; // lane-group slot -> local segment (nullptr = identity).  Which segment a group works on changes no sum:
                           // columns are handed out sorted by (loss kind, length), rows by length, so that the 16 groups of a wave
                           // evaluate the same loss formula and finish their lists together.
@@ -786,7 +788,7 @@ __global__ void __launch_bounds__(NW * 64, L2 ? 1 : 4) tiled_col_pass_kernel(con
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane % G, gi = lane / G;
   const int64_t slot = (L2 ? a.seg_begin : 0) + (int64_t)blockIdx.x * SPB + (wave - LW) * NGW + gi;
-  const int sup = L2 ? a.sup_fixed : (int)blockIdx.y;
+  const int sup = L2 ? a.sup_fixed : a.sup0 + (int)blockIdx.y;
   bool have = wave >= LW && slot < (L2 ? a.seg_begin + a.nseg_slice : (a.npass > 0 ? a.npass : a.nseg));
   const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[slot] : slot; // which column a group works on does not change any sum
   if (!GRAD && have) have = a.active[seg] != 0;

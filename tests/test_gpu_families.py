@@ -505,29 +505,58 @@ def test_arrival_order_y_half_step_gives_the_bits_of_step_y(monkeypatch, dynamic
         assert st1["ms_wait_y"] > 0.0      # the launch stream did stand in front of late blocks (most of the pauses hide behind the super-tiles already there)
 
 
-def test_arrival_order_on_a_family_that_needs_all_of_x_waits_for_everything(monkeypatch):
-    """Every family but the phase-aligned column passes walks X in one kernel: step_y_arrival then waits for all events and runs step_y."""
+@pytest.mark.parametrize("family", ["gather", "tiled-four-lane", "tiled-lane"])
+def test_arrival_order_on_the_other_column_families(monkeypatch, family):
+    """Beyond the phase-aligned passes.  The gather sweep walks X in one kernel: step_y_arrival waits for all events and runs step_y.  The
+    LDS-tiled column passes and their lane-per-segment form (round 6) launch their gradient pass in RUNS of super-tiles,
+    each behind the in-stream waits for the blocks of X it reads, in the order the host announces them; partial sums are per (column,
+    super-tile) and col_reduce adds them in super-tile order, so the bits are glrm_hip_step_y's whatever the order -- with events that fire late
+    (a side stream that sleeps in front of each record), in two announced orders, over three iterations."""
     import torch
-    pa, X0, Y0, _, _ = c4_problem(3000, 300, 100)
+    k = 64 if family == "gather" else 32
+    if family == "tiled-four-lane":
+        monkeypatch.setenv("GLRM_HIP_LANE", "0")
+    monkeypatch.setenv("GLRM_HIP_COL_WORKGROUPS", "4096")   # many super-tiles on this small problem
+    m, n = 6000, 600
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, 100, value_model=0)
+    one = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 0.5)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, one, reg, reg)
     api = hip()
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
     res = {}
     for arrival in (False, True):
-        h = api.create(pa, stream=torch.cuda.current_stream().cuda_stream, tiled=1)
+        h = api.create(pa, stream=torch.cuda.current_stream().cuda_stream, tiled=1 if family == "gather" else 2, profile=1)
         try:
-            assert not api.kernel_stats(h)["tiled"] & BLOCKED_COLS
+            flags = api.kernel_stats(h)["tiled"]
+            assert not flags & BLOCKED_COLS and bool(flags & 2) == (family != "gather") and bool(flags & 512) == (family == "tiled-lane")
             api.set_factors(h, X0, Y0)
             api.reset_stepsizes(h, 1.0)
-            for _ in range(2):
+            for it in range(3):
                 api.step_x(h, 0.01)
                 if arrival:
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    api.step_y_arrival(h, 0.01, [(2000, 3000, ev.cuda_event), (0, 2000, None)])
+                    chunks = [(lo, lo + 750) for lo in (0, 3000, 750, 3750, 4500, 5250)]
+                    blocks, keep = [(1500, 3000, None)], []
+                    with torch.cuda.stream(side):
+                        side.wait_stream(torch.cuda.current_stream())
+                        for lo, hi in chunks:
+                            torch.cuda._sleep(400_000)
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                            keep.append(ev)
+                            blocks.append((lo, hi, ev.cuda_event))
+                    if it == 1:
+                        blocks = blocks[::-1]
+                    api.step_y_arrival(h, 0.01, blocks)
                 else:
                     api.step_y(h, 0.01)
             X, Y = np.zeros_like(X0), np.zeros_like(Y0)
             api.get_factors(h, X, Y)
-            res[arrival] = (X, Y)
+            res[arrival] = (X, Y, api.kernel_stats(h))
         finally:
             api.destroy(h)
     assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+    for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
+        assert res[True][2][key] == res[False][2][key]
+    assert res[False][2]["ms_wait_y"] == 0.0 and res[True][2]["ms_wait_y"] > 0.0   # the launch stream did stand in front of late blocks
