@@ -47,7 +47,7 @@ struct glrm_handle {
   bool own_stream = false;
   int64_t m = 0, n = 0;
   int k = 0, kp = 0, G = 4, R = 2;
-  int unroll_row = 1, unroll_col = 1;
+  int unroll_row = 1, unroll_col = 1, unroll_long = 8;
   // LDS-tiled sweeps (glrm_tiled.hpp)
   bool rows_sorted = false, cols_sorted = false;
   double fixed_alpha = 0.0;           // > 0 while a SparseProxGradParams step (no line search) is being launched
@@ -82,6 +82,10 @@ struct glrm_handle {
   double* lane_val[2] = {nullptr, nullptr};
   int64_t lane_nwb[2] = {0, 0}, lane_steps[2] = {0, 0};
   int lane_ntiles[2] = {0, 0};
+  int32_t* lane_inv[2] = {nullptr, nullptr};   // local segment -> slot of the layout (sides whose slots are permuted); -1 = not in the layout
+  // trial rounds read out of the SELL layout (lane_pass_kernel FORM 2): the still-searching segments class by class, rebuilt every round
+  int32_t *lane_gcnt = nullptr, *lane_gbase = nullptr, *lane_gtotal = nullptr, *lane_glist = nullptr;
+  int64_t lane_gcap = 0, lane_gchunks = 0;
   // general sweeps: multi-dimensional losses / wrapped regularizers (glrm_multi.hip)
   bool multi = false;
   int64_t d = 0;                      // vectors of Y = sum of embedding dimensions (= n for scalar losses)

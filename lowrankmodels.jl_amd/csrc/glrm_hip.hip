@@ -586,7 +586,8 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
                   h->jold_r, h->active_r, h->ntrial_r, h->ystart, h->mtrial, h->mpart_loss, h->mpart_G, h->mgtot,
                   h->mobjold, h->mactive, h->mnactive, h->colperm, h->rowperm, h->seglist_r, h->seglist_c, h->rowdescid, h->udesc,
                   h->gramH, h->gram_part, h->jloss_r, h->jloss_c, h->lock_ctr, h->actlist, h->blk_perm_c, h->blk_long_c,
-                  h->lane_bptr[0], h->lane_bptr[1], h->lane_off[0], h->lane_off[1], h->lane_val[0], h->lane_val[1]};
+                  h->lane_bptr[0], h->lane_bptr[1], h->lane_off[0], h->lane_off[1], h->lane_val[0], h->lane_val[1],
+                  h->lane_inv[0], h->lane_inv[1], h->lane_gcnt, h->lane_gbase, h->lane_gtotal, h->lane_glist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->iter_exec) (void)hipGraphExecDestroy(h->iter_exec);
@@ -683,6 +684,7 @@ static int create_impl(glrm_handle* h, const glrm_problem* p, const glrm_options
   h->kp = h->G * h->R;
   h->unroll_row = env_int("GLRM_HIP_UNROLL_ROW", 2) == 2 ? 2 : 1; // 2 observations per group in flight: -20 % on the L2-latency-bound row sweep
   h->unroll_col = env_int("GLRM_HIP_UNROLL_COL", 1) == 2 ? 2 : 1;
+  h->unroll_long = env_int("GLRM_HIP_UNROLL_LONG", 8) >= 8 ? 8 : 1; // 8-wave segments: observations per lane group in flight (launch_sweep_loss)
   h->profile = o ? o->profile : 0;
   h->tiled_opt = o ? o->tiled : 0;
   h->sum_order_opt = o ? o->sum_order : 0;
@@ -1000,6 +1002,22 @@ static void launch_sweep_loss(int loss, int unroll, const SweepArgs& a, hipStrea
     if (a.eval_only) hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSSV, 1, true>), dim3(grid), block, 0, st, a); \
     else hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSSV, UV, false>), dim3(grid), block, 0, st, a);          \
   } while (0)
+  if constexpr (WAVES == 8) {
+    // One 8-wave workgroup per very long segment (the diverted columns of a power-law view: 880 000 observations at the C2-Zipf recipe) is
+    // bound by the latency of its factor gathers: with one observation per lane group in flight the longest column alone took 13.7 ms of a
+    // 15.7 ms Y half-step (profiles/r06_c2_zipf_kernel_stats.csv).  Eight per group in flight (a group still adds its observations
+    // t == gg (mod TG) in ascending order: the bits do not depend on U) -- session r6_26.
+    if (unroll >= 8 && !a.eval_only) {
+      switch (loss) {
+        case LOSS_QUAD_UNIFORM: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_QUAD_UNIFORM, 8, false>), dim3(grid), block, 0, st, a); break;
+        case LOSS_SEGMENT: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_SEGMENT, 8, false>), dim3(grid), block, 0, st, a); break;
+        case LOSS_SEGMENT_NOTRIG: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_SEGMENT_NOTRIG, 8, false>), dim3(grid), block, 0, st, a); break;
+        case LOSS_PER_OBS_NOTRIG: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_PER_OBS_NOTRIG, 8, false>), dim3(grid), block, 0, st, a); break;
+        default: hipLaunchKernelGGL((sweep_kernel<G, R, WAVES, LOSS_PER_OBS, 8, false>), dim3(grid), block, 0, st, a); break;
+      }
+      return;
+    }
+  }
   switch (loss) {
     case LOSS_QUAD_UNIFORM:
       if (unroll == 2) GLRM_LAUNCH(LOSS_QUAD_UNIFORM, 2);
@@ -1151,7 +1169,7 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
       SweepArgs b = a;
       b.seglist = h->blk_long_c;
       b.nseg = h->blk_nlong_c;
-      launch_sweep(h->G, h->R, 8, loss, 1, b, h->side_stream);
+      launch_sweep(h->G, h->R, 8, loss, h->unroll_long, b, h->side_stream);
     }
     rc = tiled ? glrm_run_tiled(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only)
                : glrm_run_blocked(h, rows, loss, a.loss_by_segment, min_stepsize, eval_only);
@@ -1174,7 +1192,7 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
       if (cls == 0 && !eval_only) {
         if ((rc = glrm_run_cached(h, loss, min_stepsize, nullptr, 0, h->stream))) return rc;
       } else {
-        launch_sweep(h->G, h->R, cls == 0 ? 1 : glrm_class_waves(cls), loss, cls <= 1 ? unroll : 1, a, h->stream);
+        launch_sweep(h->G, h->R, cls == 0 ? 1 : glrm_class_waves(cls), loss, cls <= 1 ? unroll : (glrm_class_waves(cls) == 8 ? h->unroll_long : 1), a, h->stream);
       }
     } else {
       // fork: the minority classes on the side stream, beside the majority class on the main stream; join
@@ -1193,7 +1211,7 @@ static int run_sweep(glrm_handle* h, int which, double min_stepsize, int eval_on
           SweepArgs b = a;
           b.seglist = lst + off;
           b.nseg = ncls[c];
-          launch_sweep(h->G, h->R, c == 0 ? 1 : glrm_class_waves(c), loss, c <= 1 ? unroll : 1, b, st);
+          launch_sweep(h->G, h->R, c == 0 ? 1 : glrm_class_waves(c), loss, c <= 1 ? unroll : (glrm_class_waves(c) == 8 ? h->unroll_long : 1), b, st);
         }
       }
       if (rc_cls) { // join before reporting: later work on h->stream (and a stream capture) must stay ordered after what the side stream already holds

@@ -24,11 +24,11 @@ namespace {
 constexpr int LANE_NW = 8; // 8 waves x 64 segments per workgroup, 256 VGPRs per lane
 constexpr int lane_tile_rows(int kp) { return ((150 * 1024) / (kp * 8 + 16)) / 16 * 16; } // = tile_rows_c(kp, 1): the order unit of the lists
 
-template <int LOSS, bool GRAD, bool CSR>
+template <int LOSS, bool GRAD, int FORM>
 int launch_lane_inst(const TiledArgs& a, const LaneArgs& la, int64_t nblocks, hipStream_t st) {
   constexpr int KP = 32, T = lane_tile_rows(KP);
   const int LDSB = T * KP * 8 + (loss_mode(LOSS) == 2 ? a.n_udesc * 32 : 0);
-  auto k = lane_pass_kernel<KP, LANE_NW, T, LOSS, GRAD, CSR>;
+  auto k = lane_pass_kernel<KP, LANE_NW, T, LOSS, GRAD, FORM>;
   HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); // (per device: a process may drive several)
   const unsigned gx = (unsigned)((nblocks + LANE_NW - 1) / LANE_NW);
   if (gx == 0) return GLRM_OK;
@@ -36,14 +36,14 @@ int launch_lane_inst(const TiledArgs& a, const LaneArgs& la, int64_t nblocks, hi
   return GLRM_OK;
 }
 
-template <bool GRAD, bool CSR>
+template <bool GRAD, int FORM>
 int launch_lane_loss(int loss, const TiledArgs& a, const LaneArgs& la, int64_t nblocks, hipStream_t st) {
   switch (loss) {
-    case LOSS_QUAD_UNIFORM: return launch_lane_inst<0, GRAD, CSR>(a, la, nblocks, st);
-    case LOSS_SEGMENT: return launch_lane_inst<1, GRAD, CSR>(a, la, nblocks, st);
-    case LOSS_SEGMENT_NOTRIG: return launch_lane_inst<3, GRAD, CSR>(a, la, nblocks, st);
-    case LOSS_PER_OBS: return launch_lane_inst<2, GRAD, CSR>(a, la, nblocks, st);
-    case LOSS_PER_OBS_NOTRIG: return launch_lane_inst<4, GRAD, CSR>(a, la, nblocks, st);
+    case LOSS_QUAD_UNIFORM: return launch_lane_inst<0, GRAD, FORM>(a, la, nblocks, st);
+    case LOSS_SEGMENT: return launch_lane_inst<1, GRAD, FORM>(a, la, nblocks, st);
+    case LOSS_SEGMENT_NOTRIG: return launch_lane_inst<3, GRAD, FORM>(a, la, nblocks, st);
+    case LOSS_PER_OBS: return launch_lane_inst<2, GRAD, FORM>(a, la, nblocks, st);
+    case LOSS_PER_OBS_NOTRIG: return launch_lane_inst<4, GRAD, FORM>(a, la, nblocks, st);
     default: return fail(GLRM_ERR_UNSUPPORTED, "lane-per-segment passes: no kernel for loss variant %d", loss);
   }
 }
@@ -98,6 +98,7 @@ bool glrm_lane_wants(const glrm_handle* h, bool rows) {
 // finalize, after glrm_setup_tiled has chosen the LDS tiles and built the slot permutations: decide the family per side and build its SELL layout
 int glrm_setup_lane(glrm_handle* h) {
   h->lane[0] = h->lane[1] = 0;
+  int64_t gseg_max = 0;
   const int T = lane_tile_rows(h->kp);
   hipStream_t st = h->stream;
   for (int side = 0; side < 2; ++side) {
@@ -146,10 +147,25 @@ int glrm_setup_lane(glrm_handle* h) {
                        h->kp * 8, h->lane_bptr[side], h->lane_off[side], h->lane_val[side]);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "lane layout: build failed"));
     cleanup(0);
+    if (perm) { // FORM 2 of the rounds finds a segment's slot through the inverse of the slot permutation
+      HIPCK(hipMalloc((void**)&h->lane_inv[side], (size_t)nseg * 4));
+      HIPCK(hipMemsetAsync(h->lane_inv[side], 0xFF, (size_t)nseg * 4, st));
+      hipLaunchKernelGGL(lane_inv_kernel, dim3((unsigned)((nslots + 255) / 256)), dim3(256), 0, st, perm, nslots, h->lane_inv[side]);
+      HIPCK(hipGetLastError());
+    }
+    if (nseg > gseg_max) gseg_max = nseg;
     if (env_int("GLRM_HIP_LANE_TRACE", 0))
       fprintf(stderr, "[glrm lane] %s view: %lld slots in %lld wave blocks x %d tiles, %lld steps of 64 = %.3f x the %lld observations\n", rows ? "row" : "column",
               (long long)nslots, (long long)nwb, ntiles, (long long)steps, (double)steps * 64.0 / (double)std::max<int64_t>(1, rows ? h->nnz_r : h->nnz_c),
               (long long)(rows ? h->nnz_r : h->nnz_c));
+  }
+  if (gseg_max > 0 && !h->lane_glist) { // the wave lists of the rounds (one set serves both sides: a half-step at a time)
+    h->lane_gchunks = (gseg_max + LANE_CC - 1) / LANE_CC;
+    h->lane_gcap = h->lane_gchunks * 16; // waves: a chunk holds at most 64 segments of a class
+    HIPCK(hipMalloc((void**)&h->lane_gcnt, (size_t)h->lane_gchunks * 4));
+    HIPCK(hipMalloc((void**)&h->lane_gbase, (size_t)h->lane_gchunks * 4));
+    HIPCK(hipMalloc((void**)&h->lane_gtotal, 4));
+    HIPCK(hipMalloc((void**)&h->lane_glist, (size_t)h->lane_gcap * 64 * 4));
   }
   return GLRM_OK;
 }
@@ -167,6 +183,9 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
   la.ntiles = h->lane_ntiles[side];
   la.nwb = h->lane_nwb[side];
   la.slot0 = 0;
+  la.inv = h->lane_inv[side];
+  la.glist = h->lane_glist;
+  la.gwaves = 0;
   (void)min_stepsize;
   // does the SELL layout cover this launch?  It was built on the side's full slot space (slot permutation included); a row sub-range
   // (glrm_hip_step_x_range) is covered when the slots are the rows themselves: its wave blocks run with the lanes outside the range masked
@@ -191,9 +210,9 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
     TiledArgs r = a;
     r.sup0 = s0;
     r.nsup_launch = s1 - s0;
-    if (sell_ok) return launch_lane_loss<true, false>(loss, r, la, blk_hi - blk_lo, st);
+    if (sell_ok) return launch_lane_loss<true, 0>(loss, r, la, blk_hi - blk_lo, st);
     r.npass = 0;
-    return launch_lane_loss<true, true>(loss, r, csr_args(r), (r.nseg + 63) / 64, st);
+    return launch_lane_loss<true, 1>(loss, r, csr_args(r), (r.nseg + 63) / 64, st);
   };
   rc = rows ? grad(0, a.nsup) : glrm_for_sup_runs_in_arrival_order(h, a.nsup, (int64_t)a.tiles_per_sup * lane_tile_rows(h->kp), grad); // (rows read Y: complete)
   if (rc) return rc;
@@ -201,36 +220,90 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
   HIPCK(hipGetLastError());
   if (eval_only) return GLRM_OK;
   const TiledArgs full = a;
+  const bool gather = env_int("GLRM_HIP_LANE_ROUNDS", 1) != 0 && sell_ok && h->lane_glist && la.bptr && h->lane_steps[side] > 0 &&
+                      full.nseg <= h->lane_gchunks * (int64_t)LANE_CC;
   constexpr int MAX_ROUNDS = 4096; // see glrm_run_tiled
   for (int round = 0;; ++round) {
     if (round == MAX_ROUNDS) return fail(GLRM_ERR_INVALID, "line search still running after %d rounds (min_stepsize %g)", MAX_ROUNDS, min_stepsize);
     unsigned int nact = 0;
+    TiledArgs t = full;
+    TiledArgs d = full;
     HIPCK(hipMemcpyAsync(&nact, h->nactive, 4, hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
     if (nact == 0) break;
     HIPCK(hipMemsetAsync(h->nactive, 0, 4, st));
-    TiledArgs t = full;
-    // while many segments still search the pass walks the SELL layout over the full grid (idle segments masked: the cost of a whole pass,
-    // whatever the fraction); the few that are left afterwards run the CSR form over the compact list, which costs 5-8 x as much per
-    // observation (one lane walks its own list: uncoalesced) -- measured cross-over at about a sixth of the segments (session r6_20)
+    const int trace = env_int("GLRM_HIP_LANE_TRACE", 0);
+    // Three forms of the trial pass, all adding the same terms in the same order.  FORM 0 walks the SELL layout over the full grid (idle
+    // segments masked): the cost of a whole pass whatever the fraction that searches.  The CSR form over the compact list costs 5-8 x as much
+    // per observation (one lane walks its own list, nothing in flight), but only for the segments listed.  FORM 2 (session r6_25) lists the
+    // searching segments class by class and reads their steps out of the SELL layout: the work of the fraction that searches, ahead of its
+    // use -- but a wave's lanes then sit in 1 / fraction different wave blocks of the layout, each 4-byte read its own 64-byte line.
+    // Measured on the C5 recipe at 1M rows (profiles/r06_c5family_lane_rounds_trace.txt): rows -- 98 % searching: 11.9-13.2 ms against 9.85
+    // of FORM 0; 1 %: 3.0 ms against ~0.7 of the CSR form; columns (slots permuted by kind and length: a wave's segments are scattered
+    // over the layout) -- 51 %: 24.6 ms against 10.7.  So FORM 2 serves the middle fractions of sides whose slots are the segments in order.
+    const int64_t pct = (int64_t)nact * 100 / (full.nseg > 0 ? full.nseg : 1);
+    const bool use_gather = gather && !la.inv && pct >= env_int("GLRM_HIP_LANE_GATHER_FROM", 0) && pct < env_int("GLRM_HIP_LANE_GATHER_TO", 70);
+    if (use_gather) {
+      const int off16 = (int)(full.own_offset & 15);
+      // few segments left (a wave's lanes sit in different wave blocks of the layout anyway): waves packed from the previous decide kernel's
+      // compact list; otherwise chunk by chunk, so that a wave's segments are neighbours in the layout
+      bool packed = lists && (int64_t)nact * 100 < full.nseg * env_int("GLRM_HIP_LANE_GATHER_PACKED", 4);
+      int32_t tot[2] = {0, 0};
+      if (packed) {
+        const int spread = env_int("GLRM_HIP_LANE_GATHER_SPREAD", 32768); // searching segments per step of q: ~2 048 waves before a wave takes more per class
+        int q = (int)(((int64_t)nact + spread - 1) / spread);
+        q = q < 1 ? 1 : (q > 4 ? 4 : q);
+        hipLaunchKernelGGL(lane_compact_list_kernel, dim3(1), dim3(1024), 0, st, list[cur], (int)nact, off16, q, (int)h->lane_gcap, h->lane_glist, h->lane_gtotal);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(tot, h->lane_gtotal, 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+        if (tot[0] < 0) packed = false; // (one class holds nearly every entry: the waves would not fit the list)
+      }
+      if (!packed) {
+        const int64_t nchunks = (full.nseg + LANE_CC - 1) / LANE_CC;
+        const unsigned cg = (unsigned)((nchunks + 3) / 4);
+        hipLaunchKernelGGL(lane_compact_count_kernel, dim3(cg), dim3(256), 0, st, full.active, full.nseg, nchunks, h->lane_gcnt);
+        hipLaunchKernelGGL(lane_compact_scan_kernel, dim3(1), dim3(1024), 0, st, h->lane_gcnt, nchunks, h->lane_gbase, h->lane_gtotal);
+        hipLaunchKernelGGL(lane_compact_fill_kernel, dim3(cg), dim3(256), 0, st, full.active, full.nseg, nchunks, off16, h->lane_gbase, h->lane_glist);
+        HIPCK(hipGetLastError());
+        HIPCK(hipMemcpyAsync(tot, h->lane_gtotal, 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipStreamSynchronize(st));
+      }
+      tot[1] = tot[0];
+      la.gwaves = tot[0];
+      if (trace >= 2) fprintf(stderr, "[glrm lane] %s round %d: %u of %lld segments search: SELL gathered%s, %d waves\n", rows ? "row" : "column", round, nact, (long long)full.nseg, packed ? " (packed)" : "", tot[1]);
+      t.npass = 0;
+      rc = launch_lane_loss<false, 2>(loss, t, la, (int64_t)tot[1], st);
+      if (rc) return rc;
+      if (lists) {
+        d.actlist_in = list[cur];
+        d.actlist_out = list[cur ^ 1];
+        d.nact_in = nact;
+        cur ^= 1;
+      }
+      launch_small(1, d, st);
+      HIPCK(hipGetLastError());
+      continue;
+    }
+    // (measured cross-over of the two older forms at about a sixth of the segments, session r6_20)
     const bool compact = lists && ((int64_t)nact * 6 < full.nseg || !sell_ok);
+    if (trace >= 2) fprintf(stderr, "[glrm lane] %s round %d: %u of %lld segments search: %s\n", rows ? "row" : "column", round, nact, (long long)full.nseg, compact ? "CSR" : "SELL full grid");
     if (compact) {
       t.segperm = list[cur];
       t.nseg = nact;
       t.npass = 0;
-      rc = launch_lane_loss<false, true>(loss, t, csr_args(t), ((int64_t)nact + 63) / 64, st);
+      rc = launch_lane_loss<false, 1>(loss, t, csr_args(t), ((int64_t)nact + 63) / 64, st);
     } else if (sell_ok) {
-      rc = launch_lane_loss<false, false>(loss, t, la, blk_hi - blk_lo, st);
+      rc = launch_lane_loss<false, 0>(loss, t, la, blk_hi - blk_lo, st);
     } else {
       t.npass = 0;
-      rc = launch_lane_loss<false, true>(loss, t, csr_args(t), (t.nseg + 63) / 64, st);
+      rc = launch_lane_loss<false, 1>(loss, t, csr_args(t), (t.nseg + 63) / 64, st);
     }
     if (rc) return rc;
-    TiledArgs d = full;
     if (lists) {
       d.actlist_in = list[cur];
-      d.nact_in = nact;
       d.actlist_out = list[cur ^ 1];
+      d.nact_in = nact;
       cur ^= 1;
     }
     launch_small(1, d, st);

@@ -49,6 +49,10 @@ struct LaneArgs {
   int ntiles;          // tiles of the opposing factor (stride of bptr minus one)
   int64_t nwb;         // wave blocks the layout holds (a launch rounds its grid up to whole workgroups: blocks beyond have no steps)
   int64_t slot0;       // local id of TiledArgs' segment 0 in the slot space the layout was built on (row sub-ranges: glrm_hip_step_x_range)
+  // FORM 2 (trial rounds over the still-searching segments, read out of the SELL layout): the segments class by class (lane_compact_* below)
+  const int32_t* inv;    // local segment -> slot of the layout (nullptr: slot = segment + slot0)
+  const int32_t* glist;  // [gwaves][64]: the local segment of every lane of the round (-1: idle), lane_compact_fill_kernel
+  int64_t gwaves;
 };
 
 __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
@@ -57,23 +61,45 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 }
 
 // GRAD: pass 1 (gradient + loss partials at a.own); else a trial pass (loss partials at a.trial for the still-searching segments).
-// CSR: the (index, value) pairs come from the segment's own list (one lane walks it: uncoalesced) instead of the SELL layout -- the compact
-// trial rounds over the few segments still searching and sub-range sweeps the layout does not cover; the same sums in the same order.
-template <int KP, int NW, int TILE, int LOSS, bool GRAD, bool CSR>
+// FORM 0: the SELL layout over the full grid of slots (idle segments masked).
+// FORM 1 ("CSR"): the (index, value) pairs come from the segment's own list (one lane walks it: uncoalesced, nothing in flight ahead of its
+// use) -- sub-range sweeps the layout does not cover; the fallback of the trial rounds.
+// FORM 2 (session r6_25): the trial rounds over the segments STILL SEARCHING, read out of the SELL layout.  A wave takes 64 of them --
+// lane l one of class (global id) & 15 == l & 15, so the rotated chunk walk stays bank-conflict free -- and every lane walks the steps of its
+// OWN (wave block, tile) at its own slot of the layout: the segments of a wave come from neighbouring wave blocks (the class lists are in
+// ascending order), so its loads still share lines (about 12 / fraction-still-searching lines per step against 128 of the CSR form) and
+// run U steps ahead like FORM 0's.  All three forms add the same terms in the same order.
+template <int KP, int NW, int TILE, int LOSS, bool GRAD, int FORM>
 __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a, const LaneArgs la) {
+  constexpr bool CSR = FORM == 1;
+  static_assert(FORM == 0 || FORM == 1 || (FORM == 2 && !GRAD), "the gathered form runs trial rounds only");
   static_assert(KP == 32, "one lane per segment: x, g and y of a segment in one lane's registers -- built for a padded rank of 32");
   constexpr int C = KP / 2;            // 16-byte chunks per vector
   constexpr int U = GRAD ? 2 : 4;      // steps in flight ahead of their use (even: a step's position parity inside its window is u & 1)
   constexpr int PSTRIDE = KP + 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t wb = (CSR ? 0 : la.slot0 / 64) + (int64_t)blockIdx.x * NW + wave; // wave block in the layout's slot space
+  const int64_t wb = (FORM != 0 ? 0 : la.slot0 / 64) + (int64_t)blockIdx.x * NW + wave; // wave block in the layout's slot space (FORM 2: wave of the round)
   const int64_t slot = wb * 64 + lane;
-  const int64_t rel = CSR ? slot : slot - la.slot0;                                 // slot relative to TiledArgs' segment 0
+  const int64_t rel = FORM != 0 ? slot : slot - la.slot0;                                 // slot relative to TiledArgs' segment 0
   const int64_t nslots = CSR ? a.nseg : (a.npass > 0 ? a.npass : a.nseg);
   const int sup = a.sup0 + (int)blockIdx.y;
   bool have = rel >= 0 && rel < nslots;
-  const int64_t seg = (have && a.segperm) ? (int64_t)a.segperm[rel] : (have ? rel : 0);
+  int64_t seg = 0;
+  int64_t lwb = wb; // wave block and lane of the layout whose steps this lane walks
+  int ll = lane;
+  if constexpr (FORM == 2) {
+    have = wb < la.gwaves;
+    seg = have ? (int64_t)la.glist[wb * 64 + lane] : -1; // of class (global id) & 15 == lane & 15: lane_compact_fill_kernel
+    have = seg >= 0;
+    if (!have) seg = 0;
+    const int64_t ls = la.inv ? (int64_t)la.inv[seg] : seg + la.slot0;
+    have = have && ls >= 0 && (ls >> 6) < la.nwb;
+    lwb = have ? ls >> 6 : 0;
+    ll = (int)(ls & 63);
+  } else {
+    seg = (have && a.segperm) ? (int64_t)a.segperm[rel] : (have ? rel : 0);
+  }
   if (!GRAD && have) have = a.active[seg] != 0;
   if (!GRAD && !__syncthreads_or(have ? 1 : 0)) return; // nothing left to evaluate in this block of segments
   const int64_t gseg = a.own_offset + seg;
@@ -143,16 +169,47 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
     end = have ? a.ptr[seg + 1] : 0;
     pos = have ? lower_bound_idx<1>(a.idx, beg, end, (int64_t)tb * TILE) : 0;
   }
-  const bool wb_ok = CSR || wb < la.nwb;
-  const int64_t* bp = (CSR || !wb_ok) ? nullptr : la.bptr + wb * (int64_t)(la.ntiles + 1);
+  const bool wb_ok = CSR || (FORM == 2 ? have : wb < la.nwb);
+  const int64_t* bp = (CSR || !wb_ok) ? nullptr : la.bptr + lwb * (int64_t)(la.ntiles + 1);
+  // steps [s0, s1) of the current tile in the layout (FORM 0: the same in every lane of the wave -- loop control stays scalar; FORM 2: the
+  // lane's own wave block); the end of the next tile is requested one tile ahead
+  int64_t s0 = 0, s1 = 0;
+  if constexpr (!CSR) {
+    if (bp) {
+      s0 = bp[tb];
+      s1 = bp[tb + 1];
+    }
+    if constexpr (FORM == 0) {
+      s0 = uniform_i64(s0);
+      s1 = uniform_i64(s1);
+    }
+  }
 #if GLRM_LANE_PREFETCH
   int pf0 = 0, pf1 = 0, pf2 = 0;
 #endif
   for (int t = tb; t < te; ++t) {
     const int64_t lo = (int64_t)t * TILE;
     const int64_t hi = lo + TILE < a.n_other ? lo + TILE : a.n_other;
+    int64_t s2 = s1;
+    if constexpr (!CSR) {
+      if (bp && t + 1 < te) s2 = bp[t + 2];
+    }
     __syncthreads(); // everybody is done with the previous tile
     dma_tile_all<2, KP / 2, NW, true>(a.other, lo, hi, lds, wave, lane); // unpadded rows: a plain copy by LDS-DMA from all waves
+    // the first U steps of the tile are requested behind its staging: they have landed when the tile has (before session r6_25 they were
+    // requested after the barrier: one exposed round trip to the stream per tile)
+    int32_t off[U], noff[U];
+    double av[U], nav[U];
+    int n = 0;
+    if constexpr (!CSR) {
+      n = (int)(s1 - s0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool v = have && u < n;
+        off[u] = v ? la.off[(s0 + u) * 64 + ll] : -1;
+        av[u] = v ? la.val[(s0 + u) * 64 + ll] : 0.0;
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #if GLRM_LANE_PREFETCH
     asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2)); // the prefetch registers of the previous tile stay reserved until their loads have landed
@@ -185,25 +242,13 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
         ++e;
       }
     } else {
-      int64_t s = wb_ok ? uniform_i64(bp[t]) : 0; // (the same value in every lane of the wave: keep the loop control scalar)
-      const int64_t s1 = wb_ok ? uniform_i64(bp[t + 1]) : 0;
-      if (s >= s1) continue;
-      int32_t off[U], noff[U];
-      double av[U], nav[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t q = s + u < s1 ? s + u : s1 - 1;
-        off[u] = la.off[q * 64 + lane];
-        av[u] = la.val[q * 64 + lane];
-        if (s + u >= s1 || !have) off[u] = -1;
-      }
-      for (; s < s1; s += U) { // (s - first step of the tile) stays a multiple of U, U even: step u of a block sits at position parity u & 1
+      // (i stays a multiple of U, U even: step i + u of a segment's window sits at position parity u & 1)
+      for (int i = 0; FORM == 0 ? i < n : __any(i < n) != 0; i += U) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-          const int64_t q = s + U + u < s1 ? s + U + u : s1 - 1;
-          noff[u] = la.off[q * 64 + lane];
-          nav[u] = la.val[q * 64 + lane];
-          if (s + U + u >= s1 || !have) noff[u] = -1;
+          const bool v = have && i + U + u < n;
+          noff[u] = v ? la.off[(s0 + i + U + u) * 64 + ll] : -1;
+          nav[u] = v ? la.val[(s0 + i + U + u) * 64 + ll] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -217,6 +262,9 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
           av[u] = nav[u];
         }
       }
+      if constexpr (FORM == 0) s2 = uniform_i64(s2);
+      s0 = s1;
+      s1 = s2;
     }
   }
   if (have) {
@@ -291,6 +339,184 @@ static __global__ void __launch_bounds__(64) lane_fill_kernel(const int64_t* __r
       val[s * 64 + lane] = v;
     }
   }
+}
+
+// ---- the still-searching segments, wave by wave (FORM 2 of the pass) ---------------------------------------------------------------
+// glist[w][l] = the local segment lane l of wave w of the round works on (-1: idle), gtotal[0] = the waves of the round.  Lane l takes a
+// segment of class (global id) & 15 == l & 15 (bank-conflict free tile reads), and the lanes of a wave come from ONE chunk of 1 024
+// consecutive segments = 16 wave blocks of the layout, so that its loads share lines.  (First version, session r6_25: one ascending list per
+// class, wave w = entries 4w .. 4w + 3 of every list -- the lists drift apart by the square root of their length, tens of wave blocks at
+// 1M rows, and a wave's 64 lanes sat in ~16 different blocks: 25-40 ps per searching observation against 9.85 of the full grid.)  A chunk
+// is one wavefront's work: lane (sub = lane >> 4, cs = lane & 15) owns the segments chunk x 1 024 + sub x 256 + j x 16 + cs, j = 0 .. 15 --
+// one class, ascending; waves of the chunk = the longest class list / 4, rounded up (shorter classes leave idle lanes: binomial imbalance,
+// ~20 % at half the segments searching).  Three small launches per round: waves per chunk, exclusive scan, fill.
+constexpr int LANE_CC = 1024;
+
+__device__ __forceinline__ unsigned lane_chunk_mask(const int32_t* __restrict__ active, int64_t nseg, int64_t chunk, int lane) {
+  const int64_t seg0 = chunk * LANE_CC + (int64_t)(lane >> 4) * 256 + (lane & 15);
+  unsigned m = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int64_t seg = seg0 + j * 16;
+    if (seg < nseg && active[seg] != 0) m |= 1u << j;
+  }
+  return m;
+}
+
+// waves the chunk needs: the longest of its 16 class lists / 4, rounded up (the same value in every lane)
+__device__ __forceinline__ int lane_chunk_waves(int cnt) {
+  int c = cnt + __shfl_xor(cnt, 16, 64);
+  c += __shfl_xor(c, 32, 64); // the class total, in all four lanes of the class
+#pragma unroll
+  for (int d = 1; d < 16; d <<= 1) {
+    const int o = __shfl_xor(c, d, 64);
+    c = o > c ? o : c;
+  }
+  return (c + 3) / 4;
+}
+
+static __global__ void __launch_bounds__(256) lane_compact_count_kernel(const int32_t* __restrict__ active, int64_t nseg, int64_t nchunks, int32_t* __restrict__ nwv) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk >= nchunks) return;
+  const int nw = lane_chunk_waves(__popc(lane_chunk_mask(active, nseg, chunk, lane)));
+  if (lane == 0) nwv[chunk] = nw;
+}
+
+// wbase = exclusive scan of nwv over the chunks, total[0] = the sum (one workgroup)
+static __global__ void __launch_bounds__(1024) lane_compact_scan_kernel(const int32_t* __restrict__ nwv, int64_t nchunks, int32_t* __restrict__ wbase, int32_t* __restrict__ total) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int64_t c0 = 0; c0 < nchunks; c0 += 1024) {
+    const int64_t ch = c0 + threadIdx.x;
+    const int v = ch < nchunks ? nwv[ch] : 0;
+    int incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(incl, d, 64);
+      if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int before = carry;
+    for (int w = 0; w < wave; ++w) before += wsum[w];
+    if (ch < nchunks) wbase[ch] = before + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = before + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) total[0] = carry;
+}
+
+static __global__ void __launch_bounds__(256) lane_compact_fill_kernel(const int32_t* __restrict__ active, int64_t nseg, int64_t nchunks, int off16, const int32_t* __restrict__ wbase,
+                                                                       int32_t* __restrict__ glist) {
+  const int lane = threadIdx.x & 63;
+  const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (chunk >= nchunks) return;
+  const unsigned m = lane_chunk_mask(active, nseg, chunk, lane);
+  const int cnt = __popc(m);
+  const int nw = lane_chunk_waves(cnt);
+  const int64_t w0 = wbase[chunk];
+  const int csk = ((lane & 15) - off16) & 15; // the owner lanes of the class this lane serves: (global id) & 15 == lane & 15
+  for (int w = 0; w < nw; ++w) {
+    int rem = 4 * w + (lane >> 4), seg = -1;
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+      const int c = __shfl(cnt, sub * 16 + csk, 64);
+      const unsigned mm = (unsigned)__shfl((int)m, sub * 16 + csk, 64);
+      if (seg < 0 && rem >= 0) {
+        if (rem < c) {
+          int j = 0, r = rem;
+          for (; j < 16; ++j)
+            if ((mm >> j) & 1u) {
+              if (r == 0) break;
+              --r;
+            }
+          seg = (int)(chunk * LANE_CC) + sub * 256 + j * 16 + csk;
+          rem = -1;
+        } else {
+          rem -= c;
+        }
+      }
+    }
+    glist[(w0 + w) * 64 + lane] = seg;
+  }
+}
+
+// Few segments still searching (the tail rounds of a line search: a few percent down to a single row): a wave's 64 lanes sit in 64 different
+// wave blocks of the layout whatever the order, so nothing is gained by keeping a chunk's segments together -- and the chunked lists above
+// leave most lanes idle (794 searching rows of 1M: 546 waves).  Here the round's waves are packed from the compact list of the previous
+// decide kernel: entry e of class c = (global id) & 15 with rank r among the list's entries of that class goes to wave r / q, lane
+// (r % q) x 16 + c.  q (1 .. 4 entries per class and wave) spreads a short list over the chip: such a round is bound by the tile staging
+// and the line requests of ITS workgroups, not by lanes -- 44 000 rows of 1M packed into full waves (90 workgroups, every lane its own
+// line): 3.2 ms; the same rows in a third-filled waves on 244 workgroups: 1.7 ms (session r6_29).  One workgroup; ranks by ballots per
+// class (list order: deterministic), idle lanes = -1.  total[0] = the waves, or minus that number when glist (cap waves) cannot hold them.
+static __global__ void __launch_bounds__(1024) lane_compact_list_kernel(const int32_t* __restrict__ list, int nact, int off16, int q, int cap, int32_t* __restrict__ glist,
+                                                                        int32_t* __restrict__ total) {
+  __shared__ int wcnt[16][16]; // [wave][class]
+  __shared__ int nwaves;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  int mine = 0; // lane k < 16: entries of class k this wave has met
+  for (int e0 = wave * 64; e0 < nact; e0 += 1024) {
+    const int e = e0 + lane;
+    const int cls = e < nact ? ((list[e] + off16) & 15) : -1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int n = __popcll(__ballot(cls == k));
+      if (lane == k) mine += n;
+    }
+  }
+  if (lane < 16) wcnt[wave][lane] = mine;
+  __syncthreads();
+  if (threadIdx.x < 16) { // exclusive prefix over the waves, per class; the class total decides the waves of the round
+    int run = 0, mx = 0;
+    for (int w = 0; w < 16; ++w) {
+      const int c = wcnt[w][threadIdx.x];
+      wcnt[w][threadIdx.x] = run;
+      run += c;
+    }
+    mx = (run + q - 1) / q;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+      const int o = __shfl_xor(mx, d, 64);
+      mx = o > mx ? o : mx;
+    }
+    if (threadIdx.x == 0) {
+      nwaves = mx <= cap ? mx : -1;
+      total[0] = mx <= cap ? mx : -mx;
+    }
+  }
+  __syncthreads();
+  if (nwaves < 0) return;
+  for (int i = threadIdx.x; i < nwaves * 64; i += 1024) glist[i] = -1;
+  __threadfence();
+  __syncthreads();
+  int base = lane < 16 ? wcnt[wave][lane] : 0; // lane k: rank of this wave's next entry of class k
+  for (int e0 = wave * 64; e0 < nact; e0 += 1024) {
+    const int e = e0 + lane;
+    const int seg = e < nact ? list[e] : 0;
+    const int cls = e < nact ? ((seg + off16) & 15) : -1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const unsigned long long b = __ballot(cls == k);
+      const int start = __shfl(base, k, 64);
+      if (cls == k) {
+        const int r = start + __popcll(b & below);
+        glist[(int64_t)(r / q) * 64 + (r % q) * 16 + k] = seg;
+      }
+      if (lane == k) base += __popcll(b);
+    }
+  }
+}
+
+// inv[perm[slot]] = slot (inv preset to -1: segments outside the layout -- diverted long columns)
+static __global__ void lane_inv_kernel(const int32_t* __restrict__ perm, int64_t nslots, int32_t* __restrict__ inv) {
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s < nslots) inv[perm[s]] = (int32_t)s;
 }
 
 } // namespace glrm
