@@ -2,12 +2,13 @@
 //
 // A side (rows / columns) of a handle runs this family instead of the four-lane tiled kernels when glrm_setup_tiled chose the LDS tiles for it
 // and (all functions of the WHOLE problem's signature and of (k, losses, options), never of the shard -- the two families add in different
-// orders): padded rank 32; one loss descriptor per segment or per model (rows of a model with a loss per column stay on the four-lane kernels);
-// at most GLRM_HIP_LANE_MAX_NNZ observations in the view (default 2e9: the SELL copy is 12 B x ~1.5 per observation on top of the lists).
+// orders): padded rank 32; one loss descriptor per segment or per model, or -- rows of a model with a loss per column -- at most 256 distinct
+// descriptors in the model; at most 2e9 (columns) / 6e9 (rows) observations in the view (the SELL copy is 12 B x its padding per observation on
+// top of the lists; GLRM_HIP_LANE_MAX_NNZ_M / _ROWS_M).
 // The half-step is the pass machinery of the tiled column sweep on BOTH sides: gradient pass -> col_reduce (J_old, first trial point, list of
 // searching segments) -> rounds of (trial pass, col_decide); rows run it with ONE super-tile (nothing is re-added).  The first trial of a
-// half-step walks the SELL layout over the full grid (idle segments masked); later rounds, whose segments are few, run the CSR form of the
-// same kernel over the compact list: the same sums in the same order, so which form ran changes no bit.
+// half-step walks the SELL layout over the full grid (idle segments masked); later rounds run whichever of the kernel's three forms fits
+// the fraction of segments that still searches (glrm_run_lane): the same sums in the same order, so which form ran changes no bit.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -84,11 +85,11 @@ bool glrm_lane_wants(const glrm_handle* h, bool rows) {
   const int want = env_int("GLRM_HIP_LANE", 3); // bit0 rows, bit1 columns
   if (!((want >> (rows ? 0 : 1)) & 1) || h->kp != 32 || !h->tile_cfg || h->tile_lw > 0 || h->multi || h->dense || h->sum_order_opt) return false;
   if (lane_tile_rows(h->kp) != h->order_unit) return false; // (loader-wave experiments order the lists by half tiles)
-  // a loss per column: the row view meets a descriptor per observation -- through one-byte ids, i.e. at most 256 distinct descriptors
-  // OPT-IN (GLRM_HIP_LANE_PER_OBS=1): parity-green, but measured slower than the four-lane kernels on the C5 recipe (1M rows: X half-step 64.4
-  // against 45.8 ms, session r6_19/20 -- three serialized loss formulas per step, spills around them, and the line search's later rounds,
-  // 45 % / 20 % / ... of the rows, on the slow CSR form)
-  if (rows && h->n_losses > 1 && (!env_int("GLRM_HIP_UDESC", 1) || !env_int("GLRM_HIP_LANE_PER_OBS", 0) || !glrm_lane_few_descriptors(h))) return false;
+  // a loss per column: the row view meets a descriptor per observation -- through one-byte ids, i.e. at most 256 distinct descriptors.
+  // Default since session r6_33 (GLRM_HIP_LANE_PER_OBS=0 keeps such rows on the four-lane kernels): with the trial rounds read out of the
+  // SELL layout (glrm_run_lane) the C5 recipe's X half-step is 42.5 against 46.6 ms at 1M rows and 194 against 215 ms at its stated size.
+  // (Session r6_19/20, rounds on the CSR form: 64.4 against 45.8 ms -- opt-in then.)
+  if (rows && h->n_losses > 1 && (!env_int("GLRM_HIP_UDESC", 1) || !env_int("GLRM_HIP_LANE_PER_OBS", 1) || !glrm_lane_few_descriptors(h))) return false;
   // the SELL copy is 12 B x its padding per observation on top of the lists: a memory policy per view (rows: the copy REPLACES the kind-grouped
   // private row view of such models, and rows pad little; columns pad x 1.5-1.8).  C5 at its stated size: 5e9 observations per view
   const int64_t max_nnz = (int64_t)env_int(rows ? "GLRM_HIP_LANE_MAX_NNZ_ROWS_M" : "GLRM_HIP_LANE_MAX_NNZ_M", rows ? 6000 : 2000) * 1000000ll;

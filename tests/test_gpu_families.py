@@ -310,7 +310,7 @@ def test_borrowed_device_arrays_give_the_bits_of_copied_ones(tiled, mix):
         for a, b in zip(snap, (w.rowptr, w.colidx, w.rowvals, w.colptr, w.rowidx, w.colvals)):
             assert torch.equal(a, b)
     # bit0 / bit1: the LDS tiles on both sides; bit8 / bit9: in their lane-per-segment form (rank 32; rows only with ONE loss descriptor)
-    assert out[0][3] == out[1][3] == ((3 | 512 | (0 if mix else 256)) if tiled == 2 else 0)
+    assert out[0][3] == out[1][3] == ((3 | 512 | 256) if tiled == 2 else 0)
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
     with pytest.raises(_capi.GLRMError):   # host arrays cannot be borrowed
         pa, X0, Y0 = ragged_problem(np.random.default_rng(1), 30, 20, 4, 5)
@@ -560,3 +560,55 @@ def test_arrival_order_on_the_other_column_families(monkeypatch, family):
     for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
         assert res[True][2][key] == res[False][2][key]
     assert res[False][2]["ms_wait_y"] == 0.0 and res[True][2]["ms_wait_y"] > 0.0   # the launch stream did stand in front of late blocks
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_lane_trial_rounds_give_the_same_bits_in_every_form(monkeypatch, mixed):
+    """The trial rounds of the lane-per-segment passes (csrc/glrm_lane.hip: glrm_run_lane) pick one of three forms of the same kernel by the
+    fraction of segments that still searches: the SELL layout over the full grid, the CSR form over the compact list, and (session r6_25) the
+    layout read by gathered waves -- wave lists built chunk by chunk, or packed from the decide kernel's list for the tail rounds.  Every form
+    adds the same terms in the same order: forcing each of them on all rounds (thresholds through the environment) gives the bits of the
+    default mix, with the same number of trials and accepts.  Rows of 300 observations started far from a minimum search for several rounds
+    (start step sizes of 64: every row rejects a few trials, then the searches thin out); QuadLoss and a loss per column (descriptor ids in
+    the stream's offset word, rows and columns)."""
+    m, n, k = 9000, 1500, 32
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, 300, value_model=0, loss_mix=1 if mixed else 0)
+    if mixed:
+        kinds = [L.QuadLoss(0.8).descriptor(), L.HuberLoss(1.1, crossover=0.7).descriptor(), L.OrdinalHingeLoss(1, 5, 0.9).descriptor()]
+        losses = np.array([kinds[f % 3] for f in range(n)], dtype=_capi.LOSS_DTYPE)
+    else:
+        losses = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 0.5)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, losses, reg, reg)
+    api = hip()
+    forms = {
+        "default": {},
+        "older forms (full grid / CSR)": {"GLRM_HIP_LANE_ROUNDS": "0"},
+        "gathered, chunk lists": {"GLRM_HIP_LANE_GATHER_TO": "101", "GLRM_HIP_LANE_GATHER_PACKED": "0"},
+        "gathered, packed lists": {"GLRM_HIP_LANE_GATHER_TO": "101", "GLRM_HIP_LANE_GATHER_PACKED": "101", "GLRM_HIP_LANE_GATHER_SPREAD": "1000"},
+    }
+    res = {}
+    for name, env in forms.items():
+        for key in ("GLRM_HIP_LANE_ROUNDS", "GLRM_HIP_LANE_GATHER_TO", "GLRM_HIP_LANE_GATHER_PACKED", "GLRM_HIP_LANE_GATHER_SPREAD"):
+            monkeypatch.delenv(key, raising=False)
+        for key, v in env.items():
+            monkeypatch.setenv(key, v)
+        h = api.create(pa, tiled=2)
+        try:
+            assert api.kernel_stats(h)["tiled"] & (256 | 512) == (256 | 512)
+            api.set_factors(h, 0.3 * X0, 0.3 * Y0)
+            api.reset_stepsizes(h, 64.0)
+            for it in range(4):
+                api.step_x(h, 0.01)
+                api.step_y(h, 0.01)
+            X, Y = np.zeros_like(X0), np.zeros_like(Y0)
+            api.get_factors(h, X, Y)
+            res[name] = (X, Y, api.kernel_stats(h))
+        finally:
+            api.destroy(h)
+    X, Y, st = res["default"]
+    assert st["trials_x"] > 2 * 4 * m and st["trials_y"] > 4 * n   # the searches did run for several rounds
+    for name, (Xf, Yf, stf) in res.items():
+        assert np.array_equal(Xf, X) and np.array_equal(Yf, Y), name
+        for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
+            assert stf[key] == st[key], (name, key)

@@ -349,7 +349,7 @@ def test_two_shards_on_one_gpu_equal_one_shard(mode, mixed):
     api = hip()
     params = L.ProxGradParams(max_iter=6)
     o1, X1, Y1, st1 = cases.run_engine(api, pa, X0, Y0, params, tiled=mode)
-    assert st1["tiled"] == ((3 | 512 | (0 if mixed else 256)) if mode == 2 else 0)   # LDS tiles, at rank 32 in their lane-per-segment form
+    assert st1["tiled"] == ((3 | 512 | 256) if mode == 2 else 0)   # LDS tiles, at rank 32 in their lane-per-segment form
     def shard(rb, re, cb, ce):
         r0, r1, c0, c1 = pa.rowptr[rb], pa.rowptr[re], pa.colptr[cb], pa.colptr[ce]
         return _capi.ProblemArrays(m, n, k, np.ascontiguousarray(pa.rowptr[rb:re + 1] - r0), np.ascontiguousarray(pa.colidx[r0:r1]),

@@ -132,19 +132,21 @@ def test_heterogeneous_columns_on_the_lds_tiles(monkeypatch):
 
 
 def test_heterogeneous_columns_on_the_lane_per_segment_passes(monkeypatch):
-    """The same model with both views on the lane-per-segment passes -- the column view with ONE loss descriptor per column, the row view
-    (opt-in: GLRM_HIP_LANE_PER_OBS=1; measured slower than the four-lane kernels) with a descriptor per OBSERVATION: its
-    one-byte id rides in the SELL offset word, the descriptors sit in LDS behind the tile, and the row view keeps the caller's order (no kind
-    grouping: every lane evaluates its own observation's formula)."""
-    monkeypatch.setenv("GLRM_HIP_LANE_PER_OBS", "1")
+    """The same model with both views on the lane-per-segment passes (the default at rank 32 since session r6_33) -- the column view with ONE
+    loss descriptor per column, the row view with a descriptor per OBSERVATION: its one-byte id rides in the SELL offset word, the descriptors
+    sit in LDS behind the tile, and the row view keeps the caller's order (no kind grouping: every lane evaluates its own observation's
+    formula).  The trial rounds after the first run all three forms of the pass (full grid / gathered from the layout / CSR)."""
+    monkeypatch.delenv("GLRM_HIP_LANE_PER_OBS", raising=False)
     pa, X0, Y0 = problem(5000, 1500, 32, 300, (1, 0, 1.0), mixed=True)
     o = engine_and_oracle_in_its_order(pa, X0, Y0, 6, TILED_R | TILED_C, ("windowed", "windowed"), tiled=2)
     assert [(x.lanes, x.comps, x.batch, x.rotate, x.private_order) for x in o] == [(2, 16, 2, 2, 0)] * 2
 
 
-def test_heterogeneous_rows_stay_on_the_four_lane_kernels_by_default():
-    """The default family choice for a model with a loss per column: the lane-per-segment passes on the column view, the four-lane kernels
-    (kind-grouped windows, private_order = 2) on the row view."""
+def test_heterogeneous_rows_on_the_four_lane_kernels(monkeypatch):
+    """GLRM_HIP_LANE_PER_OBS=0 (the default until session r6_33, and what views beyond 6e9 observations or models of more than 256 distinct
+    descriptors run): the lane-per-segment passes on the column view, the four-lane kernels (kind-grouped windows, private_order = 2) on
+    the row view."""
+    monkeypatch.setenv("GLRM_HIP_LANE_PER_OBS", "0")
     pa, X0, Y0 = problem(5000, 1500, 32, 300, (1, 0, 1.0), mixed=True)
     o = engine_and_oracle_in_its_order(pa, X0, Y0, 6, TILED_R | TILED_C, ("windowed", "windowed"), tiled=2)
     assert (o[0].lanes, o[0].batch, o[0].rotate, o[0].private_order) == (4, 4, 0, 2) and (o[1].lanes, o[1].comps, o[1].batch, o[1].rotate) == (2, 16, 2, 2)
@@ -158,11 +160,12 @@ def test_heterogeneous_columns_on_the_gather_sweeps():
     assert o[0].batch == 4 and o[0].batch_one_wave_only == 0 and o[1].batch == 4 and o[1].batch_one_wave_only == 1
 
 
-def test_rows_regrouped_by_loss_kind_are_followed_by_the_oracle():
-    """With the default kind grouping the row view of a heterogeneous model is walked in a private order -- inside every tile window the
+def test_rows_regrouped_by_loss_kind_are_followed_by_the_oracle(monkeypatch):
+    """With the kind grouping of the four-lane kernels (GLRM_HIP_LANE_PER_OBS=0) the row view of a heterogeneous model is walked in a private order -- inside every tile window the
     entries grouped by ascending loss kind, stably (glrm_tiled.hpp: group_rows_by_kind_kernel).  That is a function of the caller's list
     alone: the engine reports private_order = 2 and the oracle restates the grouping (glrm_cpu_set_sum_order) -- bit-identical factors.
     A TILE-SORTED private copy (private_order = 1) stays out of the oracle's reach."""
+    monkeypatch.setenv("GLRM_HIP_LANE_PER_OBS", "0")
     pa, X0, Y0 = problem(5000, 1500, 32, 300, (1, 0, 1.0), mixed=True)
     o = engine_and_oracle_in_its_order(pa, X0, Y0, 6, TILED_R | TILED_C, ("windowed", "windowed"), tiled=2)
     assert o[0].private_order == 2 and o[1].private_order == 0 and o[0].batch == 4

@@ -63,8 +63,10 @@ def expected_orders(m, n, k, q, mixed=False):
     if mixed and not (tiled_r and tiled_c and G in (4, 8) and R == 8):
         raise SystemExit("a heterogeneous recipe outside the LDS-tiled families: write the gather families' batch rules down here first")
     # lane-per-segment form of the LDS-tiled passes (csrc/glrm_lane.hip: glrm_setup_lane): padded rank 32, at most 2e9 observations in the view;
-    # rows only when the model has ONE loss descriptor.  Reported as the two-lane layout with the rotated chunk walk (rotate = 2)
-    lane_r = tiled_r and kp == 32 and not mixed and nnz <= 6_000_000_000   # (rows of a model with a loss per column: opt-in only, GLRM_HIP_LANE_PER_OBS)
+    # rows of a model with a loss per column as well since session r6_33 (a descriptor per observation through one-byte ids: at most 256
+    # distinct descriptors -- the bench recipes hold three).  Reported as the two-lane layout with the rotated chunk walk (rotate = 2); the row
+    # view keeps the caller's order (no kind grouping)
+    lane_r = tiled_r and kp == 32 and nnz <= 6_000_000_000
     lane_c = tiled_c and kp == 32 and nnz <= 2_000_000_000
     if tiled_r:
         rows.update(family=2, window=T, windows_per_sup=0, batch=G if mixed else 2, private_order=2 if mixed else 0)
