@@ -50,7 +50,27 @@ static int make_segperm(glrm_handle* h, bool rows, int32_t** out, int64_t long_f
     if (kinds && lt[x].kind != lt[y].kind) return lt[x].kind < lt[y].kind;
     return ptr[x + 1] - ptr[x] > ptr[y + 1] - ptr[y];
   });
-  if (!rows && tile_rot_rt(h->G, h->R)) {
+  const bool lane_side = (rows ? h->tiled_row : h->tiled_col) && glrm_lane_wants(h, rows) && env_int("GLRM_HIP_LANE_DEAL", 1);
+  if (lane_side) {
+    // The lane-per-segment passes (glrm_lane.hpp) read their tiles conflict free when the 16 lanes of an LDS cycle hold 16 different
+    // classes (global id) & 15 -- true when slot s holds a segment of class s & 15.  In natural order that is given; a sorted list is dealt
+    // out class by class (the 16 classes are equally frequent, so a wave still meets segments of one kind and similar length; a class
+    // that runs dry is filled from the longest remaining queue: costs conflicts at the tail, never bits).  Measured before (session r6_35,
+    // C5 recipe at 1M rows, columns sorted by kind and length): bank conflicts in 48 % of the column passes' LDS cycles.
+    std::vector<int32_t> q[16];
+    const int64_t g0 = rows ? h->rb : h->cb;
+    for (int32_t sgm : perm) q[(g0 + sgm) & 15].push_back(sgm);
+    size_t head[16] = {0};
+    for (int64_t slot = 0; slot < nslots; ++slot) {
+      int c = (int)(slot & 15);
+      if (head[c] >= q[c].size()) {
+        size_t best = 0;
+        for (int d = 0; d < 16; ++d)
+          if (q[d].size() - head[d] > best) { best = q[d].size() - head[d]; c = d; }
+      }
+      perm[(size_t)slot] = q[c][head[c]++];
+    }
+  } else if (!rows && tile_rot_rt(h->G, h->R)) {
     // the column passes read their tiles conflict-free (glrm_tiled.hpp: tile_rot) when slot s holds a segment of class (s & 7) >> 1,
     // class = ((global id) & 7) >> 1: deal the sorted list out class by class, two per block of eight slots -- the four classes are
     // equally frequent, so every wave still meets segments of one kind and similar length; a class that runs dry is filled from the
