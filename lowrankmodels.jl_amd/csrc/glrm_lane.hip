@@ -234,47 +234,49 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
     if (nact == 0) break;
     HIPCK(hipMemsetAsync(h->nactive, 0, 4, st));
     const int trace = env_int("GLRM_HIP_LANE_TRACE", 0);
-    // Three forms of the trial pass, all adding the same terms in the same order.  FORM 0 walks the SELL layout over the full grid (idle
-    // segments masked): the cost of a whole pass whatever the fraction that searches.  The CSR form over the compact list costs 5-8 x as much
-    // per observation (one lane walks its own list, nothing in flight), but only for the segments listed.  FORM 2 (session r6_25) lists the
-    // searching segments class by class and reads their steps out of the SELL layout: the work of the fraction that searches, ahead of its
-    // use -- but a wave's lanes then sit in 1 / fraction different wave blocks of the layout, each 4-byte read its own 64-byte line.
-    // Measured on the C5 recipe at 1M rows (profiles/r06_c5family_lane_rounds_trace.txt): rows -- 98 % searching: 11.9-13.2 ms against 9.85
-    // of FORM 0; 1 %: 3.0 ms against ~0.7 of the CSR form; columns (slots permuted by kind and length: a wave's segments are scattered
-    // over the layout) -- 51 %: 24.6 ms against 10.7.  So FORM 2 serves the middle fractions of sides whose slots are the segments in order.
+    // Three forms of the trial pass, all adding the same terms in the same order (tests/test_gpu_families.py forces each of them on every
+    // round).  FORM 0 walks the SELL layout over the full grid (idle segments masked): the cost of a whole pass whatever the fraction that
+    // searches -- from 70 % up.  FORM 2 reads the layout through gathered waves (glrm_lane.hpp): waves built chunk by chunk of 1 024
+    // segments while a wave's lanes can share lines (sides whose slots are the segments in order), packed from the decide kernel's compact
+    // list and spread over the chip for the tail rounds (any side).  The CSR form (one lane walks its own list, nothing in flight: 3-5 ms
+    // for any tail round) is what remains for the middle fractions of sides with permuted slots and for sub-ranges the layout does not
+    // cover.  C5 recipe, 1M rows, X half-step (profiles/r06_c5family_lane_rounds_trace.txt): full grid 9.85 ms; gathered 7.8 ms at 55 %,
+    // 5.4 at 32 %, 3.1 at 12 %, 1.5-2.1 for the tails.
     const int64_t pct = (int64_t)nact * 100 / (full.nseg > 0 ? full.nseg : 1);
-    const bool use_gather = gather && !la.inv && pct >= env_int("GLRM_HIP_LANE_GATHER_FROM", 0) && pct < env_int("GLRM_HIP_LANE_GATHER_TO", 70);
+    bool packed = lists && (int64_t)nact * 100 < full.nseg * env_int("GLRM_HIP_LANE_GATHER_PACKED", 4);
+    bool use_gather = gather && (!la.inv || packed) && pct >= env_int("GLRM_HIP_LANE_GATHER_FROM", 0) && pct < env_int("GLRM_HIP_LANE_GATHER_TO", 70);
+    int32_t gwaves = 0;
     if (use_gather) {
       const int off16 = (int)(full.own_offset & 15);
-      // few segments left (a wave's lanes sit in different wave blocks of the layout anyway): waves packed from the previous decide kernel's
-      // compact list; otherwise chunk by chunk, so that a wave's segments are neighbours in the layout
-      bool packed = lists && (int64_t)nact * 100 < full.nseg * env_int("GLRM_HIP_LANE_GATHER_PACKED", 4);
-      int32_t tot[2] = {0, 0};
       if (packed) {
         const int spread = env_int("GLRM_HIP_LANE_GATHER_SPREAD", 32768); // searching segments per step of q: ~2 048 waves before a wave takes more per class
         int q = (int)(((int64_t)nact + spread - 1) / spread);
         q = q < 1 ? 1 : (q > 4 ? 4 : q);
         hipLaunchKernelGGL(lane_compact_list_kernel, dim3(1), dim3(1024), 0, st, list[cur], (int)nact, off16, q, (int)h->lane_gcap, h->lane_glist, h->lane_gtotal);
         HIPCK(hipGetLastError());
-        HIPCK(hipMemcpyAsync(tot, h->lane_gtotal, 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(&gwaves, h->lane_gtotal, 4, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
-        if (tot[0] < 0) packed = false; // (one class holds nearly every entry: the waves would not fit the list)
+        if (gwaves < 0) { // (one class holds nearly every entry: the waves would not fit the list)
+          packed = false;
+          if (la.inv) use_gather = false;
+        }
       }
-      if (!packed) {
+      if (use_gather && !packed) {
         const int64_t nchunks = (full.nseg + LANE_CC - 1) / LANE_CC;
         const unsigned cg = (unsigned)((nchunks + 3) / 4);
         hipLaunchKernelGGL(lane_compact_count_kernel, dim3(cg), dim3(256), 0, st, full.active, full.nseg, nchunks, h->lane_gcnt);
         hipLaunchKernelGGL(lane_compact_scan_kernel, dim3(1), dim3(1024), 0, st, h->lane_gcnt, nchunks, h->lane_gbase, h->lane_gtotal);
         hipLaunchKernelGGL(lane_compact_fill_kernel, dim3(cg), dim3(256), 0, st, full.active, full.nseg, nchunks, off16, h->lane_gbase, h->lane_glist);
         HIPCK(hipGetLastError());
-        HIPCK(hipMemcpyAsync(tot, h->lane_gtotal, 4, hipMemcpyDeviceToHost, st));
+        HIPCK(hipMemcpyAsync(&gwaves, h->lane_gtotal, 4, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));
       }
-      tot[1] = tot[0];
-      la.gwaves = tot[0];
-      if (trace >= 2) fprintf(stderr, "[glrm lane] %s round %d: %u of %lld segments search: SELL gathered%s, %d waves\n", rows ? "row" : "column", round, nact, (long long)full.nseg, packed ? " (packed)" : "", tot[1]);
+    }
+    if (use_gather) {
+      la.gwaves = gwaves;
+      if (trace >= 2) fprintf(stderr, "[glrm lane] %s round %d: %u of %lld segments search: SELL gathered%s, %d waves\n", rows ? "row" : "column", round, nact, (long long)full.nseg, packed ? " (packed)" : "", (int)gwaves);
       t.npass = 0;
-      rc = launch_lane_loss<false, 2>(loss, t, la, (int64_t)tot[1], st);
+      rc = launch_lane_loss<false, 2>(loss, t, la, (int64_t)gwaves, st);
       if (rc) return rc;
       if (lists) {
         d.actlist_in = list[cur];
