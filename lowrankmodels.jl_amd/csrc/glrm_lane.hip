@@ -25,11 +25,11 @@ namespace {
 constexpr int LANE_NW = 8; // 8 waves x 64 segments per workgroup, 256 VGPRs per lane
 constexpr int lane_tile_rows(int kp) { return ((150 * 1024) / (kp * 8 + 16)) / 16 * 16; } // = tile_rows_c(kp, 1): the order unit of the lists
 
-template <int LOSS, bool GRAD, int FORM>
+template <int LOSS, bool GRAD, int FORM, bool COMPACT = false>
 int launch_lane_inst(const TiledArgs& a, const LaneArgs& la, int64_t nblocks, hipStream_t st) {
   constexpr int KP = 32, T = lane_tile_rows(KP);
   const int LDSB = T * KP * 8 + (loss_mode(LOSS) == 2 ? a.n_udesc * 32 : 0);
-  auto k = lane_pass_kernel<KP, LANE_NW, T, LOSS, GRAD, FORM>;
+  auto k = lane_pass_kernel<KP, LANE_NW, T, LOSS, GRAD, FORM, COMPACT>;
   HIPCK(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, LDSB)); // (per device: a process may drive several)
   const unsigned gx = (unsigned)((nblocks + LANE_NW - 1) / LANE_NW);
   if (gx == 0) return GLRM_OK;
@@ -39,6 +39,18 @@ int launch_lane_inst(const TiledArgs& a, const LaneArgs& la, int64_t nblocks, hi
 
 template <bool GRAD, int FORM>
 int launch_lane_loss(int loss, const TiledArgs& a, const LaneArgs& la, int64_t nblocks, hipStream_t st) {
+  if constexpr (FORM == 0) {
+    if (la.off16) { // the compact form of the stream (sides without a descriptor id in the offset word)
+      switch (loss) {
+        case LOSS_QUAD_UNIFORM: return launch_lane_inst<0, GRAD, 0, true>(a, la, nblocks, st);
+        case LOSS_SEGMENT: return launch_lane_inst<1, GRAD, 0, true>(a, la, nblocks, st);
+        case LOSS_SEGMENT_NOTRIG: return launch_lane_inst<3, GRAD, 0, true>(a, la, nblocks, st);
+        default: return fail(GLRM_ERR_UNSUPPORTED, "lane-per-segment passes, compact stream: no kernel for loss variant %d", loss);
+      }
+    }
+  } else if (FORM == 2 && la.off16) {
+    return fail(GLRM_ERR_UNSUPPORTED, "lane-per-segment passes: the gathered form does not read the compact stream");
+  }
   switch (loss) {
     case LOSS_QUAD_UNIFORM: return launch_lane_inst<0, GRAD, FORM>(a, la, nblocks, st);
     case LOSS_SEGMENT: return launch_lane_inst<1, GRAD, FORM>(a, la, nblocks, st);
@@ -92,7 +104,9 @@ bool glrm_lane_wants(const glrm_handle* h, bool rows) {
   if (rows && h->n_losses > 1 && (!env_int("GLRM_HIP_UDESC", 1) || !env_int("GLRM_HIP_LANE_PER_OBS", 1) || !glrm_lane_few_descriptors(h))) return false;
   // the SELL copy is 12 B x its padding per observation on top of the lists: a memory policy per view (rows: the copy REPLACES the kind-grouped
   // private row view of such models, and rows pad little; columns pad x 1.5-1.8).  C5 at its stated size: 5e9 observations per view
-  const int64_t max_nnz = (int64_t)env_int(rows ? "GLRM_HIP_LANE_MAX_NNZ_ROWS_M" : "GLRM_HIP_LANE_MAX_NNZ_M", rows ? 6000 : 2000) * 1000000ll;
+  // (columns beyond 2e9 observations: the COMPACT form of the stream -- 2-byte offsets, unpadded values, 11.5 instead of 21 B per observation at
+  // x 1.76 padding; GLRM_HIP_LANE_COMPACT = 0 never, 1 every side it serves, 2 (default) views beyond 2e9 observations)
+  const int64_t max_nnz = (int64_t)env_int(rows ? "GLRM_HIP_LANE_MAX_NNZ_ROWS_M" : "GLRM_HIP_LANE_MAX_NNZ_M", rows || env_int("GLRM_HIP_LANE_COMPACT", 2) ? 6000 : 2000) * 1000000ll;
   return (rows ? h->sig.nnz_rows : h->sig.nnz_cols) <= max_nnz;
 }
 
@@ -122,12 +136,16 @@ int glrm_setup_lane(glrm_handle* h) {
     const int32_t* perm = rows ? h->rowperm : h->colperm;
     const int64_t ncell = nwb * ntiles;
     if (ncell > (int64_t)1 << 30) { h->lane[side] = 0; continue; } // (cannot happen at shapes the LDS tiles are chosen for)
-    int64_t *cnt = nullptr, *scan = nullptr;
+    // the compact form of the stream for this side?  A function of the whole problem (view size, losses, options), like the family itself
+    const int cmode = env_int("GLRM_HIP_LANE_COMPACT", 2);
+    const bool compact = !(rows && h->n_losses > 1) && (cmode == 1 || (cmode == 2 && (rows ? h->sig.nnz_rows : h->sig.nnz_cols) > 2000000000ll));
+    int64_t *cnt = nullptr, *scan = nullptr, *vcnt = nullptr;
     void* tmp = nullptr;
-    auto cleanup = [&](int rc) { (void)hipFree(cnt); (void)hipFree(scan); (void)hipFree(tmp); return rc; };
+    auto cleanup = [&](int rc) { (void)hipFree(cnt); (void)hipFree(scan); (void)hipFree(vcnt); (void)hipFree(tmp); return rc; };
     HIPCK(hipMalloc((void**)&cnt, (size_t)ncell * 8));
     if (hipMalloc((void**)&scan, (size_t)ncell * 8) != hipSuccess) return cleanup(fail(GLRM_ERR_OOM, "out of device memory"));
-    hipLaunchKernelGGL(lane_count_kernel, dim3((unsigned)nwb), dim3(64), 0, st, ptr, idx, perm, nslots, T, ntiles, cnt);
+    if (compact && hipMalloc((void**)&vcnt, (size_t)ncell * 8) != hipSuccess) return cleanup(fail(GLRM_ERR_OOM, "out of device memory"));
+    hipLaunchKernelGGL(lane_count_kernel, dim3((unsigned)nwb), dim3(64), 0, st, ptr, idx, perm, nslots, T, ntiles, cnt, vcnt);
     size_t bytes = 0;
     if (hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, cnt, scan, (int)ncell, st) != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "scan (size query) failed"));
     if (hipMalloc(&tmp, bytes ? bytes : 1) != hipSuccess) return cleanup(fail(GLRM_ERR_OOM, "out of device memory"));
@@ -142,10 +160,34 @@ int glrm_setup_lane(glrm_handle* h) {
     const int64_t steps = last[0] + last[1];
     h->lane_steps[side] = steps;
     const int64_t s1 = steps > 0 ? steps : 1;
-    if (hipMalloc((void**)&h->lane_off[side], (size_t)s1 * 64 * 4) != hipSuccess || hipMalloc((void**)&h->lane_val[side], (size_t)s1 * 64 * 8) != hipSuccess)
-      return cleanup(fail(GLRM_ERR_OOM, "out of device memory for the lane-per-segment stream of the %s view (%lld steps of 64 entries)", rows ? "row" : "column", (long long)steps));
-    hipLaunchKernelGGL(lane_fill_kernel, dim3((unsigned)nwb), dim3(64), 0, st, ptr, idx, vals, (rows && h->n_losses > 1) ? h->rowdescid : nullptr, perm, nslots, T, ntiles,
-                       h->kp * 8, h->lane_bptr[side], h->lane_off[side], h->lane_val[side]);
+    if (compact) {
+      // values before every (wave block, tile): the same scan over the observation counts (the step scan's scratch serves again)
+      if (hipcub::DeviceScan::ExclusiveSum(tmp, bytes, vcnt, scan, (int)ncell, st) != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "scan failed"));
+      if (hipMalloc((void**)&h->lane_vptr[side], (size_t)nwb * (ntiles + 1) * 8) != hipSuccess) return cleanup(fail(GLRM_ERR_OOM, "out of device memory"));
+      hipLaunchKernelGGL(lane_bptr_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, scan, vcnt, nwb, ntiles, h->lane_vptr[side]);
+      const int64_t nv = std::max<int64_t>(1, rows ? h->nnz_r : h->nnz_c);
+      const bool ok = hipMalloc((void**)&h->lane_off16[side], (size_t)s1 * 64 * 2) == hipSuccess && hipMalloc((void**)&h->lane_val[side], (size_t)nv * 8) == hipSuccess;
+      if (!ok) {
+        // No room for the stream beside the lists: the side stays on the four-lane kernels.  (The only family choice that can depend on
+        // the device rather than on the problem; glrm_hip_sum_order reports what runs, and the super-tile geometry is already fixed.)
+        (void)hipGetLastError();
+        (void)hipFree(h->lane_off16[side]); (void)hipFree(h->lane_val[side]); (void)hipFree(h->lane_vptr[side]); (void)hipFree(h->lane_bptr[side]);
+        h->lane_off16[side] = nullptr; h->lane_val[side] = nullptr; h->lane_vptr[side] = nullptr; h->lane_bptr[side] = nullptr;
+        h->lane[side] = 0;
+        h->lane_steps[side] = 0;
+        fprintf(stderr, "[glrm lane] no device memory for the compact stream of the %s view (%.1f GB): the view stays on the four-lane LDS-tiled kernels\n", rows ? "row" : "column",
+                ((double)s1 * 128 + (double)nv * 8) / 1e9);
+        cleanup(0);
+        continue;
+      }
+      hipLaunchKernelGGL(lane_fill_compact_kernel, dim3((unsigned)nwb), dim3(64), 0, st, ptr, idx, vals, perm, nslots, T, ntiles, h->lane_bptr[side], h->lane_vptr[side],
+                         h->lane_off16[side], h->lane_val[side]);
+    } else {
+      if (hipMalloc((void**)&h->lane_off[side], (size_t)s1 * 64 * 4) != hipSuccess || hipMalloc((void**)&h->lane_val[side], (size_t)s1 * 64 * 8) != hipSuccess)
+        return cleanup(fail(GLRM_ERR_OOM, "out of device memory for the lane-per-segment stream of the %s view (%lld steps of 64 entries)", rows ? "row" : "column", (long long)steps));
+      hipLaunchKernelGGL(lane_fill_kernel, dim3((unsigned)nwb), dim3(64), 0, st, ptr, idx, vals, (rows && h->n_losses > 1) ? h->rowdescid : nullptr, perm, nslots, T, ntiles,
+                         h->kp * 8, h->lane_bptr[side], h->lane_off[side], h->lane_val[side]);
+    }
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return cleanup(fail(GLRM_ERR_HIP, "lane layout: build failed"));
     cleanup(0);
     if (perm) { // FORM 2 of the rounds finds a segment's slot through the inverse of the slot permutation
@@ -156,9 +198,9 @@ int glrm_setup_lane(glrm_handle* h) {
     }
     if (nseg > gseg_max) gseg_max = nseg;
     if (env_int("GLRM_HIP_LANE_TRACE", 0))
-      fprintf(stderr, "[glrm lane] %s view: %lld slots in %lld wave blocks x %d tiles, %lld steps of 64 = %.3f x the %lld observations\n", rows ? "row" : "column",
+      fprintf(stderr, "[glrm lane] %s view: %lld slots in %lld wave blocks x %d tiles, %lld steps of 64 = %.3f x the %lld observations%s\n", rows ? "row" : "column",
               (long long)nslots, (long long)nwb, ntiles, (long long)steps, (double)steps * 64.0 / (double)std::max<int64_t>(1, rows ? h->nnz_r : h->nnz_c),
-              (long long)(rows ? h->nnz_r : h->nnz_c));
+              (long long)(rows ? h->nnz_r : h->nnz_c), compact ? " (compact stream: 2-byte offsets padded, values unpadded)" : "");
   }
   if (gseg_max > 0 && !h->lane_glist) { // the wave lists of the rounds (one set serves both sides: a half-step at a time)
     h->lane_gchunks = (gseg_max + LANE_CC - 1) / LANE_CC;
@@ -181,6 +223,8 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
   la.bptr = h->lane_bptr[side];
   la.off = h->lane_off[side];
   la.val = h->lane_val[side];
+  la.off16 = h->lane_off16[side];
+  la.vptr = h->lane_vptr[side];
   la.ntiles = h->lane_ntiles[side];
   la.nwb = h->lane_nwb[side];
   la.slot0 = 0;
@@ -221,7 +265,7 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
   HIPCK(hipGetLastError());
   if (eval_only) return GLRM_OK;
   const TiledArgs full = a;
-  const bool gather = env_int("GLRM_HIP_LANE_ROUNDS", 1) != 0 && sell_ok && h->lane_glist && la.bptr && h->lane_steps[side] > 0 &&
+  const bool gather = env_int("GLRM_HIP_LANE_ROUNDS", 1) != 0 && sell_ok && h->lane_glist && la.bptr && h->lane_steps[side] > 0 && !la.off16 &&
                       full.nseg <= h->lane_gchunks * (int64_t)LANE_CC;
   constexpr int MAX_ROUNDS = 4096; // see glrm_run_tiled
   for (int round = 0;; ++round) {

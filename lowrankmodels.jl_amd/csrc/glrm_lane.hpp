@@ -46,6 +46,11 @@ struct LaneArgs {
   const int32_t* off;  // [steps][64] byte offset of the staged vector inside its tile (local index x kp x 8, below 2^20) | the id of the
                        // entry's loss descriptor << 20 (rows of a model with a loss per column; 0 otherwise); -1 = idle lane
   const double* val;   // [steps][64]
+  // COMPACT form of the stream (views whose padded copy would not fit: C5's column view at its stated size): 2-byte offsets (tile-local
+  // index of the staged vector, 0xFFFF = idle lane) in the padded [steps][64] arrangement, the VALUES unpadded -- a step's values are those
+  // of its busy lanes in lane order, the steps of a wave block back to back; vptr[wave block][tile] = index of the tile's first value
+  const uint16_t* off16; // nullptr: the padded form above
+  const int64_t* vptr;
   int ntiles;          // tiles of the opposing factor (stride of bptr minus one)
   int64_t nwb;         // wave blocks the layout holds (a launch rounds its grid up to whole workgroups: blocks beyond have no steps)
   int64_t slot0;       // local id of TiledArgs' segment 0 in the slot space the layout was built on (row sub-ranges: glrm_hip_step_x_range)
@@ -69,9 +74,10 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 // OWN (wave block, tile) at its own slot of the layout: the segments of a wave come from neighbouring wave blocks (the class lists are in
 // ascending order), so its loads still share lines (about 12 / fraction-still-searching lines per step against 128 of the CSR form) and
 // run U steps ahead like FORM 0's.  All three forms add the same terms in the same order.
-template <int KP, int NW, int TILE, int LOSS, bool GRAD, int FORM>
+template <int KP, int NW, int TILE, int LOSS, bool GRAD, int FORM, bool COMPACT = false>
 __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a, const LaneArgs la) {
   constexpr bool CSR = FORM == 1;
+  static_assert(!COMPACT || (FORM == 0 && loss_mode(LOSS) != 2), "the compact stream: full-grid passes of sides without a descriptor id in the offset word");
   static_assert(FORM == 0 || FORM == 1 || (FORM == 2 && !GRAD), "the gathered form runs trial rounds only");
   static_assert(KP == 32, "one lane per segment: x, g and y of a segment in one lane's registers -- built for a padded rank of 32");
   constexpr int C = KP / 2;            // 16-byte chunks per vector
@@ -184,6 +190,18 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
       s1 = uniform_i64(s1);
     }
   }
+  // COMPACT: the values of a wave block are unpadded, so a lane finds its value of a step at (values before the step) + (busy lanes below
+  // it) -- a running wave-uniform count and a ballot; the offsets run one batch ahead of the values, and the first batch of a tile is
+  // requested a whole tile ahead, so that no round trip to the stream stands between a tile's staging and its first step
+  int64_t vrun = 0;
+  int rawT[U];
+  if constexpr (COMPACT) {
+    if (bp) vrun = uniform_i64(la.vptr[lwb * (int64_t)(la.ntiles + 1) + tb]);
+    const int n0 = (int)(s1 - s0);
+#pragma unroll
+    for (int u = 0; u < U; ++u) rawT[u] = (bp && u < n0) ? (int)la.off16[(s0 + u) * 64 + lane] : 0xFFFF;
+  }
+  auto below = [&](unsigned long long m) { return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
 #if GLRM_LANE_PREFETCH
   int pf0 = 0, pf1 = 0, pf2 = 0;
 #endif
@@ -201,7 +219,21 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
     int32_t off[U], noff[U];
     double av[U], nav[U];
     int n = 0;
-    if constexpr (!CSR) {
+    int raw1[U]; // COMPACT: the offsets of the batch after the current one
+    if constexpr (COMPACT) {
+      n = (int)(s1 - s0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = rawT[u];
+        const unsigned long long m = __ballot(r != 0xFFFF);
+        const bool v = have && r != 0xFFFF;
+        off[u] = v ? r * (KP * 8) : -1;
+        av[u] = v ? la.val[vrun + below(m)] : 0.0;
+        vrun += __popcll(m);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) raw1[u] = (bp && U + u < n) ? (int)la.off16[(s0 + U + u) * 64 + lane] : 0xFFFF;
+    } else if constexpr (!CSR) {
       n = (int)(s1 - s0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -230,7 +262,37 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
       if (l2 < nlines) asm volatile("global_load_dword %0, %1, off" : "=v"(pf2) : "v"(nsrc + (int64_t)l2 * 128) : "memory");
     }
 #endif
-    if constexpr (CSR) {
+    if constexpr (COMPACT) {
+      s2 = uniform_i64(s2);
+      const int nn = (int)(s2 - s1);
+#pragma unroll
+      for (int u = 0; u < U; ++u) rawT[u] = (bp && t + 1 < te && u < nn) ? (int)la.off16[(s1 + u) * 64 + lane] : 0xFFFF;
+      for (int i = 0; i < n; i += U) {
+        int raw2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { // batch i + U: its offsets have landed, its values are requested
+          const int r = raw1[u];
+          const unsigned long long m = __ballot(r != 0xFFFF);
+          const bool v = have && r != 0xFFFF;
+          noff[u] = v ? r * (KP * 8) : -1;
+          nav[u] = v ? la.val[vrun + below(m)] : 0.0;
+          vrun += __popcll(m);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) raw2[u] = (bp && i + 2 * U + u < n) ? (int)la.off16[(s0 + i + 2 * U + u) * 64 + lane] : 0xFFFF;
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (off[u] >= 0) entry(off[u], av[u], u & 1, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          off[u] = noff[u];
+          av[u] = nav[u];
+          raw1[u] = raw2[u];
+        }
+      }
+      s0 = s1;
+      s1 = s2;
+    } else if constexpr (CSR) {
       int e = 0;
       while (pos < end) {
         const int c = a.idx[pos];
@@ -281,7 +343,7 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
 
 // steps of (wave block, tile) = the longest run of the block's 64 segments inside the tile; one 64-thread workgroup per wave block
 static __global__ void __launch_bounds__(64) lane_count_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const int32_t* __restrict__ perm,
-                                                               int64_t nslots, int tile, int ntiles, int64_t* __restrict__ cnt) {
+                                                               int64_t nslots, int tile, int ntiles, int64_t* __restrict__ cnt, int64_t* __restrict__ vcnt) {
   const int lane = threadIdx.x;
   const int64_t wb = blockIdx.x, slot = wb * 64 + lane;
   const bool have = slot < nslots;
@@ -292,6 +354,12 @@ static __global__ void __launch_bounds__(64) lane_count_kernel(const int64_t* __
     const int64_t nxt = lower_bound_idx<1>(idx, pos, end, (int64_t)(t + 1) * tile);
     int c = (int)(nxt - pos);
     pos = nxt;
+    if (vcnt) { // the compact form: observations of the (wave block, tile), not only its steps
+      int sum = c;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) sum += __shfl_xor(sum, d, 64);
+      if (lane == 0) vcnt[wb * ntiles + t] = sum;
+    }
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
       const int o = __shfl_xor(c, d, 64);
@@ -337,6 +405,42 @@ static __global__ void __launch_bounds__(64) lane_fill_kernel(const int64_t* __r
       }
       off[s * 64 + lane] = o;
       val[s * 64 + lane] = v;
+    }
+  }
+}
+
+// the compact form of the stream (LaneArgs::off16 / vptr): padded 2-byte offsets, unpadded values
+static __global__ void __launch_bounds__(64) lane_fill_compact_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const double* __restrict__ vals,
+                                                                      const int32_t* __restrict__ perm, int64_t nslots, int tile, int ntiles, const int64_t* __restrict__ bptr,
+                                                                      const int64_t* __restrict__ vptr, uint16_t* __restrict__ off16, double* __restrict__ val) {
+  const int lane = threadIdx.x;
+  const int64_t wb = blockIdx.x, slot = wb * 64 + lane;
+  const bool have = slot < nslots;
+  const int64_t seg = have ? (perm ? (int64_t)perm[slot] : slot) : 0;
+  int64_t pos = have ? ptr[seg] : 0;
+  const int64_t end = have ? ptr[seg + 1] : 0;
+  const int64_t* bp = bptr + wb * (int64_t)(ntiles + 1);
+  int64_t vrun = vptr[wb * (int64_t)(ntiles + 1)];
+  for (int t = 0; t < ntiles; ++t) {
+    const int64_t lo = (int64_t)t * tile, hi = lo + tile;
+    const int64_t s1 = bp[t + 1];
+    for (int64_t s = bp[t]; s < s1; ++s) {
+      bool has = false;
+      int o = 0xFFFF;
+      double v = 0.0;
+      if (pos < end) {
+        const int c = idx[pos];
+        if (c < hi) {
+          has = true;
+          o = (int)(c - lo);
+          v = vals[pos];
+          ++pos;
+        }
+      }
+      off16[s * 64 + lane] = (uint16_t)o;
+      const unsigned long long m = __ballot(has);
+      if (has) val[vrun + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = v;
+      vrun += __popcll(m);
     }
   }
 }

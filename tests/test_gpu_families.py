@@ -586,10 +586,13 @@ def test_lane_trial_rounds_give_the_same_bits_in_every_form(monkeypatch, mixed):
         "older forms (full grid / CSR)": {"GLRM_HIP_LANE_ROUNDS": "0"},
         "gathered, chunk lists": {"GLRM_HIP_LANE_GATHER_TO": "101", "GLRM_HIP_LANE_GATHER_PACKED": "0"},
         "gathered, packed lists": {"GLRM_HIP_LANE_GATHER_TO": "101", "GLRM_HIP_LANE_GATHER_PACKED": "101", "GLRM_HIP_LANE_GATHER_SPREAD": "1000"},
+        # the COMPACT form of the stream (2-byte offsets padded, values unpadded: what views beyond 2e9 observations run) on every side it
+        # serves -- both views of the QuadLoss model, the column view of the model with a loss per column; its rounds: full grid / CSR
+        "compact stream": {"GLRM_HIP_LANE_COMPACT": "1"},
     }
     res = {}
     for name, env in forms.items():
-        for key in ("GLRM_HIP_LANE_ROUNDS", "GLRM_HIP_LANE_GATHER_TO", "GLRM_HIP_LANE_GATHER_PACKED", "GLRM_HIP_LANE_GATHER_SPREAD"):
+        for key in ("GLRM_HIP_LANE_ROUNDS", "GLRM_HIP_LANE_GATHER_TO", "GLRM_HIP_LANE_GATHER_PACKED", "GLRM_HIP_LANE_GATHER_SPREAD", "GLRM_HIP_LANE_COMPACT"):
             monkeypatch.delenv(key, raising=False)
         for key, v in env.items():
             monkeypatch.setenv(key, v)

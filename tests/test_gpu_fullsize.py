@@ -358,9 +358,9 @@ def test_c3_full_size_dense_path_and_oracle_spot_check(quad_gram):
 def test_c5_full_size_heterogeneous_columns_and_oracle_spot_check():
     """BASELINE configs[4] at its STATED size: 5M x 50k, rank 32, 5e9 observations, QuadLoss / LogisticLoss / OrdinalHingeLoss(1, 5) by
     column (f mod 3), QuadReg(1.0).  The 120 GB of lists are handed over in place (GLRM_PROBLEM_BORROW_DEVICE_ARRAYS); both half-steps
-    run on the LDS tiles: the row view in their lane-per-segment form (session r6_33: a 64 GB SELL stream with the descriptor ids in its
-    offset words, caller's order), the column view on the four-lane kernels (its padded stream would not fit beside the lists); in-kernel
-    fp64 exp / log.  One X half-step and one Y half-step are compared with the oracle on sampled rows (1 000 observations each, all three
+    run on the LDS tiles in their lane-per-segment form: the row view with a 64 GB SELL stream (descriptor ids in its offset words,
+    caller's order), the column view with the COMPACT stream (2-byte offsets padded x 1.76, values unpadded: 58 GB where the padded form
+    would need 105 -- session r6_40); in-kernel fp64 exp / log.  One X half-step and one Y half-step are compared with the oracle on sampled rows (1 000 observations each, all three
     loss kinds) and columns (100 000 observations each, one of every kind); the recorded objective is re-evaluated; offsets beyond 2^32."""
     import gc
     import torch
@@ -372,7 +372,7 @@ def test_c5_full_size_heterogeneous_columns_and_oracle_spot_check():
     h = api.create(w.problem(borrow=True), stream=torch.cuda.current_stream().cuda_stream)
     ld = api.factor_ld(h)
     st = api.kernel_stats(h)
-    assert ld == 32 and st["tiled"] == (3 | 256) and st["nnz_rows"] == m * q
+    assert ld == 32 and st["tiled"] == (3 | 256 | 512) and st["nnz_rows"] == m * q
     dX, dY = w.init_factors(ld)
     dC, dR = torch.zeros(n, dtype=torch.float64, device=dX.device), torch.zeros(m, dtype=torch.float64, device=dX.device)
     api.bind_buffers(h, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())

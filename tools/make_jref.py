@@ -67,7 +67,7 @@ def expected_orders(m, n, k, q, mixed=False):
     # distinct descriptors -- the bench recipes hold three).  Reported as the two-lane layout with the rotated chunk walk (rotate = 2); the row
     # view keeps the caller's order (no kind grouping)
     lane_r = tiled_r and kp == 32 and nnz <= 6_000_000_000
-    lane_c = tiled_c and kp == 32 and nnz <= 2_000_000_000
+    lane_c = tiled_c and kp == 32 and nnz <= 6_000_000_000   # (beyond 2e9 observations on the compact form of the stream: same sums)
     if tiled_r:
         rows.update(family=2, window=T, windows_per_sup=0, batch=G if mixed else 2, private_order=2 if mixed else 0)
         if lane_r:
