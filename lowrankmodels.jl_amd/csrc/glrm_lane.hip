@@ -248,6 +248,7 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
   auto csr_args = [&](const TiledArgs& t) { // the CSR form numbers its slots from 0 over t.nseg (a compact list or a plain range)
     LaneArgs c = la;
     c.slot0 = 0;
+    c.gwaves = 0;
     return c;
   };
   // gradient pass: under glrm_hip_step_y_arrival (columns) in runs of super-tiles, each behind the blocks of X it reads (announced order)
@@ -333,9 +334,13 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
       continue;
     }
     // (measured cross-over of the two older forms at about a sixth of the segments, session r6_20)
-    const bool compact = lists && ((int64_t)nact * 6 < full.nseg || !sell_ok);
+    const bool compact = lists && ((int64_t)nact * 100 < full.nseg * env_int("GLRM_HIP_LANE_CSR_BELOW", 16) || !sell_ok);
     if (trace >= 2) fprintf(stderr, "[glrm lane] %s round %d: %u of %lld segments search: %s\n", rows ? "row" : "column", round, nact, (long long)full.nseg, compact ? "CSR" : "SELL full grid");
     if (compact) {
+      // (tried in session r6_45/46 and taken out again: this form over class-aware wave lists -- conflict-free tile reads -- measured the same at
+      // full waves and worse spread over the chip; nor did batching its list reads move it.  A CSR round costs 2.8 x the full grid's time
+      // per workgroup and tile at C5's stated size: 512 lanes walk 512 lists 1.2 MB apart, which is an address-translation pattern, not a
+      // bandwidth or bank pattern.  Cross-over with the full grid stays at a sixth of the segments.)
       t.segperm = list[cur];
       t.nseg = nact;
       t.npass = 0;

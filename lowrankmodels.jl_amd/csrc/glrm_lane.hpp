@@ -175,6 +175,24 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
     end = have ? a.ptr[seg + 1] : 0;
     pos = have ? lower_bound_idx<1>(a.idx, beg, end, (int64_t)tb * TILE) : 0;
   }
+  // CSR form: the lane's list in batches of four entries (opposing index -- INT_MAX behind the end of the list --, value, descriptor id):
+  // batch A is being consumed (cursor qk), batch B is in flight; a batch's four loads go out back to back, so a line of the list is
+  // fetched once per batch instead of once per entry
+  int qa[4], qb[4], qda[4], qdb[4], qk = 0;
+  double qva[4], qvb[4];
+  int64_t qpos = pos; // list position of A[0]
+  auto qload = [&](int (&c)[4], double (&v)[4], int (&d)[4], int64_t p0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool more = CSR && p0 + j < end;
+      c[j] = more ? a.idx[p0 + j] : 0x7FFFFFFF;
+      v[j] = more ? a.vals[p0 + j] : 0.0;
+      d[j] = 0;
+      if constexpr (CSR && loss_mode(LOSS) == 2) d[j] = more ? (int)a.descid[p0 + j] : 0;
+    }
+  };
+  qload(qa, qva, qda, qpos);
+  qload(qb, qvb, qdb, qpos + 4);
   const bool wb_ok = CSR || (FORM == 2 ? have : wb < la.nwb);
   const int64_t* bp = (CSR || !wb_ok) ? nullptr : la.bptr + lwb * (int64_t)(la.ntiles + 1);
   // steps [s0, s1) of the current tile in the layout (FORM 0: the same in every lane of the wave -- loop control stays scalar; FORM 2: the
@@ -293,15 +311,30 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
       s0 = s1;
       s1 = s2;
     } else if constexpr (CSR) {
+      // (session r6_43/44; before: index, value and descriptor id were requested when the step needed them.  Measured the same: what this form
+      // pays is the address translation of 512 lists far apart, see glrm_run_lane)
       int e = 0;
-      while (pos < end) {
-        const int c = a.idx[pos];
-        if (c >= (int)hi) break;
-        int did = 0;
-        if constexpr (loss_mode(LOSS) == 2) did = a.descid[pos];
-        entry((c - (int)lo) * (KP * 8), a.vals[pos], e & 1, did);
-        ++pos;
-        ++e;
+      for (;;) {
+        const int hc = qk == 0 ? qa[0] : qk == 1 ? qa[1] : qk == 2 ? qa[2] : qa[3];
+        const bool go = hc < (int)hi;
+        if (__any(go) == 0) break;
+        if (go) {
+          const double hv = qk == 0 ? qva[0] : qk == 1 ? qva[1] : qk == 2 ? qva[2] : qva[3];
+          const int hd = qk == 0 ? qda[0] : qk == 1 ? qda[1] : qk == 2 ? qda[2] : qda[3];
+          entry((hc - (int)lo) * (KP * 8), hv, e & 1, hd);
+          ++e;
+          if (++qk == 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              qa[j] = qb[j];
+              qva[j] = qvb[j];
+              qda[j] = qdb[j];
+            }
+            qload(qb, qvb, qdb, qpos + 8);
+            qpos += 4;
+            qk = 0;
+          }
+        }
       }
     } else {
       // (i stays a multiple of U, U even: step i + u of a segment's window sits at position parity u & 1)
