@@ -84,6 +84,8 @@ struct glrm_handle {
   int lane_ntiles[2] = {0, 0};
   uint16_t* lane_off16[2] = {nullptr, nullptr}; // the compact form of the stream (glrm_lane.hpp: LaneArgs::off16 / vptr) of the sides that run it
   int64_t* lane_vptr[2] = {nullptr, nullptr};
+  int32_t* lane_sval[2] = {nullptr, nullptr};
+  int lane_dealt[2] = {0, 0};                    // the side's sorted slot permutation was dealt out by class (make_segperm): slot s holds a segment of class s & 15
   int32_t* lane_inv[2] = {nullptr, nullptr};   // local segment -> slot of the layout (sides whose slots are permuted); -1 = not in the layout
   // trial rounds read out of the SELL layout (lane_pass_kernel FORM 2): the still-searching segments class by class, rebuilt every round
   int32_t *lane_gcnt = nullptr, *lane_gbase = nullptr, *lane_gtotal = nullptr, *lane_glist = nullptr;

@@ -587,7 +587,7 @@ extern "C" void glrm_hip_destroy(glrm_handle* h) {
                   h->mobjold, h->mactive, h->mnactive, h->colperm, h->rowperm, h->seglist_r, h->seglist_c, h->rowdescid, h->udesc,
                   h->gramH, h->gram_part, h->jloss_r, h->jloss_c, h->lock_ctr, h->actlist, h->blk_perm_c, h->blk_long_c,
                   h->lane_bptr[0], h->lane_bptr[1], h->lane_off[0], h->lane_off[1], h->lane_val[0], h->lane_val[1],
-                  h->lane_inv[0], h->lane_inv[1], h->lane_off16[0], h->lane_off16[1], h->lane_vptr[0], h->lane_vptr[1], h->lane_gcnt, h->lane_gbase, h->lane_gtotal, h->lane_glist};
+                  h->lane_inv[0], h->lane_inv[1], h->lane_off16[0], h->lane_off16[1], h->lane_vptr[0], h->lane_vptr[1], h->lane_sval[0], h->lane_sval[1], h->lane_gcnt, h->lane_gbase, h->lane_gtotal, h->lane_glist};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->iter_exec) (void)hipGraphExecDestroy(h->iter_exec);

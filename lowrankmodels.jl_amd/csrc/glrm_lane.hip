@@ -48,8 +48,16 @@ int launch_lane_loss(int loss, const TiledArgs& a, const LaneArgs& la, int64_t n
         default: return fail(GLRM_ERR_UNSUPPORTED, "lane-per-segment passes, compact stream: no kernel for loss variant %d", loss);
       }
     }
-  } else if (FORM == 2 && la.off16) {
-    return fail(GLRM_ERR_UNSUPPORTED, "lane-per-segment passes: the gathered form does not read the compact stream");
+  } else if constexpr (FORM == 2 && !GRAD) {
+    if (la.off16) {
+      if (!la.sval) return fail(GLRM_ERR_UNSUPPORTED, "lane-per-segment passes: the gathered form needs the step bases of the compact stream");
+      switch (loss) {
+        case LOSS_QUAD_UNIFORM: return launch_lane_inst<0, false, 2, true>(a, la, nblocks, st);
+        case LOSS_SEGMENT: return launch_lane_inst<1, false, 2, true>(a, la, nblocks, st);
+        case LOSS_SEGMENT_NOTRIG: return launch_lane_inst<3, false, 2, true>(a, la, nblocks, st);
+        default: return fail(GLRM_ERR_UNSUPPORTED, "lane-per-segment passes, compact stream: no kernel for loss variant %d", loss);
+      }
+    }
   }
   switch (loss) {
     case LOSS_QUAD_UNIFORM: return launch_lane_inst<0, GRAD, FORM>(a, la, nblocks, st);
@@ -138,7 +146,8 @@ int glrm_setup_lane(glrm_handle* h) {
     if (ncell > (int64_t)1 << 30) { h->lane[side] = 0; continue; } // (cannot happen at shapes the LDS tiles are chosen for)
     // the compact form of the stream for this side?  A function of the whole problem (view size, losses, options), like the family itself
     const int cmode = env_int("GLRM_HIP_LANE_COMPACT", 2);
-    const bool compact = !(rows && h->n_losses > 1) && (cmode == 1 || (cmode == 2 && (rows ? h->sig.nnz_rows : h->sig.nnz_cols) > 2000000000ll));
+    const bool compact = !(rows && h->n_losses > 1) && (cmode == 1 || (cmode == 2 && (rows ? h->sig.nnz_rows : h->sig.nnz_cols) > 2000000000ll)) &&
+                         64 * (rows ? h->sig.max_row_len : h->sig.max_col_len) < ((int64_t)1 << 31); // (a wave block's values are counted in 31 bits: LaneArgs::sval)
     int64_t *cnt = nullptr, *scan = nullptr, *vcnt = nullptr;
     void* tmp = nullptr;
     auto cleanup = [&](int rc) { (void)hipFree(cnt); (void)hipFree(scan); (void)hipFree(vcnt); (void)hipFree(tmp); return rc; };
@@ -166,13 +175,14 @@ int glrm_setup_lane(glrm_handle* h) {
       if (hipMalloc((void**)&h->lane_vptr[side], (size_t)nwb * (ntiles + 1) * 8) != hipSuccess) return cleanup(fail(GLRM_ERR_OOM, "out of device memory"));
       hipLaunchKernelGGL(lane_bptr_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, scan, vcnt, nwb, ntiles, h->lane_vptr[side]);
       const int64_t nv = std::max<int64_t>(1, rows ? h->nnz_r : h->nnz_c);
-      const bool ok = hipMalloc((void**)&h->lane_off16[side], (size_t)s1 * 64 * 2) == hipSuccess && hipMalloc((void**)&h->lane_val[side], (size_t)nv * 8) == hipSuccess;
+      const bool ok = hipMalloc((void**)&h->lane_off16[side], (size_t)s1 * 64 * 2) == hipSuccess && hipMalloc((void**)&h->lane_sval[side], (size_t)s1 * 4) == hipSuccess &&
+                      hipMalloc((void**)&h->lane_val[side], (size_t)nv * 8) == hipSuccess;
       if (!ok) {
         // No room for the stream beside the lists: the side stays on the four-lane kernels.  (The only family choice that can depend on
         // the device rather than on the problem; glrm_hip_sum_order reports what runs, and the super-tile geometry is already fixed.)
         (void)hipGetLastError();
-        (void)hipFree(h->lane_off16[side]); (void)hipFree(h->lane_val[side]); (void)hipFree(h->lane_vptr[side]); (void)hipFree(h->lane_bptr[side]);
-        h->lane_off16[side] = nullptr; h->lane_val[side] = nullptr; h->lane_vptr[side] = nullptr; h->lane_bptr[side] = nullptr;
+        (void)hipFree(h->lane_off16[side]); (void)hipFree(h->lane_sval[side]); (void)hipFree(h->lane_val[side]); (void)hipFree(h->lane_vptr[side]); (void)hipFree(h->lane_bptr[side]);
+        h->lane_off16[side] = nullptr; h->lane_sval[side] = nullptr; h->lane_val[side] = nullptr; h->lane_vptr[side] = nullptr; h->lane_bptr[side] = nullptr;
         h->lane[side] = 0;
         h->lane_steps[side] = 0;
         fprintf(stderr, "[glrm lane] no device memory for the compact stream of the %s view (%.1f GB): the view stays on the four-lane LDS-tiled kernels\n", rows ? "row" : "column",
@@ -181,7 +191,7 @@ int glrm_setup_lane(glrm_handle* h) {
         continue;
       }
       hipLaunchKernelGGL(lane_fill_compact_kernel, dim3((unsigned)nwb), dim3(64), 0, st, ptr, idx, vals, perm, nslots, T, ntiles, h->lane_bptr[side], h->lane_vptr[side],
-                         h->lane_off16[side], h->lane_val[side]);
+                         h->lane_off16[side], h->lane_sval[side], h->lane_val[side]);
     } else {
       if (hipMalloc((void**)&h->lane_off[side], (size_t)s1 * 64 * 4) != hipSuccess || hipMalloc((void**)&h->lane_val[side], (size_t)s1 * 64 * 8) != hipSuccess)
         return cleanup(fail(GLRM_ERR_OOM, "out of device memory for the lane-per-segment stream of the %s view (%lld steps of 64 entries)", rows ? "row" : "column", (long long)steps));
@@ -225,6 +235,7 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
   la.val = h->lane_val[side];
   la.off16 = h->lane_off16[side];
   la.vptr = h->lane_vptr[side];
+  la.sval = h->lane_sval[side];
   la.ntiles = h->lane_ntiles[side];
   la.nwb = h->lane_nwb[side];
   la.slot0 = 0;
@@ -266,7 +277,7 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
   HIPCK(hipGetLastError());
   if (eval_only) return GLRM_OK;
   const TiledArgs full = a;
-  const bool gather = env_int("GLRM_HIP_LANE_ROUNDS", 1) != 0 && sell_ok && h->lane_glist && la.bptr && h->lane_steps[side] > 0 && !la.off16 &&
+  const bool gather = env_int("GLRM_HIP_LANE_ROUNDS", 1) != 0 && sell_ok && h->lane_glist && la.bptr && h->lane_steps[side] > 0 &&
                       full.nseg <= h->lane_gchunks * (int64_t)LANE_CC;
   constexpr int MAX_ROUNDS = 4096; // see glrm_run_tiled
   for (int round = 0;; ++round) {
@@ -289,7 +300,10 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
     // 5.4 at 32 %, 3.1 at 12 %, 1.5-2.1 for the tails.
     const int64_t pct = (int64_t)nact * 100 / (full.nseg > 0 ? full.nseg : 1);
     bool packed = lists && (int64_t)nact * 100 < full.nseg * env_int("GLRM_HIP_LANE_GATHER_PACKED", 4);
-    bool use_gather = gather && (!la.inv || packed) && pct >= env_int("GLRM_HIP_LANE_GATHER_FROM", 0) && pct < env_int("GLRM_HIP_LANE_GATHER_TO", 70);
+    // (sides with permuted slots: chunk lists over the SLOTS, which were dealt out class by class -- make_segperm)
+    const int32_t* gperm = la.inv ? full.segperm : nullptr;
+    const bool chunks_ok = !la.inv || (h->lane_dealt[side] && gperm && env_int("GLRM_HIP_LANE_GATHER_SLOTS", 1));
+    bool use_gather = gather && (chunks_ok || packed) && pct >= env_int("GLRM_HIP_LANE_GATHER_FROM", 0) && pct < env_int("GLRM_HIP_LANE_GATHER_TO", 70);
     int32_t gwaves = 0;
     if (use_gather) {
       const int off16 = (int)(full.own_offset & 15);
@@ -303,15 +317,16 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
         HIPCK(hipStreamSynchronize(st));
         if (gwaves < 0) { // (one class holds nearly every entry: the waves would not fit the list)
           packed = false;
-          if (la.inv) use_gather = false;
+          if (!chunks_ok) use_gather = false;
         }
       }
       if (use_gather && !packed) {
-        const int64_t nchunks = (full.nseg + LANE_CC - 1) / LANE_CC;
+        const int64_t nitems = gperm ? (full.npass > 0 ? full.npass : full.nseg) : full.nseg;
+        const int64_t nchunks = (nitems + LANE_CC - 1) / LANE_CC;
         const unsigned cg = (unsigned)((nchunks + 3) / 4);
-        hipLaunchKernelGGL(lane_compact_count_kernel, dim3(cg), dim3(256), 0, st, full.active, full.nseg, nchunks, h->lane_gcnt);
+        hipLaunchKernelGGL(lane_compact_count_kernel, dim3(cg), dim3(256), 0, st, full.active, nitems, nchunks, gperm, h->lane_gcnt);
         hipLaunchKernelGGL(lane_compact_scan_kernel, dim3(1), dim3(1024), 0, st, h->lane_gcnt, nchunks, h->lane_gbase, h->lane_gtotal);
-        hipLaunchKernelGGL(lane_compact_fill_kernel, dim3(cg), dim3(256), 0, st, full.active, full.nseg, nchunks, off16, h->lane_gbase, h->lane_glist);
+        hipLaunchKernelGGL(lane_compact_fill_kernel, dim3(cg), dim3(256), 0, st, full.active, nitems, nchunks, gperm ? 0 : off16, gperm, h->lane_gbase, h->lane_glist);
         HIPCK(hipGetLastError());
         HIPCK(hipMemcpyAsync(&gwaves, h->lane_gtotal, 4, hipMemcpyDeviceToHost, st));
         HIPCK(hipStreamSynchronize(st));

@@ -49,8 +49,12 @@ struct LaneArgs {
   // COMPACT form of the stream (views whose padded copy would not fit: C5's column view at its stated size): 2-byte offsets (tile-local
   // index of the staged vector, 0xFFFF = idle lane) in the padded [steps][64] arrangement, the VALUES unpadded -- a step's values are those
   // of its busy lanes in lane order, the steps of a wave block back to back; vptr[wave block][tile] = index of the tile's first value
+  // offset word: bits 0-9 the tile-local index, bits 10-15 the lane's rank among the busy lanes of its step; sval[step] = values of the wave
+  // block before the step (with vptr[wave block][0] the index of the step's first value): what a lane of a GATHERED wave (FORM 2) finds its
+  // value by, where the full grid counts along
   const uint16_t* off16; // nullptr: the padded form above
   const int64_t* vptr;
+  const int32_t* sval;
   int ntiles;          // tiles of the opposing factor (stride of bptr minus one)
   int64_t nwb;         // wave blocks the layout holds (a launch rounds its grid up to whole workgroups: blocks beyond have no steps)
   int64_t slot0;       // local id of TiledArgs' segment 0 in the slot space the layout was built on (row sub-ranges: glrm_hip_step_x_range)
@@ -77,7 +81,8 @@ __device__ __forceinline__ int64_t uniform_i64(int64_t v) {
 template <int KP, int NW, int TILE, int LOSS, bool GRAD, int FORM, bool COMPACT = false>
 __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a, const LaneArgs la) {
   constexpr bool CSR = FORM == 1;
-  static_assert(!COMPACT || (FORM == 0 && loss_mode(LOSS) != 2), "the compact stream: full-grid passes of sides without a descriptor id in the offset word");
+  static_assert(!COMPACT || (FORM != 1 && loss_mode(LOSS) != 2), "the compact stream: sides without a descriptor id in the offset word");
+  constexpr bool CF0 = COMPACT && FORM == 0, CF2 = COMPACT && FORM == 2;
   static_assert(FORM == 0 || FORM == 1 || (FORM == 2 && !GRAD), "the gathered form runs trial rounds only");
   static_assert(KP == 32, "one lane per segment: x, g and y of a segment in one lane's registers -- built for a padded rank of 32");
   constexpr int C = KP / 2;            // 16-byte chunks per vector
@@ -213,7 +218,11 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
   // requested a whole tile ahead, so that no round trip to the stream stands between a tile's staging and its first step
   int64_t vrun = 0;
   int rawT[U];
-  if constexpr (COMPACT) {
+  int64_t vblk = 0; // CF2: index of the lane's wave block's first value
+  if constexpr (CF2) {
+    if (bp) vblk = la.vptr[lwb * (int64_t)(la.ntiles + 1)];
+  }
+  if constexpr (CF0) {
     if (bp) vrun = uniform_i64(la.vptr[lwb * (int64_t)(la.ntiles + 1) + tb]);
     const int n0 = (int)(s1 - s0);
 #pragma unroll
@@ -238,14 +247,25 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
     double av[U], nav[U];
     int n = 0;
     int raw1[U]; // COMPACT: the offsets of the batch after the current one
-    if constexpr (COMPACT) {
+    int sv1[U], rw0[U], sb0[U]; // CF2: the batch's step bases; the first batch of the tile
+    if constexpr (CF2) {
+      n = (int)(s1 - s0);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool v = have && u < n, w = have && U + u < n;
+        rw0[u] = v ? (int)la.off16[(s0 + u) * 64 + ll] : 0xFFFF;
+        sb0[u] = v ? la.sval[s0 + u] : 0;
+        raw1[u] = w ? (int)la.off16[(s0 + U + u) * 64 + ll] : 0xFFFF;
+        sv1[u] = w ? la.sval[s0 + U + u] : 0;
+      }
+    } else if constexpr (CF0) {
       n = (int)(s1 - s0);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int r = rawT[u];
         const unsigned long long m = __ballot(r != 0xFFFF);
         const bool v = have && r != 0xFFFF;
-        off[u] = v ? r * (KP * 8) : -1;
+        off[u] = v ? (r & 1023) * (KP * 8) : -1;
         av[u] = v ? la.val[vrun + below(m)] : 0.0;
         vrun += __popcll(m);
       }
@@ -280,7 +300,44 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
       if (l2 < nlines) asm volatile("global_load_dword %0, %1, off" : "=v"(pf2) : "v"(nsrc + (int64_t)l2 * 128) : "memory");
     }
 #endif
-    if constexpr (COMPACT) {
+    if constexpr (CF2) {
+      // (the first batch's values wait for its offsets: one exposed round trip per tile -- these are rounds, not passes)
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = rw0[u];
+        const bool v = r != 0xFFFF;
+        off[u] = v ? (r & 1023) * (KP * 8) : -1;
+        av[u] = v ? la.val[vblk + sb0[u] + (r >> 10)] : 0.0;
+      }
+      for (int i = 0; __any(i < n) != 0; i += U) {
+        int raw2[U], sv2[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int r = raw1[u];
+          const bool v = r != 0xFFFF;
+          noff[u] = v ? (r & 1023) * (KP * 8) : -1;
+          nav[u] = v ? la.val[vblk + sv1[u] + (r >> 10)] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const bool w = have && i + 2 * U + u < n;
+          raw2[u] = w ? (int)la.off16[(s0 + i + 2 * U + u) * 64 + ll] : 0xFFFF;
+          sv2[u] = w ? la.sval[s0 + i + 2 * U + u] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+          if (off[u] >= 0) entry(off[u], av[u], u & 1, 0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          off[u] = noff[u];
+          av[u] = nav[u];
+          raw1[u] = raw2[u];
+          sv1[u] = sv2[u];
+        }
+      }
+      s0 = s1;
+      s1 = s2;
+    } else if constexpr (CF0) {
       s2 = uniform_i64(s2);
       const int nn = (int)(s2 - s1);
 #pragma unroll
@@ -292,7 +349,7 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
           const int r = raw1[u];
           const unsigned long long m = __ballot(r != 0xFFFF);
           const bool v = have && r != 0xFFFF;
-          noff[u] = v ? r * (KP * 8) : -1;
+          noff[u] = v ? (r & 1023) * (KP * 8) : -1;
           nav[u] = v ? la.val[vrun + below(m)] : 0.0;
           vrun += __popcll(m);
         }
@@ -445,7 +502,8 @@ static __global__ void __launch_bounds__(64) lane_fill_kernel(const int64_t* __r
 // the compact form of the stream (LaneArgs::off16 / vptr): padded 2-byte offsets, unpadded values
 static __global__ void __launch_bounds__(64) lane_fill_compact_kernel(const int64_t* __restrict__ ptr, const int32_t* __restrict__ idx, const double* __restrict__ vals,
                                                                       const int32_t* __restrict__ perm, int64_t nslots, int tile, int ntiles, const int64_t* __restrict__ bptr,
-                                                                      const int64_t* __restrict__ vptr, uint16_t* __restrict__ off16, double* __restrict__ val) {
+                                                                      const int64_t* __restrict__ vptr, uint16_t* __restrict__ off16, int32_t* __restrict__ sval,
+                                                                      double* __restrict__ val) {
   const int lane = threadIdx.x;
   const int64_t wb = blockIdx.x, slot = wb * 64 + lane;
   const bool have = slot < nslots;
@@ -453,7 +511,8 @@ static __global__ void __launch_bounds__(64) lane_fill_compact_kernel(const int6
   int64_t pos = have ? ptr[seg] : 0;
   const int64_t end = have ? ptr[seg + 1] : 0;
   const int64_t* bp = bptr + wb * (int64_t)(ntiles + 1);
-  int64_t vrun = vptr[wb * (int64_t)(ntiles + 1)];
+  const int64_t v0 = vptr[wb * (int64_t)(ntiles + 1)];
+  int64_t vrun = v0;
   for (int t = 0; t < ntiles; ++t) {
     const int64_t lo = (int64_t)t * tile, hi = lo + tile;
     const int64_t s1 = bp[t + 1];
@@ -470,9 +529,11 @@ static __global__ void __launch_bounds__(64) lane_fill_compact_kernel(const int6
           ++pos;
         }
       }
-      off16[s * 64 + lane] = (uint16_t)o;
       const unsigned long long m = __ballot(has);
-      if (has) val[vrun + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = v;
+      const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      off16[s * 64 + lane] = (uint16_t)(has ? (o | (rank << 10)) : 0xFFFF); // (tile-local index below 1 024: the tile holds 560 vectors)
+      if (has) val[vrun + rank] = v;
+      if (lane == 0) sval[s] = (int32_t)(vrun - v0);
       vrun += __popcll(m);
     }
   }
@@ -489,13 +550,14 @@ static __global__ void __launch_bounds__(64) lane_fill_compact_kernel(const int6
 // ~20 % at half the segments searching).  Three small launches per round: waves per chunk, exclusive scan, fill.
 constexpr int LANE_CC = 1024;
 
-__device__ __forceinline__ unsigned lane_chunk_mask(const int32_t* __restrict__ active, int64_t nseg, int64_t chunk, int lane) {
-  const int64_t seg0 = chunk * LANE_CC + (int64_t)(lane >> 4) * 256 + (lane & 15);
+// (perm != nullptr: the chunks are chunks of SLOTS of a permuted layout -- dealt out class by class, so slot s holds a segment of class s & 15)
+__device__ __forceinline__ unsigned lane_chunk_mask(const int32_t* __restrict__ active, int64_t nitems, int64_t chunk, int lane, const int32_t* __restrict__ perm) {
+  const int64_t i0 = chunk * LANE_CC + (int64_t)(lane >> 4) * 256 + (lane & 15);
   unsigned m = 0;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    const int64_t seg = seg0 + j * 16;
-    if (seg < nseg && active[seg] != 0) m |= 1u << j;
+    const int64_t i = i0 + j * 16;
+    if (i < nitems && active[perm ? (int64_t)perm[i] : i] != 0) m |= 1u << j;
   }
   return m;
 }
@@ -512,11 +574,12 @@ __device__ __forceinline__ int lane_chunk_waves(int cnt) {
   return (c + 3) / 4;
 }
 
-static __global__ void __launch_bounds__(256) lane_compact_count_kernel(const int32_t* __restrict__ active, int64_t nseg, int64_t nchunks, int32_t* __restrict__ nwv) {
+static __global__ void __launch_bounds__(256) lane_compact_count_kernel(const int32_t* __restrict__ active, int64_t nseg, int64_t nchunks, const int32_t* __restrict__ perm,
+                                                                        int32_t* __restrict__ nwv) {
   const int lane = threadIdx.x & 63;
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (chunk >= nchunks) return;
-  const int nw = lane_chunk_waves(__popc(lane_chunk_mask(active, nseg, chunk, lane)));
+  const int nw = lane_chunk_waves(__popc(lane_chunk_mask(active, nseg, chunk, lane, perm)));
   if (lane == 0) nwv[chunk] = nw;
 }
 
@@ -548,12 +611,12 @@ static __global__ void __launch_bounds__(1024) lane_compact_scan_kernel(const in
   if (threadIdx.x == 0) total[0] = carry;
 }
 
-static __global__ void __launch_bounds__(256) lane_compact_fill_kernel(const int32_t* __restrict__ active, int64_t nseg, int64_t nchunks, int off16, const int32_t* __restrict__ wbase,
-                                                                       int32_t* __restrict__ glist) {
+static __global__ void __launch_bounds__(256) lane_compact_fill_kernel(const int32_t* __restrict__ active, int64_t nseg, int64_t nchunks, int off16, const int32_t* __restrict__ perm,
+                                                                       const int32_t* __restrict__ wbase, int32_t* __restrict__ glist) {
   const int lane = threadIdx.x & 63;
   const int64_t chunk = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (chunk >= nchunks) return;
-  const unsigned m = lane_chunk_mask(active, nseg, chunk, lane);
+  const unsigned m = lane_chunk_mask(active, nseg, chunk, lane, perm);
   const int cnt = __popc(m);
   const int nw = lane_chunk_waves(cnt);
   const int64_t w0 = wbase[chunk];
@@ -573,6 +636,7 @@ static __global__ void __launch_bounds__(256) lane_compact_fill_kernel(const int
               --r;
             }
           seg = (int)(chunk * LANE_CC) + sub * 256 + j * 16 + csk;
+          if (perm) seg = perm[seg];
           rem = -1;
         } else {
           rem -= c;

@@ -59,6 +59,7 @@ static int make_segperm(glrm_handle* h, bool rows, int32_t** out, int64_t long_f
     // C5 recipe at 1M rows, columns sorted by kind and length): bank conflicts in 48 % of the column passes' LDS cycles.
     std::vector<int32_t> q[16];
     const int64_t g0 = rows ? h->rb : h->cb;
+    h->lane_dealt[rows ? 0 : 1] = 1;
     for (int32_t sgm : perm) q[(g0 + sgm) & 15].push_back(sgm);
     size_t head[16] = {0};
     for (int64_t slot = 0; slot < nslots; ++slot) {
