@@ -293,9 +293,10 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
     // Three forms of the trial pass, all adding the same terms in the same order (tests/test_gpu_families.py forces each of them on every
     // round).  FORM 0 walks the SELL layout over the full grid (idle segments masked): the cost of a whole pass whatever the fraction that
     // searches -- from 70 % up.  FORM 2 reads the layout through gathered waves (glrm_lane.hpp): waves built chunk by chunk of 1 024
-    // segments while a wave's lanes can share lines (sides whose slots are the segments in order), packed from the decide kernel's compact
-    // list and spread over the chip for the tail rounds (any side).  The CSR form (one lane walks its own list, nothing in flight: 3-5 ms
-    // for any tail round) is what remains for the middle fractions of sides with permuted slots and for sub-ranges the layout does not
+    // segments (or SLOTS, where the layout's slots are permuted: they were dealt out class by class) so that a wave's lanes share lines,
+    // packed from the decide kernel's compact list and spread over the chip for the tail rounds.  On the compact stream a lane finds its
+    // value through the rank in its offset word and the step's base.  The CSR form (one lane walks its own list: the address translation
+    // of 512 lists far apart, 3-5 ms for any tail round) is what remains for sub-ranges the layout does not
     // cover.  C5 recipe, 1M rows, X half-step (profiles/r06_c5family_lane_rounds_trace.txt): full grid 9.85 ms; gathered 7.8 ms at 55 %,
     // 5.4 at 32 %, 3.1 at 12 %, 1.5-2.1 for the tails.
     const int64_t pct = (int64_t)nact * 100 / (full.nseg > 0 ? full.nseg : 1);
