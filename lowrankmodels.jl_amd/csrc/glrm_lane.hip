@@ -292,7 +292,7 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
     const int trace = env_int("GLRM_HIP_LANE_TRACE", 0);
     // Three forms of the trial pass, all adding the same terms in the same order (tests/test_gpu_families.py forces each of them on every
     // round).  FORM 0 walks the SELL layout over the full grid (idle segments masked): the cost of a whole pass whatever the fraction that
-    // searches -- from 70 % up.  FORM 2 reads the layout through gathered waves (glrm_lane.hpp): waves built chunk by chunk of 1 024
+    // searches -- from 70 % up (sweep at C5's stated size, session r6_50: 55 / 70 / 85 % = 344.5 / 341.6 / 340.5 ms: flat).  FORM 2 reads the layout through gathered waves (glrm_lane.hpp): waves built chunk by chunk of 1 024
     // segments (or SLOTS, where the layout's slots are permuted: they were dealt out class by class) so that a wave's lanes share lines,
     // packed from the decide kernel's compact list and spread over the chip for the tail rounds.  On the compact stream a lane finds its
     // value through the rank in its offset word and the step's base.  The CSR form (one lane walks its own list: the address translation
