@@ -69,6 +69,22 @@ int launch_lane_loss(int loss, const TiledArgs& a, const LaneArgs& la, int64_t n
   }
 }
 
+// a wave per segment, no tile: the tail rounds of a side with one super-tile (glrm_lane.hpp: lane_tail_kernel)
+constexpr int LANE_TAIL_CAP = 2048; // entries of a segment it parks in LDS
+int launch_lane_tail(int loss, const TiledArgs& a, const int32_t* list, int nact, hipStream_t st) {
+  constexpr int KP = 32, T = lane_tile_rows(KP);
+  const unsigned gx = (unsigned)((nact + 1) / 2);
+  switch (loss) {
+    case LOSS_QUAD_UNIFORM: hipLaunchKernelGGL((lane_tail_kernel<KP, 0, LANE_TAIL_CAP>), dim3(gx), dim3(128), 0, st, a, list, nact, T); break;
+    case LOSS_SEGMENT: hipLaunchKernelGGL((lane_tail_kernel<KP, 1, LANE_TAIL_CAP>), dim3(gx), dim3(128), 0, st, a, list, nact, T); break;
+    case LOSS_SEGMENT_NOTRIG: hipLaunchKernelGGL((lane_tail_kernel<KP, 3, LANE_TAIL_CAP>), dim3(gx), dim3(128), 0, st, a, list, nact, T); break;
+    case LOSS_PER_OBS: hipLaunchKernelGGL((lane_tail_kernel<KP, 2, LANE_TAIL_CAP>), dim3(gx), dim3(128), 0, st, a, list, nact, T); break;
+    case LOSS_PER_OBS_NOTRIG: hipLaunchKernelGGL((lane_tail_kernel<KP, 4, LANE_TAIL_CAP>), dim3(gx), dim3(128), 0, st, a, list, nact, T); break;
+    default: return fail(GLRM_ERR_UNSUPPORTED, "lane-per-segment passes: no tail kernel for loss variant %d", loss);
+  }
+  return GLRM_OK;
+}
+
 // the small kernels of the pass machinery in the two-lane layout the family's sums are reported in
 void launch_small(int which, const TiledArgs& a, hipStream_t st) {
   constexpr int G = 2, R = 16;
@@ -300,6 +316,20 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
     // cover.  C5 recipe, 1M rows, X half-step (profiles/r06_c5family_lane_rounds_trace.txt): full grid 9.85 ms; gathered 7.8 ms at 55 %,
     // 5.4 at 32 %, 3.1 at 12 %, 1.5-2.1 for the tails.
     const int64_t pct = (int64_t)nact * 100 / (full.nseg > 0 ? full.nseg : 1);
+    // Tail rounds of a side with one super-tile whose segments fit the kernel's LDS parking (rows of up to 2 048 observations): a wave per
+    // segment instead of a lane's serial walk through every tile (1.5-9 ms per round at C5's stated size, eight to ten of them per X
+    // half-step) -- below GLRM_HIP_LANE_TAIL percent of the segments
+    if (lists && full.nsup == 1 && (rows ? h->sig.max_row_len : h->sig.max_col_len) <= LANE_TAIL_CAP && (int64_t)nact * 100 < full.nseg * (int64_t)env_int("GLRM_HIP_LANE_TAIL", 5)) {
+      if (trace >= 2) fprintf(stderr, "[glrm lane] %s round %d: %u of %lld segments search: a wave per segment\n", rows ? "row" : "column", round, nact, (long long)full.nseg);
+      if ((rc = launch_lane_tail(loss, full, list[cur], (int)nact, st))) return rc;
+      d.actlist_in = list[cur];
+      d.actlist_out = list[cur ^ 1];
+      d.nact_in = nact;
+      cur ^= 1;
+      launch_small(1, d, st);
+      HIPCK(hipGetLastError());
+      continue;
+    }
     bool packed = lists && (int64_t)nact * 100 < full.nseg * env_int("GLRM_HIP_LANE_GATHER_PACKED", 4);
     // (sides with permuted slots: chunk lists over the SLOTS, which were dealt out class by class -- make_segperm)
     const int32_t* gperm = la.inv ? full.segperm : nullptr;

@@ -429,6 +429,90 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
   }
 }
 
+// ---- tail rounds of a side with ONE super-tile (rows): a wave per segment, no tile ---------------------------------------------------
+// A trial round over a few segments still pays a lane's serial walk through every tile of the opposing factor (~1.5 ms for a row of C5
+// whatever the number of rows, 8-10 such rounds per X half-step).  Here a WAVE takes one segment: lane l evaluates the entries l, l + 64, ...
+// of its list with the vectors read straight from memory -- the same two fma chains over the chunks i ^ p, the same loss formula, so the same
+// term bit for bit -- and the terms are then added as the passes add them: two sequential sums over the entries at even / odd position inside
+// their tile window, in list order (the terms are parked in LDS, compacted by parity; lanes 0 and 1 run the two chains).
+template <int KP, int LOSS, int CAP>
+__global__ void __launch_bounds__(128) lane_tail_kernel(const TiledArgs a, const int32_t* __restrict__ list, int nact, int tile) {
+  constexpr int C = KP / 2, PSTRIDE = KP + 2;
+  __shared__ double ebuf[2][CAP], obuf[2][CAP / 2 + 32];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int w = (int)blockIdx.x * 2 + wv;
+  if (w >= nact) return; // (wave-uniform)
+  const int64_t seg = list[w];
+  const int64_t gseg = a.own_offset + seg;
+  const int p = (int)(gseg & (C - 1));
+  const double2* xp = reinterpret_cast<const double2*>(a.trial + seg * (int64_t)KP);
+  double2 x[C];
+#pragma unroll
+  for (int i = 0; i < C; ++i) x[i] = xp[i ^ p];
+  LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
+  if constexpr (loss_mode(LOSS) != 2) segloss = load_loss(a.losses, a.loss_by_segment ? gseg : 0);
+  const int64_t beg = a.ptr[seg];
+  const int len = (int)(a.ptr[seg + 1] - beg);
+  const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane)), upto = below | (1ull << lane);
+  int ne = 0, no = 0, wfirst = 0, prevtile = -1; // entries parked so far by parity; first entry of the window in progress; tile of the entry before the batch
+  for (int base = 0; base < len; base += 64) {
+    const int e = base + lane;
+    const bool valid = e < len;
+    const int c = valid ? a.idx[beg + e] : 0;
+    const double av = valid ? a.vals[beg + e] : 0.0;
+    int did = 0;
+    if constexpr (loss_mode(LOSS) == 2) did = valid ? (int)a.descid[beg + e] : 0;
+    const int tl = valid ? c / tile : 0x7FFFFFFF;
+    int prev = __shfl_up(tl, 1, 64);
+    if (lane == 0) prev = prevtile;
+    const unsigned long long bm = __ballot(valid && tl != prev); // entries that open a window
+    const unsigned long long mine = bm & upto;
+    const int wstart = mine ? base + 63 - __clzll((long long)mine) : wfirst;
+    const int par = (e - wstart) & 1;
+    double L = 0.0;
+    if (valid) {
+      const double2* yp = reinterpret_cast<const double2*>(a.other + (int64_t)c * KP);
+      double2 y[C];
+#pragma unroll
+      for (int i = 0; i < C; ++i) y[i] = yp[i ^ p];
+      double uA = 0.0, uB = 0.0;
+#pragma unroll
+      for (int i = 0; i < C; i += 2) {
+        uA = fma(x[i].x, y[i].x, uA);
+        uA = fma(x[i].y, y[i].y, uA);
+        uB = fma(x[i + 1].x, y[i + 1].x, uB);
+        uB = fma(x[i + 1].y, y[i + 1].y, uB);
+      }
+      const double dot = uA + uB;
+      double dL;
+      if constexpr (LOSS == 0) {
+        const double dq = dot - av;
+        L = segloss.scale * (dq * dq);
+      } else if constexpr (loss_mode(LOSS) == 1) {
+        loss_both<false, loss_trig(LOSS)>(segloss, dot, av, L, dL);
+      } else {
+        loss_both<false, loss_trig(LOSS)>(load_loss(a.udesc, did), dot, av, L, dL);
+      }
+    }
+    const unsigned long long em = __ballot(valid && par == 0), om = __ballot(valid && par == 1);
+    if (valid) {
+      if (par) obuf[wv][no + __popcll(om & below)] = L;
+      else ebuf[wv][ne + __popcll(em & below)] = L;
+    }
+    ne += __popcll(em);
+    no += __popcll(om);
+    if (bm) wfirst = base + 63 - __clzll((long long)bm);
+    const int lastl = len - base - 1 < 63 ? len - base - 1 : 63;
+    prevtile = __shfl(tl, lastl, 64);
+  }
+  __threadfence_block();
+  double J = 0.0;
+  if (lane == 0) for (int i = 0; i < ne; ++i) J += ebuf[wv][i];
+  if (lane == 1) for (int i = 0; i < no; ++i) J += obuf[wv][i];
+  const double J1 = __shfl(J, 1, 64);
+  if (lane == 0) a.part[((int64_t)seg * a.nsup) * PSTRIDE + KP] = J + J1;
+}
+
 // ---- the SELL layout (built once per side at finalize) -------------------------------------------------------------------------
 
 // steps of (wave block, tile) = the longest run of the block's 64 segments inside the tile; one 64-thread workgroup per wave block

@@ -589,10 +589,13 @@ def test_lane_trial_rounds_give_the_same_bits_in_every_form(monkeypatch, mixed):
         # the COMPACT form of the stream (2-byte offsets padded, values unpadded: what views beyond 2e9 observations run) on every side it
         # serves -- both views of the QuadLoss model, the column view of the model with a loss per column; its rounds: full grid / CSR
         "compact stream": {"GLRM_HIP_LANE_COMPACT": "1"},
+        # every round after the first (and a first trial of few rows) of the ROW side on the tail kernel: a wave per row, no tile
+        "a wave per row": {"GLRM_HIP_LANE_TAIL": "101"},
+        "no tail kernel": {"GLRM_HIP_LANE_TAIL": "0"},
     }
     res = {}
     for name, env in forms.items():
-        for key in ("GLRM_HIP_LANE_ROUNDS", "GLRM_HIP_LANE_GATHER_TO", "GLRM_HIP_LANE_GATHER_PACKED", "GLRM_HIP_LANE_GATHER_SPREAD", "GLRM_HIP_LANE_COMPACT"):
+        for key in ("GLRM_HIP_LANE_ROUNDS", "GLRM_HIP_LANE_GATHER_TO", "GLRM_HIP_LANE_GATHER_PACKED", "GLRM_HIP_LANE_GATHER_SPREAD", "GLRM_HIP_LANE_COMPACT", "GLRM_HIP_LANE_TAIL"):
             monkeypatch.delenv(key, raising=False)
         for key, v in env.items():
             monkeypatch.setenv(key, v)
