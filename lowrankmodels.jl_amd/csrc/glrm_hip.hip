@@ -1285,7 +1285,12 @@ int glrm_arrival_wait(glrm_handle* h, int64_t lo, int64_t hi) {
 }
 
 int glrm_for_sup_runs_in_arrival_order(glrm_handle* h, int nsup, int64_t rows_per_sup, const std::function<int(int, int)>& launch) {
-  if (!h->arrival || h->n_arrival <= 0 || nsup <= 1) return launch(0, nsup);
+  if (!h->arrival || h->n_arrival <= 0) return launch(0, nsup);
+  if (nsup <= 1) { // one super-tile reads every row: behind ALL announced blocks (before session r6_69 it was launched without any wait --
+                   // problems of at most one tile of rows on several shards raced with the exchange: tests/perf/soak_lane_shards.py, seed 5004)
+    const int rc = glrm_arrival_wait(h, 0, h->m);
+    return rc ? rc : launch(0, nsup);
+  }
   // need[s] = the LAST announced block super-tile s touches: the run of super-tiles that become complete with block b is launched behind b
   std::vector<int> need((size_t)nsup, -1);
   for (int s = 0; s < nsup; ++s) {

@@ -69,10 +69,11 @@ int launch_lane_loss(int loss, const TiledArgs& a, const LaneArgs& la, int64_t n
   }
 }
 
-// a wave per segment, no tile: the tail rounds of a side with one super-tile (glrm_lane.hpp: lane_tail_kernel)
-constexpr int LANE_TAIL_CAP = 2048; // entries of a segment it parks in LDS
-int launch_lane_tail(int loss, const TiledArgs& a, const int32_t* list, int nact, hipStream_t st) {
+// a wave per (segment, super-tile), no tile: the tail rounds (glrm_lane.hpp: lane_tail_kernel)
+constexpr int LANE_TAIL_CAP = 2048; // terms it parks in LDS at a time
+int launch_lane_tail(int loss, const TiledArgs& a, const int32_t* list, int64_t nact, hipStream_t st) {
   constexpr int KP = 32, T = lane_tile_rows(KP);
+  nact *= a.nsup; // waves of the round
   const unsigned gx = (unsigned)((nact + 1) / 2);
   switch (loss) {
     case LOSS_QUAD_UNIFORM: hipLaunchKernelGGL((lane_tail_kernel<KP, 0, LANE_TAIL_CAP>), dim3(gx), dim3(128), 0, st, a, list, nact, T); break;
@@ -316,12 +317,11 @@ int glrm_run_lane(glrm_handle* h, bool rows, int loss, const TiledArgs& a_in, do
     // cover.  C5 recipe, 1M rows, X half-step (profiles/r06_c5family_lane_rounds_trace.txt): full grid 9.85 ms; gathered 7.8 ms at 55 %,
     // 5.4 at 32 %, 3.1 at 12 %, 1.5-2.1 for the tails.
     const int64_t pct = (int64_t)nact * 100 / (full.nseg > 0 ? full.nseg : 1);
-    // Tail rounds of a side with one super-tile whose segments fit the kernel's LDS parking (rows of up to 2 048 observations): a wave per
-    // segment instead of a lane's serial walk through every tile (1.5-9 ms per round at C5's stated size, eight to ten of them per X
-    // half-step) -- below GLRM_HIP_LANE_TAIL percent of the segments
-    if (lists && full.nsup == 1 && (rows ? h->sig.max_row_len : h->sig.max_col_len) <= LANE_TAIL_CAP && (int64_t)nact * 100 < full.nseg * (int64_t)env_int("GLRM_HIP_LANE_TAIL", 5)) {
+    // Tail rounds: a wave per (segment, super-tile) instead of a lane's serial walk through every tile (rows: 1.5-9 ms per round at C5's stated
+    // size, eight to ten of them per X half-step) -- below GLRM_HIP_LANE_TAIL / GLRM_HIP_LANE_TAIL_COLS percent of the segments
+    if (lists && (int64_t)nact * 100 < full.nseg * (int64_t)(full.nsup == 1 ? env_int("GLRM_HIP_LANE_TAIL", 5) : env_int("GLRM_HIP_LANE_TAIL_COLS", 3))) {
       if (trace >= 2) fprintf(stderr, "[glrm lane] %s round %d: %u of %lld segments search: a wave per segment\n", rows ? "row" : "column", round, nact, (long long)full.nseg);
-      if ((rc = launch_lane_tail(loss, full, list[cur], (int)nact, st))) return rc;
+      if ((rc = launch_lane_tail(loss, full, list[cur], (int64_t)nact, st))) return rc;
       d.actlist_in = list[cur];
       d.actlist_out = list[cur ^ 1];
       d.nact_in = nact;

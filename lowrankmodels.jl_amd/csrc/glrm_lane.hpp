@@ -429,20 +429,22 @@ __global__ void __launch_bounds__(NW * 64, 1) lane_pass_kernel(const TiledArgs a
   }
 }
 
-// ---- tail rounds of a side with ONE super-tile (rows): a wave per segment, no tile ---------------------------------------------------
+// ---- tail rounds: a wave per (segment, super-tile), no tile ---------------------------------------------------------------------------
 // A trial round over a few segments still pays a lane's serial walk through every tile of the opposing factor (~1.5 ms for a row of C5
-// whatever the number of rows, 8-10 such rounds per X half-step).  Here a WAVE takes one segment: lane l evaluates the entries l, l + 64, ...
-// of its list with the vectors read straight from memory -- the same two fma chains over the chunks i ^ p, the same loss formula, so the same
-// term bit for bit -- and the terms are then added as the passes add them: two sequential sums over the entries at even / odd position inside
-// their tile window, in list order (the terms are parked in LDS, compacted by parity; lanes 0 and 1 run the two chains).
+// whatever the number of rows, 8-10 such rounds per X half-step).  Here a WAVE takes one segment's entries inside one super-tile: lane l
+// evaluates the entries l, l + 64, ... with the vectors read straight from memory -- the same two fma chains over the chunks i ^ p, the same
+// loss formula, so the same term bit for bit -- and the terms are then added as the passes add them: two sequential sums over the entries at
+// even / odd position inside their tile window, in list order (the terms are parked in LDS, compacted by parity, CAP at a time; lanes 0 and 1
+// run the two chains), one partial per (segment, super-tile) like the passes'.
 template <int KP, int LOSS, int CAP>
-__global__ void __launch_bounds__(128) lane_tail_kernel(const TiledArgs a, const int32_t* __restrict__ list, int nact, int tile) {
-  constexpr int C = KP / 2, PSTRIDE = KP + 2;
-  __shared__ double ebuf[2][CAP], obuf[2][CAP / 2 + 32];
+__global__ void __launch_bounds__(128) lane_tail_kernel(const TiledArgs a, const int32_t* __restrict__ list, int64_t nwork, int tile) {
+  constexpr int C = KP / 2, PSTRIDE = KP + 2, OCAP = CAP / 2 + 64;
+  __shared__ double ebuf[2][CAP], obuf[2][OCAP];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int w = (int)blockIdx.x * 2 + wv;
-  if (w >= nact) return; // (wave-uniform)
-  const int64_t seg = list[w];
+  const int64_t w = (int64_t)blockIdx.x * 2 + wv;
+  if (w >= nwork) return; // (wave-uniform)
+  const int64_t seg = list[w / a.nsup];
+  const int sup = (int)(w % a.nsup);
   const int64_t gseg = a.own_offset + seg;
   const int p = (int)(gseg & (C - 1));
   const double2* xp = reinterpret_cast<const double2*>(a.trial + seg * (int64_t)KP);
@@ -451,12 +453,29 @@ __global__ void __launch_bounds__(128) lane_tail_kernel(const TiledArgs a, const
   for (int i = 0; i < C; ++i) x[i] = xp[i ^ p];
   LossDesc segloss = LossDesc{0, 1.0, 0.0, 0.0};
   if constexpr (loss_mode(LOSS) != 2) segloss = load_loss(a.losses, a.loss_by_segment ? gseg : 0);
-  const int64_t beg = a.ptr[seg];
-  const int len = (int)(a.ptr[seg + 1] - beg);
+  int64_t beg = a.ptr[seg], end = a.ptr[seg + 1];
+  if (a.nsup > 1) { // the segment's entries inside this super-tile
+    const int64_t lo = (int64_t)sup * a.tiles_per_sup * tile, hi = lo + (int64_t)a.tiles_per_sup * tile;
+    const int64_t b0 = lower_bound_idx<1>(a.idx, beg, end, lo);
+    end = lower_bound_idx<1>(a.idx, b0, end, hi);
+    beg = b0;
+  }
+  const int64_t len = end - beg;
   const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane)), upto = below | (1ull << lane);
-  int ne = 0, no = 0, wfirst = 0, prevtile = -1; // entries parked so far by parity; first entry of the window in progress; tile of the entry before the batch
-  for (int base = 0; base < len; base += 64) {
-    const int e = base + lane;
+  int ne = 0, no = 0, prevtile = -1; // terms parked by parity; tile of the entry before the batch
+  int64_t wfirst = 0;                // first entry of the window in progress
+  double J = 0.0;                    // lane 0: the sum over even positions, lane 1: over odd ones
+  auto flush = [&]() {
+    __threadfence_block();
+    if (lane == 0) for (int i = 0; i < ne; ++i) J += ebuf[wv][i];
+    if (lane == 1) for (int i = 0; i < no; ++i) J += obuf[wv][i];
+    __threadfence_block();
+    ne = 0;
+    no = 0;
+  };
+  for (int64_t base = 0; base < len; base += 64) {
+    if (ne + 64 > CAP || no + 64 > OCAP) flush();
+    const int64_t e = base + lane;
     const bool valid = e < len;
     const int c = valid ? a.idx[beg + e] : 0;
     const double av = valid ? a.vals[beg + e] : 0.0;
@@ -467,8 +486,8 @@ __global__ void __launch_bounds__(128) lane_tail_kernel(const TiledArgs a, const
     if (lane == 0) prev = prevtile;
     const unsigned long long bm = __ballot(valid && tl != prev); // entries that open a window
     const unsigned long long mine = bm & upto;
-    const int wstart = mine ? base + 63 - __clzll((long long)mine) : wfirst;
-    const int par = (e - wstart) & 1;
+    const int64_t wstart = mine ? base + 63 - __clzll((long long)mine) : wfirst;
+    const int par = (int)((e - wstart) & 1);
     double L = 0.0;
     if (valid) {
       const double2* yp = reinterpret_cast<const double2*>(a.other + (int64_t)c * KP);
@@ -502,15 +521,12 @@ __global__ void __launch_bounds__(128) lane_tail_kernel(const TiledArgs a, const
     ne += __popcll(em);
     no += __popcll(om);
     if (bm) wfirst = base + 63 - __clzll((long long)bm);
-    const int lastl = len - base - 1 < 63 ? len - base - 1 : 63;
-    prevtile = __shfl(tl, lastl, 64);
+    const int64_t left = len - base - 1;
+    prevtile = __shfl(tl, (int)(left < 63 ? left : 63), 64);
   }
-  __threadfence_block();
-  double J = 0.0;
-  if (lane == 0) for (int i = 0; i < ne; ++i) J += ebuf[wv][i];
-  if (lane == 1) for (int i = 0; i < no; ++i) J += obuf[wv][i];
+  flush();
   const double J1 = __shfl(J, 1, 64);
-  if (lane == 0) a.part[((int64_t)seg * a.nsup) * PSTRIDE + KP] = J + J1;
+  if (lane == 0) a.part[((int64_t)seg * a.nsup + sup) * PSTRIDE + KP] = J + J1;
 }
 
 // ---- the SELL layout (built once per side at finalize) -------------------------------------------------------------------------

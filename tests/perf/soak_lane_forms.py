@@ -26,8 +26,8 @@ FORMS = {
     "compact stream": {"GLRM_HIP_LANE_COMPACT": "1"},
     "compact stream, chunk lists": {"GLRM_HIP_LANE_COMPACT": "1", "GLRM_HIP_LANE_GATHER_TO": "101", "GLRM_HIP_LANE_GATHER_PACKED": "0"},
     "slots not dealt": {"GLRM_HIP_LANE_DEAL": "0"},
-    "a wave per row": {"GLRM_HIP_LANE_TAIL": "101"},
-    "no tail kernel": {"GLRM_HIP_LANE_TAIL": "0"},
+    "a wave per row": {"GLRM_HIP_LANE_TAIL": "101", "GLRM_HIP_LANE_TAIL_COLS": "101"},
+    "no tail kernel": {"GLRM_HIP_LANE_TAIL": "0", "GLRM_HIP_LANE_TAIL_COLS": "0"},
 }
 KEYS = sorted({k for env in FORMS.values() for k in env})
 

@@ -589,13 +589,13 @@ def test_lane_trial_rounds_give_the_same_bits_in_every_form(monkeypatch, mixed):
         # the COMPACT form of the stream (2-byte offsets padded, values unpadded: what views beyond 2e9 observations run) on every side it
         # serves -- both views of the QuadLoss model, the column view of the model with a loss per column; its rounds: full grid / CSR
         "compact stream": {"GLRM_HIP_LANE_COMPACT": "1"},
-        # every round after the first (and a first trial of few rows) of the ROW side on the tail kernel: a wave per row, no tile
-        "a wave per row": {"GLRM_HIP_LANE_TAIL": "101"},
-        "no tail kernel": {"GLRM_HIP_LANE_TAIL": "0"},
+        # every round after the first (and a first trial of few rows) on the tail kernel: a wave per (segment, super-tile), no tile
+        "a wave per row": {"GLRM_HIP_LANE_TAIL": "101", "GLRM_HIP_LANE_TAIL_COLS": "101"},
+        "no tail kernel": {"GLRM_HIP_LANE_TAIL": "0", "GLRM_HIP_LANE_TAIL_COLS": "0"},
     }
     res = {}
     for name, env in forms.items():
-        for key in ("GLRM_HIP_LANE_ROUNDS", "GLRM_HIP_LANE_GATHER_TO", "GLRM_HIP_LANE_GATHER_PACKED", "GLRM_HIP_LANE_GATHER_SPREAD", "GLRM_HIP_LANE_COMPACT", "GLRM_HIP_LANE_TAIL"):
+        for key in ("GLRM_HIP_LANE_ROUNDS", "GLRM_HIP_LANE_GATHER_TO", "GLRM_HIP_LANE_GATHER_PACKED", "GLRM_HIP_LANE_GATHER_SPREAD", "GLRM_HIP_LANE_COMPACT", "GLRM_HIP_LANE_TAIL", "GLRM_HIP_LANE_TAIL_COLS"):
             monkeypatch.delenv(key, raising=False)
         for key, v in env.items():
             monkeypatch.setenv(key, v)
@@ -618,3 +618,61 @@ def test_lane_trial_rounds_give_the_same_bits_in_every_form(monkeypatch, mixed):
         assert np.array_equal(Xf, X) and np.array_equal(Yf, Y), name
         for key in ("trials_x", "trials_y", "accepts_x", "accepts_y"):
             assert stf[key] == st[key], (name, key)
+
+
+@pytest.mark.parametrize("lane", ["0", "3"])
+def test_arrival_order_with_one_super_tile_waits_for_every_block(monkeypatch, lane):
+    """A problem of at most one tile of rows (m <= 560 at rank 32) has ONE super-tile, which reads every row of X: under
+    glrm_hip_step_y_arrival its gradient pass must stand behind ALL announced blocks.  (Session r6_69: it was launched without any wait --
+    found by tests/perf/soak_lane_shards.py, seed 5004: 345 rows on six shards raced with the exchange, in two runs of ten.)  Here the
+    announced blocks really ARRIVE late: their rows of the bound X buffer are zeroed on the launch stream and restored by a side stream that
+    sleeps first and records the block's event afterwards -- a pass that does not wait reads zeros and lands on other bits than glrm_hip_step_y."""
+    import torch
+    monkeypatch.setenv("GLRM_HIP_LANE", lane)
+    m, n, k = 400, 600, 32
+    rowptr, colidx, rowvals, colptr, rowidx, colvals, X0, Y0 = O.synth_cpu(m, n, k, 60, value_model=0)
+    one = np.array([(0, 0, 1.0, 0.0, 0.0)], dtype=_capi.LOSS_DTYPE)
+    reg = np.array([(1, 0, 0.5)], dtype=_capi.REG_DTYPE)
+    pa = _capi.ProblemArrays(m, n, k, rowptr, colidx, rowvals, colptr, rowidx, colvals, one, reg, reg)
+    api = hip()
+    dev = torch.device("cuda", 0)
+    side = torch.cuda.Stream(device=dev)
+    res = {}
+    for arrival in (False, True):
+        h = api.create(pa, stream=torch.cuda.current_stream().cuda_stream, tiled=2, profile=1)
+        try:
+            assert api.kernel_stats(h)["tiled"] & 2
+            ld = api.factor_ld(h)
+            dX, dY = torch.zeros(m * ld, dtype=torch.float64, device=dev), torch.zeros(n * ld, dtype=torch.float64, device=dev)
+            dX.view(m, ld)[:, :k] = torch.as_tensor(np.ascontiguousarray(X0.T), device=dev)
+            dY.view(n, ld)[:, :k] = torch.as_tensor(np.ascontiguousarray(Y0.T), device=dev)
+            dC, dR = torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(m, dtype=torch.float64, device=dev)
+            api.bind_buffers(h, dX.data_ptr(), dY.data_ptr(), dC.data_ptr(), dR.data_ptr())
+            api.reset_stepsizes(h, 1.0)
+            for it in range(2):
+                api.step_x(h, 0.01)
+                if arrival:
+                    blocks, keep = [(100, 200, None)], []
+                    late = ((0, 100), (200, 300), (300, 400))
+                    Xc = dX.clone()
+                    for lo, hi in late:
+                        dX.view(m, ld)[lo:hi] = 0.0          # (on the launch stream: the rows are not there yet)
+                    with torch.cuda.stream(side):
+                        side.wait_stream(torch.cuda.current_stream())
+                        for lo, hi in late:
+                            torch.cuda._sleep(2_000_000)
+                            dX.view(m, ld)[lo:hi] = Xc.view(m, ld)[lo:hi]
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                            keep.append(ev)
+                            blocks.append((lo, hi, ev.cuda_event))
+                    api.step_y_arrival(h, 0.01, blocks)
+                    torch.cuda.current_stream().wait_stream(side)
+                else:
+                    api.step_y(h, 0.01)
+            torch.cuda.synchronize()
+            res[arrival] = (dX.cpu().numpy().copy(), dY.cpu().numpy().copy(), api.kernel_stats(h))
+        finally:
+            api.destroy(h)
+    assert np.array_equal(res[True][0], res[False][0]) and np.array_equal(res[True][1], res[False][1])
+    assert res[False][2]["ms_wait_y"] == 0.0 and res[True][2]["ms_wait_y"] > 0.0
