@@ -34,8 +34,12 @@ KEYS = sorted({k for env in FORMS.values() for k in env})
 
 def problem(seed):
     rng = np.random.default_rng(seed)
-    m = int(rng.integers(300, 40000))
-    n = int(rng.integers(200, 5000))
+    if os.environ.get("SOAK_TINY"):   # shapes around one tile / one wave block / one chunk: shards without rows, single super-tiles
+        m = int(rng.integers(40, 1500))
+        n = int(rng.integers(40, 800))
+    else:
+        m = int(rng.integers(300, 40000))
+        n = int(rng.integers(200, 5000))
     k = 32 if rng.random() < 0.8 else int(rng.integers(17, 33))   # padded rank 32 either way
     skew = rng.random() < 0.5
     dens = rng.uniform(0.004, 0.06)

@@ -1,5 +1,5 @@
 """Soak of the lane-per-segment passes under sharding: the random ragged problems of soak_lane_forms.py, a four-iteration fit on ONE handle
-against the in-library host with 2 .. 6 shards of the same device (row blocks swept in x_chunks sub-ranges: glrm_hip_step_x_range, gathered
+against the in-library host with 2 .. 8 shards of the same device (row blocks swept in x_chunks sub-ranges: glrm_hip_step_x_range, gathered
 rounds on sub-ranges; column blocks with their own class offsets) -- the same bits for every shard count.
 
     python tests/perf/soak_lane_shards.py FIRST_SEED LAST_SEED
@@ -34,9 +34,9 @@ def main():
             o1, _ = api.fit(h, prm, X1, Y1)
         finally:
             api.destroy(h)
-        for n in sorted(set(int(v) for v in rng.integers(2, 7, size=2))):
+        for n in sorted(set(int(v) for v in rng.integers(2, 9, size=2))):
             chunks = int(rng.integers(0, 5))
-            mh = api.multi_create(pa, n, device_ids=[0] * n, x_chunks=chunks, tiled=2, arrival=int(rng.integers(0, 2)))
+            mh = api.multi_create(pa, n, device_ids=[0] * n, x_chunks=chunks, tiled=2, arrival=int(rng.integers(0, 3)))
             try:
                 X, Y = X0.copy(order="F"), Y0.copy(order="F")
                 o, _ = api.multi_fit(mh, prm, X, Y)
