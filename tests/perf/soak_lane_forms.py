@@ -41,6 +41,8 @@ def problem(seed):
         m = int(rng.integers(300, 40000))
         n = int(rng.integers(200, 5000))
     k = 32 if rng.random() < 0.8 else int(rng.integers(17, 33))   # padded rank 32 either way
+    if os.environ.get("SOAK_RANK"):
+        k = int(os.environ["SOAK_RANK"])
     skew = rng.random() < 0.5
     dens = rng.uniform(0.004, 0.06)
     if skew:   # power-law row degrees and column popularities

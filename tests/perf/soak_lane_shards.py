@@ -21,13 +21,14 @@ from soak_lane_forms import problem  # noqa: E402
 
 def main():
     first, last = int(sys.argv[1]), int(sys.argv[2])
+    tiled = int(os.environ.get("SOAK_TILED", "2"))   # 2: LDS tiles (the lane family at rank 32); 1: gather sweeps; 0: the engine's own choice
     api = _capi.hip_api()
     bad = 0
     for seed in range(first, last):
         pa, X0, Y0, info = problem(seed)
         rng = np.random.default_rng(10_000_000 + seed)
         prm = L.ProxGradParams(stepsize=[1.0, 64.0, 4096.0][seed % 3], max_iter=4, abs_tol=-1e300, rel_tol=-1e300)
-        h = api.create(pa, tiled=2)
+        h = api.create(pa, tiled=tiled)
         try:
             flags = api.kernel_stats(h)["tiled"]
             X1, Y1 = X0.copy(order="F"), Y0.copy(order="F")
@@ -36,7 +37,7 @@ def main():
             api.destroy(h)
         for n in sorted(set(int(v) for v in rng.integers(2, 9, size=2))):
             chunks = int(rng.integers(0, 5))
-            mh = api.multi_create(pa, n, device_ids=[0] * n, x_chunks=chunks, tiled=2, arrival=int(rng.integers(0, 3)))
+            mh = api.multi_create(pa, n, device_ids=[0] * n, x_chunks=chunks, tiled=tiled, arrival=int(rng.integers(0, 3)))
             try:
                 X, Y = X0.copy(order="F"), Y0.copy(order="F")
                 o, _ = api.multi_fit(mh, prm, X, Y)
